@@ -1,0 +1,225 @@
+"""Generate golden vectors by importing the REFERENCE modules (build container only).
+
+    python tests/golden/make_golden.py
+
+Imports /root/reference/mega_core/... under tests/golden/_ref_shims.py, runs the reference's
+own classes/functions on seeded inputs and stores inputs + state_dict + outputs as small
+fp32 .npz fixtures next to this file.  Only data is stored -- no reference source.
+tests/test_oracle_golden.py checks oracle/ against these files (CPU, no reference needed).
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_shims as S  # noqa: E402
+
+S.install()
+
+import torch  # noqa: E402
+
+from mega_core.modeling.detector import diffusion_det as DD  # noqa: E402
+from mega_core.modeling.roi_heads.box_head import box_head as BH  # noqa: E402
+from mega_core.modeling.roi_heads.box_head.roi_box_feature_extractors import getGreedyPerm  # noqa: E402
+from mega_core.structures.bounding_box import BoxList  # noqa: E402
+from mega_core.structures.image_list import to_image_list  # noqa: E402
+
+RED = dict(hidden=16, nheads=2, dim_ff=32, dim_dynamic=4, num_classes=30, num_proposals=100)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items() if not k.startswith("sd.")})
+
+
+def sd_arrays(module, prefix="sd."):
+    return {prefix + k: v for k, v in module.state_dict().items()}
+
+
+def randomize_norms(module, gen):
+    """LayerNorm affine params away from (1,0) so that a restatement which ignores them fails."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.LayerNorm):
+            m.weight.data.uniform_(0.5, 1.5, generator=gen)
+            m.bias.data.uniform_(-0.3, 0.3, generator=gen)
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.in_proj_bias.data.uniform_(-0.2, 0.2, generator=gen)
+            m.out_proj.bias.data.uniform_(-0.2, 0.2, generator=gen)
+
+
+def g1_schedule():
+    betas = DD.cosine_beta_schedule(1000)
+    alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).to(torch.float32)   # diffusion_det.py:226-228
+    save("g1_schedule", betas=betas, alphas_cumprod=alphas_cumprod)
+
+
+def make_head(sample_step=1, seed=0):
+    cfg = S.head_cfg(sample_step=sample_step, **RED)
+    shape = {k: SimpleNamespace(stride=s, channels=RED["hidden"]) for k, s in zip(["p3", "p4", "p5"], [8, 16, 32])}
+    torch.manual_seed(seed)
+    h = BH.DynamicHead(cfg, shape).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    randomize_norms(h, g)
+    return h, cfg
+
+
+def make_inputs(seed, n_frames=2, hw=(128, 192)):
+    g = torch.Generator().manual_seed(seed)
+    H, W = hw
+    d = RED["hidden"]
+    feats = [torch.randn(n_frames, d, H // s, W // s, generator=g) for s in (8, 16, 32)]
+    M = RED["num_proposals"]
+    # boxes of widely varying size so all three pyramid levels (and out-of-image taps) are hit
+    cxcy = torch.rand(n_frames, M, 2, generator=g) * torch.tensor([W, H]) * 1.2 - torch.tensor([W, H]) * 0.1
+    wh = torch.exp(torch.rand(n_frames, M, 2, generator=g) * 5.0 + 0.5)
+    boxes = torch.cat([cxcy - wh / 2, cxcy + wh / 2], dim=-1)
+    boxes[0, 0] = torch.tensor([10.0, 10.0, 10.0, 10.0])        # zero-area box
+    boxes[0, 1] = torch.tensor([-50.0, -40.0, 400.0, 300.0])    # larger than the image
+    return feats, boxes, g
+
+
+def g2_time_mlp(h):
+    t = torch.tensor([999, 749, 499, 249], dtype=torch.long)
+    with torch.no_grad():
+        emb = BH.SinusoidalPositionEmbeddings(256)(t)
+        out = h.time_mlp(t)
+    save("g2_time_mlp", t=t, sinusoidal256=emb, out=out,
+         **{"sd.head." + k: v for k, v in h.state_dict().items() if k.startswith("time_mlp")})
+
+
+def g3_dynamic_conv(h):
+    g = torch.Generator().manual_seed(30)
+    R, d = 12, RED["hidden"]
+    dc = h.head_series[0].inst_interact
+    pro = torch.randn(1, R, d, generator=g)
+    roi = torch.randn(49, R, d, generator=g)
+    with torch.no_grad():
+        out = dc(pro, roi)
+    save("g3_dynamic_conv", pro=pro, roi=roi, out=out, **sd_arrays(dc, "sd.dc."))
+
+
+def g4_rcnn_head(h):
+    feats, boxes, g = make_inputs(40)
+    t = torch.tensor([999, 499], dtype=torch.long)
+    with torch.no_grad():
+        time = h.time_mlp(t)
+        head0 = h.head_series[0]
+        cl0, bx0, of0 = head0(feats, boxes, None, h.box_pooler, time)          # pro_features None branch
+        head1 = h.head_series[1]
+        cl1, bx1, of1 = head1(feats, bx0, of0, h.box_pooler, time)
+        cond = torch.randn(boxes.shape[0] * boxes.shape[1], RED["hidden"], generator=g)
+        hc = h.head_series_cond[0]
+        cl2, bx2, of2 = hc(feats, bx1, of1, h.box_pooler, time, cond)
+    save("g4_rcnn_head", p3=feats[0], p4=feats[1], p5=feats[2], boxes=boxes, time=time, cond=cond,
+         cl0=cl0, bx0=bx0, of0=of0, cl1=cl1, bx1=bx1, of1=of1, cl2=cl2, bx2=bx2, of2=of2,
+         **sd_arrays(h, "sd.head."))
+
+
+def g5_dynamic_head(h):
+    feats, boxes, g = make_inputs(50)
+    t = torch.full((2,), 999, dtype=torch.long)
+    d = RED["hidden"]
+    with torch.no_grad():
+        (cl, bx, pf), k1, k2 = h(feats, boxes, t, None, box_extract=1)
+        mem0 = torch.randn(37, d, generator=g)
+        mem1 = torch.randn(11, d, generator=g)
+        h.proposal_feats_global = [mem0, mem1]
+        h.proposal_feats_local = [None, None]
+        h.proposals_feat_cur = [[cl.clone(), bx.clone(), pf.clone()]]
+        fc, fb = h(feats, boxes, t, None)                                        # x1: pop cached stages
+        h4, _ = make_head(sample_step=4)
+        h4.load_state_dict(h.state_dict())
+        h4.proposal_feats_global = [mem0, mem1]
+        h4.proposal_feats_local = [None, None]
+        t4 = torch.full((2,), 749, dtype=torch.long)
+        fc4, fb4 = h4(feats, boxes, t4, None)                                    # x4: recompute stages
+    save("g5_dynamic_head", p3=feats[0], p4=feats[1], p5=feats[2], boxes=boxes, t=t, t4=t4,
+         ext_logits=cl, ext_boxes=bx, ext_feats=pf, ext_k1=k1, ext_k2=k2, mem0=mem0, mem1=mem1,
+         fin_logits=fc, fin_boxes=fb, fin4_logits=fc4, fin4_boxes=fb4, **sd_arrays(h, "sd.head."))
+
+
+def g6_noise_transforms():
+    g = torch.Generator().manual_seed(60)
+    betas = DD.cosine_beta_schedule(1000)
+    ac = torch.cumprod(1.0 - betas, dim=0).to(torch.float32)
+    obj = SimpleNamespace(scale=2.0,
+                          sqrt_recip_alphas_cumprod=torch.sqrt(1.0 / ac),
+                          sqrt_recipm1_alphas_cumprod=torch.sqrt(1.0 / ac - 1))
+    obj.predict_noise_from_start = lambda x_t, t, x0: DD.DiffusionDet.predict_noise_from_start(obj, x_t, t, x0)
+    B, M = 3, 20
+    x = torch.randn(B, M, 4, generator=g) * 1.5
+    whwh = torch.tensor([[1000.0, 600.0, 1000.0, 600.0]]).repeat(B, 1)
+    t = torch.tensor([999, 749, 249], dtype=torch.long)
+    head_boxes = torch.rand(1, B, M, 4, generator=g) * 500
+    head_boxes[..., 2:] += head_boxes[..., :2]
+    seen = {}
+
+    def fake_head(feats, x_boxes, t_, init, box_extract=0):
+        seen["x_boxes"] = x_boxes.clone()
+        return torch.zeros(1, B, M, 30), head_boxes
+
+    fake_head.use_topk = False
+    obj.head = fake_head
+    preds, _, _ = DD.DiffusionDet.model_predictions(obj, None, whwh, x, t, None, clip_x_start=True)
+    save("g6_noise_transforms", x=x, whwh=whwh, t=t, head_boxes=head_boxes, x_boxes=seen["x_boxes"],
+         pred_noise=preds.pred_noise, x_start=preds.pred_x_start)
+
+
+def g7_greedy_perm():
+    g = torch.Generator().manual_seed(70)
+    f = torch.randn(64, 8, generator=g)
+    D = torch.cdist(f, f, p=2.0)
+    perm = getGreedyPerm(D, 24, 0)
+    # duplicate-feature case: exact ties at distance 0 once every distinct point is taken
+    f2 = torch.randn(10, 8, generator=g).repeat(3, 1)
+    D2 = torch.cdist(f2, f2, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
+    perm2 = getGreedyPerm(D2, 14, 0)
+    save("g7_greedy_perm", D=D, perm=perm, D2=D2, perm2=perm2)
+
+
+def g9_structures():
+    g = torch.Generator().manual_seed(90)
+    b = torch.rand(12, 4, generator=g) * 1400 - 200
+    bl = BoxList(b.clone(), (1000, 600), mode="xyxy").clip_to_image(remove_empty=False)
+    img = torch.rand(3, 50, 70, generator=g)
+    il = to_image_list((img,), 32)
+    save("g9_structures", boxes=b, clipped=bl.bbox, img=img, padded=il.tensors,
+         image_size=np.array(il.image_sizes[0]))
+
+
+def g10_sampler():
+    from mega_core.data.samplers.distributed import VIDTestDistributedSampler
+    ds = type("FakeDS", (), {"start_index": [0, 30, 75, 100, 160], "__len__": lambda self: 200})()
+    parts = []
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            s = VIDTestDistributedSampler(ds, num_replicas=world, rank=rank)
+            # find_zero returns None when no video starts at/after the offset
+            # (samplers/distributed.py:89-95); stored as -1 (= python slice default)
+            parts.append([world, rank, -1 if s.start is None else s.start, -1 if s.end is None else s.end])
+    save("g10_sampler", start_index=np.array(ds.start_index), length=np.array(200),
+         parts=np.array(parts, dtype=np.int64))
+
+
+if __name__ == "__main__":
+    # The reference targets torch 1.8 (INSTALL.md:3-13) where nn.MultiheadAttention.forward IS
+    # F.multi_head_attention_forward; keep torch 2.x's fused inference fast path out of the goldens.
+    torch.backends.mha.set_fastpath_enabled(False)
+    g1_schedule()
+    h, _ = make_head()
+    g2_time_mlp(h)
+    g3_dynamic_conv(h)
+    g4_rcnn_head(h)
+    g5_dynamic_head(h)
+    g6_noise_transforms()
+    g7_greedy_perm()
+    g9_structures()
+    g10_sampler()
