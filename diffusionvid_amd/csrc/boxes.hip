@@ -1,0 +1,124 @@
+// Small box-space kernels: noise->boxes (diffusion_det.py:657-660), apply_deltas
+// (box_head.py:550-590), top-75/25 memory-feature selection (box_head.py:304-317),
+// x_start / pred_noise (diffusion_det.py:649-653, :666-672) and the DDIM + box-renewal step
+// (diffusion_det.py:559-596).  fp32 throughout; no host synchronisation.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__global__ void noise_to_boxes_kernel(const float* __restrict__ x, float* __restrict__ boxes, int n, float scale, float w, float h) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4v v = *reinterpret_cast<const float4v*>(x + i * 4);
+    float c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = ((fminf(fmaxf(v[e], -scale), scale) / scale) + 1.f) / 2.f;
+    float4v o;
+    o[0] = (c[0] - 0.5f * c[2]) * w;
+    o[1] = (c[1] - 0.5f * c[3]) * h;
+    o[2] = (c[0] + 0.5f * c[2]) * w;
+    o[3] = (c[1] + 0.5f * c[3]) * h;
+    *reinterpret_cast<float4v*>(boxes + i * 4) = o;
+}
+
+__global__ void apply_deltas_kernel(const float* __restrict__ deltas, int delta_ld, const float* __restrict__ boxes,
+                                    float* __restrict__ out, int n, float wx, float wy, float ww, float wh, float clamp,
+                                    int* __restrict__ bad_flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4v b = *reinterpret_cast<const float4v*>(boxes + i * 4);
+    const float* d = deltas + (long)i * delta_ld;
+    const float widths = b[2] - b[0], heights = b[3] - b[1];
+    const float ctr_x = b[0] + 0.5f * widths, ctr_y = b[1] + 0.5f * heights;
+    const float dx = d[0] / wx, dy = d[1] / wy;
+    const float dw = fminf(d[2] / ww, clamp), dh = fminf(d[3] / wh, clamp);
+    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+    const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+    float4v o;
+    o[0] = pcx - 0.5f * pw;
+    o[1] = pcy - 0.5f * ph;
+    o[2] = pcx + 0.5f * pw;
+    o[3] = pcy + 0.5f * ph;
+    *reinterpret_cast<float4v*>(out + i * 4) = o;
+    // box_head.py:588 `assert (pred_boxes[:, 2:] >= pred_boxes[:, :2]).all()` without a host sync
+    if (bad_flag && !(o[2] >= o[0] && o[3] >= o[1])) atomicOr(bad_flag, 1);
+}
+
+// One workgroup per frame.  rank by (max logit desc, index asc); emit rows of the top-k1 / top-k2
+// sets in ascending box-index order ("mask order", box_head.py:315-317).
+__global__ __launch_bounds__(256) void topk_mask_kernel(const float* __restrict__ logits, int m, int c, int k1, int k2,
+                                                         const float* __restrict__ feats, int d, float* __restrict__ out1,
+                                                         float* __restrict__ out2) {
+    extern __shared__ float sm[];
+    float* val = sm;                                   // [m]
+    int* sel1 = reinterpret_cast<int*>(sm + m);        // [m] output slot or -1
+    int* sel2 = sel1 + m;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < m; i += blockDim.x) {
+        const float* lp = logits + ((long)f * m + i) * c;
+        float mx = lp[0];
+        for (int j = 1; j < c; ++j) mx = fmaxf(mx, lp[j]);
+        val[i] = mx;
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += blockDim.x) {
+        const float vi = val[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) {
+            const float vj = val[j];
+            rank += (vj > vi) || (vj == vi && j < i);
+        }
+        sel1[i] = rank < k1;
+        sel2[i] = rank < k2;
+    }
+    __syncthreads();
+    if (tid == 0) {  // m <= ~1000: a serial exclusive scan is negligible here
+        int p1 = 0, p2 = 0;
+        for (int i = 0; i < m; ++i) {
+            const int s1 = sel1[i], s2 = sel2[i];
+            sel1[i] = s1 ? p1 : -1;
+            sel2[i] = s2 ? p2 : -1;
+            p1 += s1;
+            p2 += s2;
+        }
+    }
+    __syncthreads();
+    const int dv = d >> 2;
+    for (int i = tid; i < m * dv; i += blockDim.x) {
+        const int row = i / dv, v = i - row * dv;
+        const int s1 = sel1[row], s2 = sel2[row];
+        if (s1 < 0) continue;
+        const float4v x = *reinterpret_cast<const float4v*>(feats + ((long)f * m + row) * d + v * 4);
+        *reinterpret_cast<float4v*>(out1 + ((long)f * k1 + s1) * d + v * 4) = x;
+        if (s2 >= 0) *reinterpret_cast<float4v*>(out2 + ((long)f * k2 + s2) * d + v * 4) = x;
+    }
+}
+
+}  // namespace
+
+int dvid_noise_to_boxes_launch(const float* x, float* boxes, int n, float scale, float w, float h, hipStream_t s) {
+    if (n == 0) return DVID_OK;
+    hipLaunchKernelGGL(noise_to_boxes_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, x, boxes, n, scale, w, h);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_apply_deltas_launch(const float* deltas, int delta_ld, const float* boxes, float* out, int n, float wx, float wy, float ww,
+                             float wh, float clamp, int* bad_flag, hipStream_t s) {
+    if (n == 0) return DVID_OK;
+    hipLaunchKernelGGL(apply_deltas_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, deltas, delta_ld, boxes, out, n, wx, wy, ww, wh,
+                       clamp, bad_flag);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_topk_mask_launch(const float* logits, int n_img, int m, int c, int k1, int k2, const float* feats, int d, float* out1,
+                          float* out2, hipStream_t s) {
+    if (n_img == 0) return DVID_OK;
+    if (d % 4 || k2 > k1 || k1 > m) return DVID_ERR_ARG;
+    const size_t smem = (size_t)m * 12;
+    hipLaunchKernelGGL(topk_mask_kernel, dim3(n_img), dim3(256), smem, s, logits, m, c, k1, k2, feats, d, out1, out2);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}

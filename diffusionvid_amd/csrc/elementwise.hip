@@ -1,0 +1,252 @@
+// HBM-bound row / pixel kernels: image prep, max-pool, layout converts, fused
+// residual+LayerNorm, time/cond modulation, SiLU.  All loads/stores are 8-16 bytes per lane.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// fp32 NCHW [n,3,h,w] in [0,1] -> normalised fp16 NHWC8 (channels 3..7 zero).
+// diffusion_det.py:301-303 normalizer fused with the layout change the stem conv wants.
+__global__ void prep_images_kernel(const float* __restrict__ in, half_t* __restrict__ out, long npix, long hw, float m0, float m1,
+                                   float m2, float s0, float s1, float s2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const long img = i / hw, pix = i - img * hw;
+    const float* p = in + img * 3 * hw + pix;
+    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    v[0] = (half_t)((p[0] - m0) * s0);
+    v[1] = (half_t)((p[hw] - m1) * s1);
+    v[2] = (half_t)((p[2 * hw] - m2) * s2);
+    *reinterpret_cast<half8*>(out + i * 8) = v;
+}
+
+// 3x3 stride-2 pad-1 max pool, NHWC fp16, one lane per 8-channel vector of an output pixel.
+__global__ void maxpool_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int n, int h, int w, int c, int ho, int wo) {
+    const int cv = c >> 3;
+    const long total = (long)n * ho * wo * cv;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int v = i % cv;
+    long t = i / cv;
+    const int ox = t % wo;
+    t /= wo;
+    const int oy = t % ho;
+    const int img = t / ho;
+    float best[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox * 2 - 1 + dx;
+            if ((unsigned)ix >= (unsigned)w) continue;
+            const half8 x = *reinterpret_cast<const half8*>(in + (((long)img * h + iy) * w + ix) * c + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], (float)x[e]);
+        }
+    }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)best[e];
+    *reinterpret_cast<half8*>(out + i * 8) = o;
+}
+
+// NHWC fp16 -> NCHW fp32 through an LDS transpose tile (32 pixels x 32 channels).
+__global__ void nchw_from_nhwc_kernel(const half_t* __restrict__ in, float* __restrict__ out, int hw, int c) {
+    __shared__ float tile[32][33];
+    const int img = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, ch = c0 + tx;
+        tile[r][tx] = (p < hw && ch < c) ? (float)in[((long)img * hw + p) * c + ch] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ch = c0 + r, p = p0 + tx;
+        if (p < hw && ch < c) out[((long)img * c + ch) * hw + p] = tile[tx][r];
+    }
+}
+
+__global__ void nhwc_from_nchw_kernel(const float* __restrict__ in, half_t* __restrict__ out, int hw, int c) {
+    __shared__ float tile[32][33];
+    const int img = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int ch = c0 + r, p = p0 + tx;
+        tile[r][tx] = (p < hw && ch < c) ? in[((long)img * c + ch) * hw + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, ch = c0 + tx;
+        if (p < hw && ch < c) out[((long)img * hw + p) * c + ch] = (half_t)tile[tx][r];
+    }
+}
+
+// y = LayerNorm(x + r) (eps 1e-5), optional ReLU; one wave per row, D = 64 * VPL * 4 / ... generic loop.
+// Statistics in fp32 (two-pass on registers), as apex amp keeps layer_norm in fp32.
+template <int MAXV>
+__global__ void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ g,
+                                     const float* __restrict__ b, float* __restrict__ y32, half_t* __restrict__ y16, int rows, int d,
+                                     int relu) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int nv = d >> 2;  // float4 vectors per row
+    float4v v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = lane + i * 64;
+        if (j < nv) {
+            v[i] = *reinterpret_cast<const float4v*>(x + (long)row * d + j * 4);
+            if (r) v[i] += *reinterpret_cast<const float4v*>(r + (long)row * d + j * 4);
+            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(sum) / d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = lane + i * 64;
+        if (j < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[i][e] - mean;
+                sq += t * t;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = lane + i * 64;
+        if (j < nv) {
+            const float4v gg = *reinterpret_cast<const float4v*>(g + j * 4);
+            const float4v bb = *reinterpret_cast<const float4v*>(b + j * 4);
+            float4v o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+                if (relu) o[e] = fmaxf(o[e], 0.f);
+            }
+            if (y32) *reinterpret_cast<float4v*>(y32 + (long)row * d + j * 4) = o;
+            if (y16) {
+                half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                *reinterpret_cast<half4*>(y16 + (long)row * d + j * 4) = h;
+            }
+        }
+    }
+}
+
+__global__ void f32_to_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4v v = *reinterpret_cast<const float4v*>(x + i * 4);
+    half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<half4*>(y + i * 4) = h;
+}
+
+__global__ void silu_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4v v = *reinterpret_cast<const float4v*>(x + i * 4);
+    half4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (half_t)(v[e] / (1.f + expf(-v[e])));
+    *reinterpret_cast<half4*>(y + i * 4) = h;
+}
+
+// box_head.py:533-536 / :643-647: fc = x * (scale + 1) + shift
+__global__ void modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale, int scale_ld,
+                                const float* __restrict__ shift, int shift_per_row, int shift_ld, half_t* __restrict__ y16, long n4,
+                                int rows_per_frame, int d) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int dv = d >> 2;
+    const long row = i / dv;
+    const int col = (int)(i - row * dv) * 4;
+    const long frame = row / rows_per_frame;
+    const float4v v = *reinterpret_cast<const float4v*>(x + i * 4);
+    const float4v sc = *reinterpret_cast<const float4v*>(scale + frame * scale_ld + col);
+    const float4v sh = *reinterpret_cast<const float4v*>(shift + (shift_per_row ? row : frame) * shift_ld + col);
+    half4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (half_t)(v[e] * (sc[e] + 1.f) + sh[e]);
+    *reinterpret_cast<half4*>(y16 + i * 4) = h;
+}
+
+}  // namespace
+
+int dvid_prep_images_launch(const float* nchw, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
+                            hipStream_t s) {
+    const long hw = (long)h * w, npix = hw * n;
+    hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, nchw, nhwc8, npix, hw, mean[0],
+                       mean[1], mean[2], inv_std[0], inv_std[1], inv_std[2]);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_maxpool3x3s2_launch(const half_t* in, half_t* out, int n, int h, int w, int c, hipStream_t s) {
+    if (c % 8) return DVID_ERR_ARG;
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long total = (long)n * ho * wo * (c / 8);
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, n, h, w, c, ho, wo);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_nchw_from_nhwc_launch(const half_t* in, float* out, int n, int h, int w, int c, hipStream_t s) {
+    const int hw = h * w;
+    hipLaunchKernelGGL(nchw_from_nhwc_kernel, dim3(ceil_div(hw, 32), ceil_div(c, 32), n), dim3(256), 0, s, in, out, hw, c);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_nhwc_from_nchw_launch(const float* in, half_t* out, int n, int h, int w, int c, hipStream_t s) {
+    const int hw = h * w;
+    hipLaunchKernelGGL(nhwc_from_nchw_kernel, dim3(ceil_div(hw, 32), ceil_div(c, 32), n), dim3(256), 0, s, in, out, hw, c);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_add_layernorm_launch(const float* x, const float* r, const float* g, const float* b, float* y32, half_t* y16, int rows,
+                              int d, int relu, hipStream_t s) {
+    if (d % 4 || d > 1024) return DVID_ERR_ARG;
+    const int wpb = 4;
+    const dim3 grid(ceil_div(rows, wpb)), block(64 * wpb);
+    if (d <= 256)
+        hipLaunchKernelGGL(add_layernorm_kernel<1>, grid, block, 0, s, x, r, g, b, y32, y16, rows, d, relu);
+    else
+        hipLaunchKernelGGL(add_layernorm_kernel<4>, grid, block, 0, s, x, r, g, b, y32, y16, rows, d, relu);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_f32_to_f16_launch(const float* x, half_t* y, long n, hipStream_t s) {
+    if (n % 4) return DVID_ERR_ARG;
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, y, n / 4);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_silu_f16_launch(const float* x, half_t* y, long n, hipStream_t s) {
+    if (n % 4) return DVID_ERR_ARG;
+    hipLaunchKernelGGL(silu_f16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, y, n / 4);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_modulate_launch(const float* x, const float* scale, int scale_ld, const float* shift, int shift_per_row, int shift_ld,
+                         half_t* y16, int rows, int rows_per_frame, int d, hipStream_t s) {
+    if (d % 4) return DVID_ERR_ARG;
+    const long n4 = (long)rows * d / 4;
+    hipLaunchKernelGGL(modulate_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, scale, scale_ld, shift, shift_per_row,
+                       shift_ld, y16, n4, rows_per_frame, d);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}

@@ -1,0 +1,69 @@
+// Internal launcher declarations (C++), one per HIP kernel family.  The public C ABI is
+// include/dvid_hip.h; these are what the runtime (model.hip) and the C-ABI op wrappers call.
+#pragma once
+#include "common.h"
+
+struct IgemmParams {
+    const half_t* in;    // NHWC fp16 [N,H,W,Cin]  (Linear: [M,K] as N=M, H=W=1, Cin=K)
+    const half_t* w;     // [Cout][Kpad], k = (ky*KW + kx)*Cin + c
+    const float* bias;   // [Cout] or nullptr
+    const void* res;     // residual (fp16, or fp32 if res_f32), see res_mode
+    void* out;           // [M][ldc] fp16 (or fp32 if out_f32)
+    int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int M, Kpad, ntaps, ldc, alg_k;
+    int relu, out_f32, res_mode, res_f32;   // res_mode: 0 none, 1 same shape, 2 nearest-x2 upsample
+    int tiles_m, tiles_n;                   // filled by the launcher
+};
+int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);
+
+// elementwise.hip
+int dvid_prep_images_launch(const float* nchw, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
+                            hipStream_t s);
+int dvid_maxpool3x3s2_launch(const half_t* in, half_t* out, int n, int h, int w, int c, hipStream_t s);
+int dvid_nchw_from_nhwc_launch(const half_t* in, float* out, int n, int h, int w, int c, hipStream_t s);
+int dvid_nhwc_from_nchw_launch(const float* in, half_t* out, int n, int h, int w, int c, hipStream_t s);
+// y = LN(x + r) * g + b, rows of D (= 256 or 64-multiple <= 1024); writes fp32 and/or fp16 copies
+int dvid_add_layernorm_launch(const float* x, const float* r, const float* g, const float* b, float* y32, half_t* y16,
+                              int rows, int d, int relu, hipStream_t s);
+int dvid_f32_to_f16_launch(const float* x, half_t* y, long n, hipStream_t s);
+// fc = x * (scale[frame] + 1) + shift  (shift per frame [B,D] or per row [R,D])
+int dvid_modulate_launch(const float* x, const float* scale, int scale_ld, const float* shift, int shift_per_row, int shift_ld,
+                         half_t* y16, int rows, int rows_per_frame, int d, hipStream_t s);
+int dvid_silu_f16_launch(const float* x, half_t* y, long n, hipStream_t s);
+
+// roialign.hip
+struct RoiLevels {
+    const half_t* feat[3];
+    int h[3], w[3];
+    float scale[3];
+};
+int dvid_roialign_launch(const RoiLevels& lv, int channels, const float* boxes, int n_img, int boxes_per_img, half_t* roi_out,
+                         float* mean_out, hipStream_t s);
+
+// attention.hip : out[b][q][:] = softmax(Q K^T * scale) V per head; fp32 in/out, row strides given
+int dvid_mha_core_launch(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads,
+                         int head_dim, int q_ld, int kv_ld, int out_ld, long q_bs, long kv_bs, long out_bs, half_t* out16,
+                         hipStream_t s);
+
+// dynconv.hip
+int dvid_dynconv_launch(const half_t* roi, const half_t* params, const float* g1, const float* b1, const float* g2,
+                        const float* b2, half_t* out, int rows, hipStream_t s);
+
+// boxes.hip
+int dvid_apply_deltas_launch(const float* deltas, int delta_ld, const float* boxes, float* out, int n, float wx, float wy, float ww,
+                             float wh, float clamp, int* bad_flag, hipStream_t s);
+int dvid_noise_to_boxes_launch(const float* x, float* boxes, int n, float scale, float w, float h, hipStream_t s);
+int dvid_topk_mask_launch(const float* logits, int n_img, int m, int c, int k1, int k2, const float* feats, int d, float* out1,
+                          float* out2, hipStream_t s);
+
+// postproc.hip
+int dvid_topk_candidates_launch(const float* logits, const float* boxes, int n_img, int nsets, int m, int c, float* cand_boxes,
+                                float* cand_scores, int* cand_labels, hipStream_t s);
+int dvid_nms_frames_launch(const float* cand_boxes, const float* cand_scores, const int* cand_labels, int n_img, int n, float img_w,
+                           float img_h, float iou, int use_nms, int out_cap, float* out_boxes, float* out_scores, int* out_labels,
+                           int* out_counts, hipStream_t s);
+
+// fps.hip
+int dvid_cdist_launch(const float* x, int n, int d, float* dist, hipStream_t s);
+int dvid_fps_launch(const float* dist, int n, int m, int bs_emul, int* idx, hipStream_t s);
+int dvid_gather_rows_launch(const float* x, const int* idx, float* y, int m, int d, hipStream_t s);

@@ -1,0 +1,853 @@
+// libdvid_hip runtime: weight ingest/repack, workspace, stage orchestration, C ABI.
+// See include/dvid_hip.h for the contract of every exported symbol.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dvid_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+void set_err(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+#define FAIL(code, ...)       \
+    do {                      \
+        set_err(__VA_ARGS__); \
+        return (code);        \
+    } while (0)
+#define TRY(expr)                       \
+    do {                                \
+        int _rc = (expr);               \
+        if (_rc != DVID_OK) {           \
+            if (!g_err[0]) set_err("%s failed (%d) at %s:%d", #expr, _rc, __FILE__, __LINE__); \
+            return _rc;                 \
+        }                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// profiling of igemm launches (bench.py roofline): events recorded on the launch stream
+// ---------------------------------------------------------------------------------------------
+struct ProfRec {
+    hipEvent_t a, b;
+    double flop;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<ProfRec> g_prof_pool;
+
+int igemm(const IgemmParams& p, hipStream_t s) {
+    if (!g_prof_on) return dvid_igemm_launch(p, s);
+    ProfRec r;
+    if (!g_prof_pool.empty()) {
+        r = g_prof_pool.back();
+        g_prof_pool.pop_back();
+    } else {
+        HIP_TRY(hipEventCreate(&r.a));
+        HIP_TRY(hipEventCreate(&r.b));
+    }
+    r.flop = 2.0 * p.M * (double)p.Cout * (double)p.alg_k;
+    HIP_TRY(hipEventRecord(r.a, s));
+    const int rc = dvid_igemm_launch(p, s);
+    HIP_TRY(hipEventRecord(r.b, s));
+    g_prof.push_back(r);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<float> v;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto d : shape) n *= d;
+        return n;
+    }
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return DVID_OK;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        bytes = 0;
+        HIP_TRY(hipMalloc(&p, n));
+        bytes = n;
+        return DVID_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ConvW {   // conv or linear weights in MFMA-operand layout
+    half_t* w = nullptr;
+    float* bias = nullptr;
+    int cin = 0, cout = 0, kh = 1, kw = 1, stride = 1, pad = 0, kpad = 0;
+    int cin_real = 0;  // un-padded input channels (algorithmic FLOP count)
+};
+struct LNW {
+    float* g = nullptr;
+    float* b = nullptr;
+    int d = 0;
+};
+struct HeadW {
+    ConvW in_proj, out_proj, dynamic_layer, out_layer, linear1, linear2, class_logits, bboxes_delta, c_mlp;
+    std::vector<ConvW> cls, reg;
+    std::vector<LNW> cls_ln, reg_ln;
+    LNW norm1, norm2, norm3, dc_norm1, dc_norm2, dc_norm3;
+    // host copies for the time conditioning (block_time_mlp.1)
+    std::vector<float> bt_w, bt_b;
+    int bt_out = 0;
+    bool cond = false;
+};
+struct Block {
+    ConvW c1, c2, c3, sc;
+    bool has_sc = false;
+};
+
+half_t f2h(float f) { return (half_t)f; }
+
+}  // namespace
+
+struct dvid_model {
+    dvid_config cfg;
+    std::map<std::string, HostTensor> raw;
+    bool finalized = false;
+    std::vector<void*> owned;  // device allocations of weights
+
+    // backbone
+    bool has_backbone = false;
+    ConvW stem;
+    std::vector<Block> blocks[4];
+    ConvW lateral[3], output[3];  // index 0 -> level 3
+    // head
+    std::vector<HeadW> heads;       // head_series
+    std::vector<HeadW> heads_cond;  // head_series_cond
+    ConvW gq, gkv, gout;            // global attention projections
+    std::vector<float> tm1_w, tm1_b, tm3_w, tm3_b;  // time_mlp host copies
+    std::map<int64_t, std::vector<float>> time_cache;  // t -> time_mlp(t) [4*hidden]
+
+    // workspace
+    int ws_frames = 0, ws_h = 0, ws_w = 0, ws_boxes = 0;
+    DevBuf img8, bufX, bufY, bufT1, bufT2, bufSC, c3, c4, c5, lat[3];
+    DevBuf roi, params, dyn, qkv, attn16, f32a, f32b, f32c, f32d, h16a, h16b, hid16, ss, deltas, kvproj, mem16;
+    std::map<int, std::vector<int64_t>> ss_keys;  // per head slot: t vector of the uploaded scale/shift table
+
+    int upload(const void* host, size_t bytes, void** dev) {
+        HIP_TRY(hipMalloc(dev, bytes));
+        owned.push_back(*dev);
+        HIP_TRY(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+        return DVID_OK;
+    }
+    const HostTensor* get(const std::string& name) const {
+        auto it = raw.find(name);
+        return it == raw.end() ? nullptr : &it->second;
+    }
+};
+
+namespace {
+
+#define NEED(var, name)                                              \
+    const HostTensor* var = m->get(name);                            \
+    if (!var) FAIL(DVID_ERR_STATE, "missing tensor '%s'", std::string(name).c_str())
+
+int upload_f32(dvid_model* m, const std::vector<float>& v, float** dev) {
+    return m->upload(v.data(), v.size() * sizeof(float), reinterpret_cast<void**>(dev));
+}
+
+// weights [cout][cin][kh][kw] (OIHW; Linear: [out][in]) -> fp16 [cout][kpad], k = (ky*kw + kx)*cin_pad + c.
+// `scale` (per cout, may be empty) is folded in before rounding to fp16; row_perm maps dst row -> src row.
+int make_conv(dvid_model* m, const HostTensor& w, const std::vector<float>& scale, const std::vector<float>& bias, int stride, int pad,
+              int cin_pad, const std::vector<int>* row_perm, ConvW* out) {
+    const int cout = (int)w.shape[0], cin = (int)w.shape[1];
+    const int kh = w.shape.size() == 4 ? (int)w.shape[2] : 1, kw = w.shape.size() == 4 ? (int)w.shape[3] : 1;
+    const int cp = cin_pad > 0 ? cin_pad : cin;
+    const int kreal = kh * kw * cp;
+    const int kpad = (kreal + 63) / 64 * 64;
+    std::vector<half_t> packed((size_t)cout * kpad, f2h(0.f));
+    for (int o = 0; o < cout; ++o) {
+        const int so = row_perm ? (*row_perm)[o] : o;
+        const float sc = scale.empty() ? 1.f : scale[so];
+        for (int c = 0; c < cin; ++c)
+            for (int y = 0; y < kh; ++y)
+                for (int x = 0; x < kw; ++x) {
+                    const float v = w.v[(((size_t)so * cin + c) * kh + y) * kw + x] * sc;
+                    packed[(size_t)o * kpad + (size_t)(y * kw + x) * cp + c] = f2h(v);
+                }
+    }
+    TRY(m->upload(packed.data(), packed.size() * sizeof(half_t), reinterpret_cast<void**>(&out->w)));
+    out->bias = nullptr;
+    if (!bias.empty()) {
+        std::vector<float> b(cout);
+        for (int o = 0; o < cout; ++o) b[o] = bias[row_perm ? (*row_perm)[o] : o];
+        TRY(upload_f32(m, b, &out->bias));
+    }
+    out->cin = cp;
+    out->cin_real = cin;
+    out->cout = cout;
+    out->kh = kh;
+    out->kw = kw;
+    out->stride = stride;
+    out->pad = pad;
+    out->kpad = kpad;
+    return DVID_OK;
+}
+
+// conv + FrozenBN (eps 1e-5) folded:  y = conv(x, w * s) + (beta - mean * s),  s = gamma * rsqrt(var + eps)
+int make_conv_bn(dvid_model* m, const std::string& name, int stride, int pad, int cin_pad, ConvW* out) {
+    NEED(w, name + ".weight");
+    NEED(g, name + ".norm.weight");
+    NEED(b, name + ".norm.bias");
+    NEED(mu, name + ".norm.running_mean");
+    NEED(var, name + ".norm.running_var");
+    const int cout = (int)w->shape[0];
+    std::vector<float> s(cout), bb(cout);
+    for (int o = 0; o < cout; ++o) {
+        s[o] = g->v[o] / sqrtf(var->v[o] + 1e-5f);
+        bb[o] = b->v[o] - mu->v[o] * s[o];
+    }
+    return make_conv(m, *w, s, bb, stride, pad, cin_pad, nullptr, out);
+}
+
+int make_linear(dvid_model* m, const std::string& name, bool has_bias, ConvW* out, const std::vector<int>* perm = nullptr,
+                int row0 = 0, int rows = -1) {
+    NEED(w, name + (name.find("in_proj") != std::string::npos ? "_weight" : ".weight"));
+    const HostTensor* b = nullptr;
+    if (has_bias) {
+        const std::string bn = name + (name.find("in_proj") != std::string::npos ? "_bias" : ".bias");
+        b = m->get(bn);
+        if (!b) FAIL(DVID_ERR_STATE, "missing tensor '%s'", bn.c_str());
+    }
+    HostTensor sub;
+    const HostTensor* src = w;
+    std::vector<float> bias;
+    if (rows >= 0) {  // row slice (in_proj q / kv parts)
+        const int in = (int)w->shape[1];
+        sub.shape = {rows, in};
+        sub.v.assign(w->v.begin() + (size_t)row0 * in, w->v.begin() + (size_t)(row0 + rows) * in);
+        src = &sub;
+        if (b) bias.assign(b->v.begin() + row0, b->v.begin() + row0 + rows);
+    } else if (b) {
+        bias = b->v;
+    }
+    if (src->shape[1] % 64) FAIL(DVID_ERR_UNSUPPORTED, "linear '%s': in_features %lld not a multiple of 64", name.c_str(),
+                                 (long long)src->shape[1]);
+    return make_conv(m, *src, {}, bias, 1, 0, 0, perm, out);
+}
+
+int make_ln(dvid_model* m, const std::string& name, LNW* out) {
+    NEED(g, name + ".weight");
+    NEED(b, name + ".bias");
+    out->d = (int)g->numel();
+    TRY(upload_f32(m, g->v, &out->g));
+    TRY(upload_f32(m, b->v, &out->b));
+    return DVID_OK;
+}
+
+int make_head(dvid_model* m, const std::string& pfx, bool cond, HeadW* h) {
+    const dvid_config& c = m->cfg;
+    const int d = c.hidden_dim, dd = c.dim_dynamic;
+    h->cond = cond;
+    TRY(make_linear(m, pfx + ".self_attn.in_proj", true, &h->in_proj));
+    TRY(make_linear(m, pfx + ".self_attn.out_proj", true, &h->out_proj));
+    // dynamic_layer rows re-ordered so that the generated parameters come out as P1T[j][c], P2T[c][j]
+    // (box_head.py:695-696 views them as param1[c][j] at c*dd + j and param2[j][c] at d*dd + j*d + c)
+    std::vector<int> perm(2 * d * dd);
+    for (int j = 0; j < dd; ++j)
+        for (int ch = 0; ch < d; ++ch) perm[j * d + ch] = ch * dd + j;
+    for (int ch = 0; ch < d; ++ch)
+        for (int j = 0; j < dd; ++j) perm[d * dd + ch * dd + j] = d * dd + j * d + ch;
+    TRY(make_linear(m, pfx + ".inst_interact.dynamic_layer", true, &h->dynamic_layer, &perm));
+    TRY(make_linear(m, pfx + ".inst_interact.out_layer", true, &h->out_layer));
+    TRY(make_ln(m, pfx + ".inst_interact.norm1", &h->dc_norm1));
+    TRY(make_ln(m, pfx + ".inst_interact.norm2", &h->dc_norm2));
+    TRY(make_ln(m, pfx + ".inst_interact.norm3", &h->dc_norm3));
+    TRY(make_linear(m, pfx + ".linear1", true, &h->linear1));
+    TRY(make_linear(m, pfx + ".linear2", true, &h->linear2));
+    TRY(make_ln(m, pfx + ".norm1", &h->norm1));
+    TRY(make_ln(m, pfx + ".norm2", &h->norm2));
+    TRY(make_ln(m, pfx + ".norm3", &h->norm3));
+    h->cls.resize(c.num_cls);
+    h->cls_ln.resize(c.num_cls);
+    for (int i = 0; i < c.num_cls; ++i) {
+        TRY(make_linear(m, pfx + ".cls_module." + std::to_string(3 * i), false, &h->cls[i]));
+        TRY(make_ln(m, pfx + ".cls_module." + std::to_string(3 * i + 1), &h->cls_ln[i]));
+    }
+    h->reg.resize(c.num_reg);
+    h->reg_ln.resize(c.num_reg);
+    for (int i = 0; i < c.num_reg; ++i) {
+        TRY(make_linear(m, pfx + ".reg_module." + std::to_string(3 * i), false, &h->reg[i]));
+        TRY(make_ln(m, pfx + ".reg_module." + std::to_string(3 * i + 1), &h->reg_ln[i]));
+    }
+    TRY(make_linear(m, pfx + ".class_logits", true, &h->class_logits));
+    TRY(make_linear(m, pfx + ".bboxes_delta", true, &h->bboxes_delta));
+    NEED(btw, pfx + ".block_time_mlp.1.weight");
+    NEED(btb, pfx + ".block_time_mlp.1.bias");
+    h->bt_w = btw->v;
+    h->bt_b = btb->v;
+    h->bt_out = (int)btw->shape[0];
+    if (h->bt_out != (cond ? d : 2 * d)) FAIL(DVID_ERR_ARG, "%s.block_time_mlp.1: unexpected out dim %d", pfx.c_str(), h->bt_out);
+    if (cond) TRY(make_linear(m, pfx + ".c_mlp.1", true, &h->c_mlp));
+    return DVID_OK;
+}
+
+int conv_run(const ConvW& w, const half_t* in, int n, int h, int wd, void* out, int relu, int out_f32, const void* res,
+             int res_mode, int res_f32, hipStream_t s, int* ho_out = nullptr, int* wo_out = nullptr, int ldc = 0) {
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = in;
+    p.w = w.w;
+    p.bias = w.bias;
+    p.res = res;
+    p.out = out;
+    p.H = h;
+    p.W = wd;
+    p.Cin = w.cin;
+    p.KH = w.kh;
+    p.KW = w.kw;
+    p.stride = w.stride;
+    p.pad = w.pad;
+    p.Ho = (h + 2 * w.pad - w.kh) / w.stride + 1;
+    p.Wo = (wd + 2 * w.pad - w.kw) / w.stride + 1;
+    p.Cout = w.cout;
+    p.M = n * p.Ho * p.Wo;
+    p.Kpad = w.kpad;
+    p.ntaps = w.kh * w.kw;
+    p.alg_k = w.kh * w.kw * (w.cin_real ? w.cin_real : w.cin);
+    p.ldc = ldc ? ldc : w.cout;
+    p.relu = relu;
+    p.out_f32 = out_f32;
+    p.res_mode = res_mode;
+    p.res_f32 = res_f32;
+    if (ho_out) *ho_out = p.Ho;
+    if (wo_out) *wo_out = p.Wo;
+    return igemm(p, s);
+}
+
+// Linear on [rows, in] fp16
+int linear_run(const ConvW& w, const half_t* in, int rows, void* out, int relu, int out_f32, hipStream_t s) {
+    return conv_run(w, in, rows, 1, 1, out, relu, out_f32, nullptr, 0, 0, s);
+}
+
+float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+// box_head.py:218-223 + :734-741 on the host (a handful of distinct t values per config)
+const std::vector<float>& time_embedding(dvid_model* m, int64_t t) {
+    auto it = m->time_cache.find(t);
+    if (it != m->time_cache.end()) return it->second;
+    const int d = m->cfg.hidden_dim, td = 4 * d, half = d / 2;
+    std::vector<float> emb(d), h1(td), out(td);
+    const float e = logf(10000.f) / (half - 1);
+    for (int i = 0; i < half; ++i) {
+        const float a = (float)t * expf((float)i * -e);
+        emb[i] = sinf(a);
+        emb[half + i] = cosf(a);
+    }
+    for (int o = 0; o < td; ++o) {
+        double acc = m->tm1_b[o];
+        for (int i = 0; i < d; ++i) acc += (double)m->tm1_w[(size_t)o * d + i] * emb[i];
+        h1[o] = gelu_exact((float)acc);
+    }
+    for (int o = 0; o < td; ++o) {
+        double acc = m->tm3_b[o];
+        for (int i = 0; i < td; ++i) acc += (double)m->tm3_w[(size_t)o * td + i] * h1[i];
+        out[o] = (float)acc;
+    }
+    return m->time_cache.emplace(t, std::move(out)).first->second;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* dvid_last_error(void) { return g_err; }
+int dvid_version(void) { return 1; }
+
+int dvid_model_create(const dvid_config* cfg, dvid_model** out) {
+    g_err[0] = 0;
+    if (!cfg || !out) FAIL(DVID_ERR_ARG, "null argument");
+    if (cfg->hidden_dim != 256 || cfg->nheads != 8 || cfg->dim_dynamic != 64 || cfg->pooler_resolution != 7 ||
+        cfg->sampling_ratio != 2)
+        FAIL(DVID_ERR_UNSUPPORTED,
+             "kernels are specialised for HIDDEN_DIM 256, NHEADS 8, DIM_DYNAMIC 64, POOLER_RESOLUTION 7, SAMPLING_RATIO 2");
+    if (cfg->dim_feedforward % 64 || cfg->num_classes < 1 || cfg->num_classes > 64)
+        FAIL(DVID_ERR_UNSUPPORTED, "DIM_FEEDFORWARD must be a multiple of 64 and 1 <= NUM_CLASSES <= 64");
+    int dev_count = 0;
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count == 0) FAIL(DVID_ERR_HIP, "no HIP device available");
+    dvid_model* m = new dvid_model();
+    m->cfg = *cfg;
+    *out = m;
+    return DVID_OK;
+}
+
+int dvid_model_destroy(dvid_model* m) {
+    if (!m) return DVID_OK;
+    for (void* p : m->owned) (void)hipFree(p);
+    DevBuf* bufs[] = {&m->img8, &m->bufX, &m->bufY, &m->bufT1, &m->bufT2, &m->bufSC, &m->c3, &m->c4, &m->c5, &m->lat[0],
+                      &m->lat[1], &m->lat[2], &m->roi, &m->params, &m->dyn, &m->qkv, &m->attn16, &m->f32a, &m->f32b, &m->f32c,
+                      &m->f32d, &m->h16a, &m->h16b, &m->hid16, &m->ss, &m->deltas, &m->kvproj, &m->mem16};
+    for (DevBuf* b : bufs) b->release();
+    delete m;
+    return DVID_OK;
+}
+
+int dvid_model_set_tensor(dvid_model* m, const char* name, const float* data, const int64_t* shape, int ndim) {
+    g_err[0] = 0;
+    if (!m || !name || !data || ndim < 0 || ndim > 8) FAIL(DVID_ERR_ARG, "bad argument");
+    if (m->finalized) FAIL(DVID_ERR_STATE, "model already finalized");
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    t.v.assign(data, data + t.numel());
+    m->raw[name] = std::move(t);
+    return DVID_OK;
+}
+
+int dvid_model_finalize(dvid_model* m) {
+    g_err[0] = 0;
+    if (!m) FAIL(DVID_ERR_ARG, "null model");
+    if (m->finalized) return DVID_OK;
+    const dvid_config& c = m->cfg;
+    m->has_backbone = c.res_blocks[0] > 0;
+    if (m->has_backbone) {
+        const std::string bu = "backbone.bottom_up.";
+        TRY(make_conv_bn(m, bu + "stem.conv1", 2, 3, 8, &m->stem));
+        for (int s = 0; s < 4; ++s) {
+            m->blocks[s].resize(c.res_blocks[s]);
+            for (int b = 0; b < c.res_blocks[s]; ++b) {
+                const std::string p = bu + "res" + std::to_string(s + 2) + "." + std::to_string(b);
+                Block& blk = m->blocks[s][b];
+                const int stride = (b == 0 && s > 0) ? 2 : 1;  // STRIDE_IN_1X1: False -> stride on the 3x3
+                TRY(make_conv_bn(m, p + ".conv1", 1, 0, 0, &blk.c1));
+                TRY(make_conv_bn(m, p + ".conv2", stride, 1, 0, &blk.c2));
+                TRY(make_conv_bn(m, p + ".conv3", 1, 0, 0, &blk.c3));
+                blk.has_sc = (b == 0);
+                if (blk.has_sc) TRY(make_conv_bn(m, p + ".shortcut", stride, 0, 0, &blk.sc));
+            }
+        }
+        for (int l = 0; l < 3; ++l) {
+            const std::string lat = "backbone.fpn_lateral" + std::to_string(l + 3);
+            const std::string outn = "backbone.fpn_output" + std::to_string(l + 3);
+            NEED(lw, lat + ".weight");
+            NEED(lb, lat + ".bias");
+            NEED(ow, outn + ".weight");
+            NEED(ob, outn + ".bias");
+            TRY(make_conv(m, *lw, {}, lb->v, 1, 0, 0, nullptr, &m->lateral[l]));
+            TRY(make_conv(m, *ow, {}, ob->v, 1, 1, 0, nullptr, &m->output[l]));
+        }
+    }
+    m->heads.resize(c.num_heads);
+    for (int i = 0; i < c.num_heads; ++i) TRY(make_head(m, "head.head_series." + std::to_string(i), false, &m->heads[i]));
+    m->heads_cond.resize(c.num_heads_cond);
+    for (int i = 0; i < c.num_heads_cond; ++i)
+        TRY(make_head(m, "head.head_series_cond." + std::to_string(i), true, &m->heads_cond[i]));
+    if (m->get("head.global_attention.0.0.in_proj_weight")) {
+        const int d = c.hidden_dim;
+        TRY(make_linear(m, "head.global_attention.0.0.in_proj", true, &m->gq, nullptr, 0, d));
+        TRY(make_linear(m, "head.global_attention.0.0.in_proj", true, &m->gkv, nullptr, d, 2 * d));
+        TRY(make_linear(m, "head.global_attention.0.0.out_proj", true, &m->gout));
+    }
+    {
+        NEED(w1, "head.time_mlp.1.weight");
+        NEED(b1, "head.time_mlp.1.bias");
+        NEED(w3, "head.time_mlp.3.weight");
+        NEED(b3, "head.time_mlp.3.bias");
+        m->tm1_w = w1->v;
+        m->tm1_b = b1->v;
+        m->tm3_w = w3->v;
+        m->tm3_b = b3->v;
+    }
+    m->raw.clear();
+    m->finalized = true;
+    return DVID_OK;
+}
+
+int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width, int boxes_per_frame) {
+    g_err[0] = 0;
+    if (!m || max_frames <= 0 || boxes_per_frame <= 0) FAIL(DVID_ERR_ARG, "bad argument");
+    if (height % 32 || width % 32) FAIL(DVID_ERR_ARG, "height/width must be multiples of 32 (got %dx%d)", height, width);
+    const size_t n = max_frames;
+    const size_t px4 = (size_t)(height / 4) * (width / 4);
+    if (m->has_backbone) {
+        TRY(m->img8.ensure(n * height * width * 8 * 2));
+        const size_t big = n * px4 * 256 * 2;  // largest activation: res2 output (also >= stem output)
+        TRY(m->bufX.ensure(big));
+        TRY(m->bufY.ensure(big));
+        TRY(m->bufT1.ensure(big));
+        TRY(m->bufT2.ensure(big));
+        TRY(m->bufSC.ensure(big));
+        TRY(m->c3.ensure(n * (px4 / 4) * 512 * 2));
+        TRY(m->c4.ensure(n * (px4 / 16) * 1024 * 2));
+        TRY(m->c5.ensure(n * (px4 / 64) * 2048 * 2));
+        for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2));
+    }
+    const size_t R = n * boxes_per_frame;
+    const int d = m->cfg.hidden_dim;
+    TRY(m->roi.ensure(R * 49 * d * 2));
+    TRY(m->dyn.ensure(R * 49 * d * 2));
+    TRY(m->params.ensure(R * 2 * d * m->cfg.dim_dynamic * 2));
+    TRY(m->qkv.ensure(R * 3 * d * 4));
+    TRY(m->attn16.ensure(R * d * 2));
+    TRY(m->f32a.ensure(R * d * 4));
+    TRY(m->f32b.ensure(R * d * 4));
+    TRY(m->f32c.ensure(R * d * 4));
+    TRY(m->f32d.ensure(R * d * 4));
+    TRY(m->h16a.ensure(R * d * 2));
+    TRY(m->h16b.ensure(R * d * 2));
+    TRY(m->hid16.ensure(R * m->cfg.dim_feedforward * 2));
+    TRY(m->ss.ensure((size_t)(m->cfg.num_heads + m->cfg.num_heads_cond) * n * 2 * d * 4));
+    TRY(m->deltas.ensure(R * 4 * 4));
+    m->ws_frames = max_frames;
+    m->ws_h = height;
+    m->ws_w = width;
+    m->ws_boxes = boxes_per_frame;
+    return DVID_OK;
+}
+
+int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
+                             void* stream) {
+    g_err[0] = 0;
+    if (!m || !m->finalized || !m->has_backbone) FAIL(DVID_ERR_STATE, "model not finalized or built without a backbone");
+    if (n > m->ws_frames || height != m->ws_h || width != m->ws_w)
+        FAIL(DVID_ERR_STATE, "workspace reserved for %d frames of %dx%d, got %d of %dx%d", m->ws_frames, m->ws_h, m->ws_w, n,
+             height, width);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float mean[3], inv_std[3];
+    for (int i = 0; i < 3; ++i) {
+        mean[i] = m->cfg.pixel_mean[i] / 255.f;
+        inv_std[i] = 1.f / (m->cfg.pixel_std[i] / 255.f);
+    }
+    TRY(dvid_prep_images_launch(images, m->img8.as<half_t>(), n, height, width, mean, inv_std, s));
+    int h = height, w = width;
+    TRY(conv_run(m->stem, m->img8.as<half_t>(), n, h, w, m->bufT1.p, 1, 0, nullptr, 0, 0, s, &h, &w));
+    TRY(dvid_maxpool3x3s2_launch(m->bufT1.as<half_t>(), m->bufX.as<half_t>(), n, h, w, 64, s));
+    h = (h + 2 - 3) / 2 + 1;
+    w = (w + 2 - 3) / 2 + 1;
+    half_t* const bx = m->bufX.as<half_t>();
+    half_t* const by = m->bufY.as<half_t>();
+    half_t* cur = bx;  // block input
+    half_t* stage_out[4] = {nullptr, m->c3.as<half_t>(), m->c4.as<half_t>(), m->c5.as<half_t>()};
+    int sh[4], sw[4];
+    for (int st = 0; st < 4; ++st) {
+        const int nb = (int)m->blocks[st].size();
+        for (int b = 0; b < nb; ++b) {
+            const Block& blk = m->blocks[st][b];
+            int h2 = h, w2 = w;
+            TRY(conv_run(blk.c1, cur, n, h, w, m->bufT1.p, 1, 0, nullptr, 0, 0, s));
+            TRY(conv_run(blk.c2, m->bufT1.as<half_t>(), n, h, w, m->bufT2.p, 1, 0, nullptr, 0, 0, s, &h2, &w2));
+            const half_t* res = cur;
+            if (blk.has_sc) {
+                TRY(conv_run(blk.sc, cur, n, h, w, m->bufSC.p, 0, 0, nullptr, 0, 0, s));
+                res = m->bufSC.as<half_t>();
+            }
+            // res3..res5 outputs persist for the FPN; everything else ping-pongs between bufX/bufY
+            half_t* dst = (b == nb - 1 && stage_out[st]) ? stage_out[st] : (cur == bx ? by : bx);
+            TRY(conv_run(blk.c3, m->bufT2.as<half_t>(), n, h2, w2, dst, 1, 0, res, 1, 0, s));
+            h = h2;
+            w = w2;
+            cur = dst;
+        }
+        sh[st] = h;
+        sw[st] = w;
+    }
+    // FPN (detectron2 FPN.forward): top-down from res5
+    void* pout[3] = {p3, p4, p5};
+    const half_t* cin[3] = {m->c3.as<half_t>(), m->c4.as<half_t>(), m->c5.as<half_t>()};
+    for (int l = 2; l >= 0; --l) {
+        const void* res = (l < 2) ? m->lat[l + 1].p : nullptr;
+        TRY(conv_run(m->lateral[l], cin[l], n, sh[l + 1], sw[l + 1], m->lat[l].p, 0, 0, res, res ? 2 : 0, 0, s));
+        TRY(conv_run(m->output[l], m->lat[l].as<half_t>(), n, sh[l + 1], sw[l + 1], pout[l], 0, 0, nullptr, 0, 0, s));
+    }
+    return DVID_OK;
+}
+
+int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, const void* p4, const void* p5, int n_frames,
+                   int height, int width, int boxes_per_frame, const float* boxes, const float* pro_features,
+                   const int64_t* t, const float* cond, float* logits, float* boxes_out, float* obj_features,
+                   int* bad_box_flag, void* stream) {
+    g_err[0] = 0;
+    if (!m || !m->finalized) FAIL(DVID_ERR_STATE, "model not finalized");
+    const std::vector<HeadW>& hv = is_cond ? m->heads_cond : m->heads;
+    if (head_index < 0 || head_index >= (int)hv.size()) FAIL(DVID_ERR_ARG, "head_index %d out of range", head_index);
+    if (is_cond && !cond) FAIL(DVID_ERR_ARG, "RCNNHead_cond needs cond");
+    if (n_frames > m->ws_frames || boxes_per_frame > m->ws_boxes) FAIL(DVID_ERR_STATE, "workspace too small; call dvid_workspace_reserve");
+    if (height % 32 || width % 32) FAIL(DVID_ERR_ARG, "height/width must be multiples of 32");
+    const HeadW& hw = hv[head_index];
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int d = m->cfg.hidden_dim, R = n_frames * boxes_per_frame, M = boxes_per_frame;
+
+    // --- time conditioning (box_head.py:533-536 / :645): host-side, cached on the t vector ---
+    const int slot = (is_cond ? m->cfg.num_heads : 0) + head_index;
+    float* ss_dev = m->ss.as<float>() + (size_t)slot * m->ws_frames * 2 * d;
+    {
+        std::vector<int64_t> key(t, t + n_frames);
+        // one cache entry per slot: re-upload only when this slot's t vector changes
+        auto& prev = m->ss_keys[slot];
+        if (prev != key) {
+            std::vector<float> tab((size_t)n_frames * hw.bt_out);
+            const int td = 4 * d;
+            for (int f = 0; f < n_frames; ++f) {
+                const std::vector<float>& te = time_embedding(m, t[f]);
+                std::vector<float> sl(td);
+                for (int i = 0; i < td; ++i) sl[i] = te[i] / (1.f + expf(-te[i]));  // SiLU
+                for (int o = 0; o < hw.bt_out; ++o) {
+                    double acc = hw.bt_b[o];
+                    for (int i = 0; i < td; ++i) acc += (double)hw.bt_w[(size_t)o * td + i] * sl[i];
+                    tab[(size_t)f * hw.bt_out + o] = (float)acc;
+                }
+            }
+            HIP_TRY(hipMemcpyAsync(ss_dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));  // `tab` is a stack temporary; happens once per distinct t vector
+            prev = key;
+        }
+    }
+
+    // --- RoIAlign ---
+    RoiLevels lv;
+    const void* pl[3] = {p3, p4, p5};
+    for (int l = 0; l < 3; ++l) {
+        lv.feat[l] = reinterpret_cast<const half_t*>(pl[l]);
+        lv.h[l] = height >> (3 + l);
+        lv.w[l] = width >> (3 + l);
+        lv.scale[l] = 1.f / (float)(8 << l);
+    }
+    float* pro32 = m->f32a.as<float>();
+    TRY(dvid_roialign_launch(lv, d, boxes, n_frames, M, m->roi.as<half_t>(), pro_features ? nullptr : pro32, s));
+    const float* pro = pro_features ? pro_features : pro32;
+    // --- self attention + norm1 ---
+    TRY(dvid_f32_to_f16_launch(pro, m->h16a.as<half_t>(), (long)R * d, s));
+    TRY(linear_run(hw.in_proj, m->h16a.as<half_t>(), R, m->qkv.p, 0, 1, s));
+    const float* qkv = m->qkv.as<float>();
+    TRY(dvid_mha_core_launch(qkv, qkv + d, qkv + 2 * d, nullptr, n_frames, M, M, m->cfg.nheads, d / m->cfg.nheads, 3 * d, 3 * d, d,
+                             (long)M * 3 * d, (long)M * 3 * d, (long)M * d, m->attn16.as<half_t>(), s));
+    TRY(linear_run(hw.out_proj, m->attn16.as<half_t>(), R, m->f32b.p, 0, 1, s));
+    float* x1 = m->f32c.as<float>();
+    TRY(dvid_add_layernorm_launch(pro, m->f32b.as<float>(), hw.norm1.g, hw.norm1.b, x1, m->h16a.as<half_t>(), R, d, 0, s));
+    // --- DynamicConv ---
+    TRY(linear_run(hw.dynamic_layer, m->h16a.as<half_t>(), R, m->params.p, 0, 0, s));
+    TRY(dvid_dynconv_launch(m->roi.as<half_t>(), m->params.as<half_t>(), hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b,
+                            m->dyn.as<half_t>(), R, s));
+    TRY(linear_run(hw.out_layer, m->dyn.as<half_t>(), R, m->f32b.p, 0, 1, s));
+    TRY(dvid_add_layernorm_launch(m->f32b.as<float>(), nullptr, hw.dc_norm3.g, hw.dc_norm3.b, m->f32b.as<float>(), nullptr, R, d, 1, s));
+    float* obj = m->f32d.as<float>();
+    TRY(dvid_add_layernorm_launch(x1, m->f32b.as<float>(), hw.norm2.g, hw.norm2.b, obj, m->h16a.as<half_t>(), R, d, 0, s));
+    // --- FFN + norm3 ---
+    TRY(linear_run(hw.linear1, m->h16a.as<half_t>(), R, m->hid16.p, 1, 0, s));
+    TRY(linear_run(hw.linear2, m->hid16.as<half_t>(), R, m->f32b.p, 0, 1, s));
+    TRY(dvid_add_layernorm_launch(obj, m->f32b.as<float>(), hw.norm3.g, hw.norm3.b, obj_features, nullptr, R, d, 0, s));
+    // --- time / cond modulation ---
+    half_t* fc16 = m->h16a.as<half_t>();
+    if (!is_cond) {
+        TRY(dvid_modulate_launch(obj_features, ss_dev, 2 * d, ss_dev + d, 0, 2 * d, fc16, R, M, d, s));
+    } else {
+        TRY(dvid_silu_f16_launch(cond, m->h16b.as<half_t>(), (long)R * d, s));
+        TRY(linear_run(hw.c_mlp, m->h16b.as<half_t>(), R, m->f32b.p, 0, 1, s));
+        TRY(dvid_modulate_launch(obj_features, ss_dev, d, m->f32b.as<float>(), 1, d, fc16, R, M, d, s));
+    }
+    // --- cls tower ---
+    const half_t* cur = fc16;
+    for (size_t i = 0; i < hw.cls.size(); ++i) {
+        TRY(linear_run(hw.cls[i], cur, R, m->f32b.p, 0, 1, s));
+        TRY(dvid_add_layernorm_launch(m->f32b.as<float>(), nullptr, hw.cls_ln[i].g, hw.cls_ln[i].b, nullptr, m->h16b.as<half_t>(), R, d,
+                                      1, s));
+        cur = m->h16b.as<half_t>();
+    }
+    TRY(conv_run(hw.class_logits, cur, R, 1, 1, logits, 0, 1, nullptr, 0, 0, s, nullptr, nullptr, m->cfg.num_classes));
+    // --- reg tower ---
+    cur = fc16;
+    half_t* regbuf[2] = {m->h16b.as<half_t>(), m->attn16.as<half_t>()};
+    for (size_t i = 0; i < hw.reg.size(); ++i) {
+        TRY(linear_run(hw.reg[i], cur, R, m->f32b.p, 0, 1, s));
+        TRY(dvid_add_layernorm_launch(m->f32b.as<float>(), nullptr, hw.reg_ln[i].g, hw.reg_ln[i].b, nullptr, regbuf[i & 1], R, d, 1, s));
+        cur = regbuf[i & 1];
+    }
+    TRY(conv_run(hw.bboxes_delta, cur, R, 1, 1, m->deltas.p, 0, 1, nullptr, 0, 0, s, nullptr, nullptr, 4));
+    TRY(dvid_apply_deltas_launch(m->deltas.as<float>(), 4, boxes, boxes_out, R, 2.f, 2.f, 1.f, 1.f, logf(100000.f / 16.f), bad_box_flag, s));
+    return DVID_OK;
+}
+
+int dvid_global_xattn(dvid_model* m, const float* query, int rows, const float* memory, int lk, float* out, void* stream) {
+    g_err[0] = 0;
+    if (!m || !m->finalized || !m->gq.w) FAIL(DVID_ERR_STATE, "model not finalized or has no global attention");
+    if (rows > m->ws_frames * m->ws_boxes) FAIL(DVID_ERR_STATE, "workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int d = m->cfg.hidden_dim;
+    TRY(m->kvproj.ensure((size_t)lk * 2 * d * 4));
+    TRY(m->mem16.ensure((size_t)lk * d * 2));
+    TRY(dvid_f32_to_f16_launch(query, m->h16a.as<half_t>(), (long)rows * d, s));
+    TRY(dvid_f32_to_f16_launch(memory, m->mem16.as<half_t>(), (long)lk * d, s));
+    TRY(linear_run(m->gq, m->h16a.as<half_t>(), rows, m->f32b.p, 0, 1, s));
+    TRY(linear_run(m->gkv, m->mem16.as<half_t>(), lk, m->kvproj.p, 0, 1, s));
+    const float* kv = m->kvproj.as<float>();
+    TRY(dvid_mha_core_launch(m->f32b.as<float>(), kv, kv + d, nullptr, 1, rows, lk, m->cfg.nheads, d / m->cfg.nheads, d, 2 * d, d, 0, 0,
+                             0, m->attn16.as<half_t>(), s));
+    TRY(linear_run(m->gout, m->attn16.as<half_t>(), rows, out, 0, 1, s));
+    return DVID_OK;
+}
+
+// ---- stand-alone ops ---------------------------------------------------------------------------
+int dvid_roialign_v2_multilevel(const void* p3, const void* p4, const void* p5, int n_frames, int height, int width, int channels,
+                                const float* boxes, int boxes_per_frame, void* roi_out, float* mean_out, void* stream) {
+    g_err[0] = 0;
+    if (height % 32 || width % 32) FAIL(DVID_ERR_ARG, "height/width must be multiples of 32");
+    RoiLevels lv;
+    const void* pl[3] = {p3, p4, p5};
+    for (int l = 0; l < 3; ++l) {
+        lv.feat[l] = reinterpret_cast<const half_t*>(pl[l]);
+        lv.h[l] = height >> (3 + l);
+        lv.w[l] = width >> (3 + l);
+        lv.scale[l] = 1.f / (float)(8 << l);
+    }
+    TRY(dvid_roialign_launch(lv, channels, boxes, n_frames, boxes_per_frame, reinterpret_cast<half_t*>(roi_out), mean_out,
+                             reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_select_topk_features(const float* logits, int n_frames, int mm, int num_classes, int k1, int k2, const float* feats,
+                              int hidden, float* out_k1, float* out_k2, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_topk_mask_launch(logits, n_frames, mm, num_classes, k1, k2, feats, hidden, out_k1, out_k2,
+                              reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_noise_to_boxes(const float* x, float* boxes, int n, float snr_scale, float img_w, float img_h, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_noise_to_boxes_launch(x, boxes, n, snr_scale, img_w, img_h, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_postproc_topk_nms(const float* logits, const float* boxes, int nsets, int n_frames, int mm, int c, float img_w, float img_h,
+                           float iou_threshold, int use_nms, float* out_boxes, float* out_scores, int* out_labels, int* out_counts,
+                           void* scratch, void* stream) {
+    g_err[0] = 0;
+    if (!scratch) FAIL(DVID_ERR_ARG, "scratch required");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t ncand = (size_t)n_frames * nsets * mm;
+    float* cb = reinterpret_cast<float*>(scratch);
+    float* cs = cb + ncand * 4;
+    int* cl = reinterpret_cast<int*>(cs + ncand);
+    TRY(dvid_topk_candidates_launch(logits, boxes, n_frames, nsets, mm, c, cb, cs, cl, s));
+    TRY(dvid_nms_frames_launch(cb, cs, cl, n_frames, nsets * mm, img_w, img_h, iou_threshold, use_nms, nsets * mm, out_boxes,
+                               out_scores, out_labels, out_counts, s));
+    return DVID_OK;
+}
+
+int dvid_cdist(const float* x, int n, int d, float* dist, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_cdist_launch(x, n, d, dist, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+int dvid_fps_greedy(const float* dist, int n, int mm, int bs_emul, int* idx, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_fps_launch(dist, n, mm, bs_emul, idx, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+int dvid_gather_rows(const float* x, const int* idx, float* y, int mm, int d, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_gather_rows_launch(x, idx, y, mm, d, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const void* residual, void* out, int n, int h, int wd,
+                         int cin, int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int out_f32, int residual_mode,
+                         void* stream) {
+    g_err[0] = 0;
+    ConvW cw;
+    cw.w = reinterpret_cast<half_t*>(const_cast<void*>(w));
+    cw.bias = const_cast<float*>(bias);
+    cw.cin = cin;
+    cw.cout = cout;
+    cw.kh = kh;
+    cw.kw = kw;
+    cw.stride = stride;
+    cw.pad = pad;
+    cw.kpad = kpad;
+    TRY(conv_run(cw, reinterpret_cast<const half_t*>(in), n, h, wd, out, relu, out_f32, residual, residual_mode, 0,
+                 reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_mha_core(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int head_dim,
+                  int q_ld, int kv_ld, int out_ld, int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_mha_core_launch(q, k, v, out, batch, lq, lk, nheads, head_dim, q_ld, kv_ld, out_ld, q_bs, kv_bs, out_bs, nullptr,
+                             reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_dynconv(const void* roi, const void* params, const float* g1, const float* b1, const float* g2, const float* b2, void* out,
+                 int rows, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_dynconv_launch(reinterpret_cast<const half_t*>(roi), reinterpret_cast<const half_t*>(params), g1, b1, g2, b2,
+                            reinterpret_cast<half_t*>(out), rows, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_add_layernorm(const float* x, const float* r, const float* g, const float* b, float* y, int rows, int d, int relu,
+                       void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_add_layernorm_launch(x, r, g, b, y, nullptr, rows, d, relu, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_nhwc_from_nchw(const float* in, void* out_f16, int n, int h, int w, int c, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_nhwc_from_nchw_launch(in, reinterpret_cast<half_t*>(out_f16), n, h, w, c, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+int dvid_nchw_from_nhwc(const void* in_f16, float* out, int n, int h, int w, int c, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_nchw_from_nhwc_launch(reinterpret_cast<const half_t*>(in_f16), out, n, h, w, c, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+int dvid_f32_to_f16(const float* x, void* y, int64_t n, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_f32_to_f16_launch(x, reinterpret_cast<half_t*>(y), (long)n, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------
+int dvid_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return DVID_OK;
+}
+int dvid_profile_reset(void) {
+    for (auto& r : g_prof) g_prof_pool.push_back(r);
+    g_prof.clear();
+    return DVID_OK;
+}
+int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches) {
+    g_err[0] = 0;
+    double ms = 0, fl = 0;
+    for (auto& r : g_prof) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        ms += t;
+        fl += r.flop;
+    }
+    if (igemm_ms) *igemm_ms = ms;
+    if (igemm_flop) *igemm_flop = fl;
+    if (igemm_launches) *igemm_launches = (int64_t)g_prof.size();
+    return DVID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// Multi-level RoIAlignV2 (aligned=True, 7x7 bins, 2x2 samples) over NHWC fp16 pyramids.
+//
+// Replaces detectron2 ROIPooler(ROIAlignV2) as called at box_head.py:507/:617 (restated in
+// oracle/roi_align.py).  HBM/L2-bound gather: one workgroup per box; 32 lanes x 8 channels
+// (16-byte loads) cover the 256-channel vector of one tap, the 8 lane-groups of the block
+// walk the 49 bins.  Output is [box][bin][channel] fp16 -- exactly the A operand of the
+// DynamicConv batched matmul -- plus the optional fp32 mean over the 49 bins that RCNNHead
+// uses as initial proposal features (box_head.py:509-510).  Coordinate math is fp32.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int P = 7;       // pooler resolution
+constexpr int G = 2;       // sampling ratio
+constexpr int CV = 32;     // 8-channel vectors per pixel (C = 256)
+
+struct Tap {
+    int lo, hi;
+    float wl, wh;
+    bool ok;
+};
+
+// torchvision bilinear_interpolate, one axis
+__device__ __forceinline__ Tap axis_tap(float y, int limit) {
+    Tap t;
+    t.ok = !(y < -1.0f || y > (float)limit);
+    if (y <= 0.f) y = 0.f;
+    int lo = (int)y;
+    int hi;
+    if (lo >= limit - 1) {
+        hi = lo = limit - 1;
+        y = (float)lo;
+    } else {
+        hi = lo + 1;
+    }
+    const float l = y - (float)lo;
+    t.lo = lo;
+    t.hi = hi;
+    t.wl = 1.f - l;  // weight of lo
+    t.wh = l;        // weight of hi
+    return t;
+}
+
+__global__ __launch_bounds__(256) void roialign_kernel(RoiLevels lv, const float* __restrict__ boxes, int boxes_per_img,
+                                                        half_t* __restrict__ roi_out, float* __restrict__ mean_out) {
+    __shared__ float red[8][256];
+    const int box = blockIdx.x;
+    const int img = box / boxes_per_img;
+    const int tid = threadIdx.x;
+    const int grp = tid >> 5, ln = tid & 31;
+
+    const float bx1 = boxes[box * 4 + 0], by1 = boxes[box * 4 + 1], bx2 = boxes[box * 4 + 2], by2 = boxes[box * 4 + 3];
+    // detectron2 assign_boxes_to_levels (canonical 224 / level 4, levels 3..5)
+    const float area = (bx2 - bx1) * (by2 - by1);
+    const bool valid_box = area >= 0.f;  // NaN / negative area: upstream matches no level -> zeros
+    float lvf = floorf(4.f + log2f(sqrtf(area) / 224.f + 1e-8f));
+    lvf = fminf(fmaxf(lvf, 3.f), 5.f);
+    const int level = valid_box ? (int)lvf - 3 : 0;
+
+    const half_t* feat = lv.feat[level];
+    const int H = lv.h[level], W = lv.w[level];
+    const float sc = lv.scale[level];
+    feat += (long)img * H * W * (CV * 8);
+
+    const float x1 = bx1 * sc - 0.5f, y1 = by1 * sc - 0.5f;
+    const float x2 = bx2 * sc - 0.5f, y2 = by2 * sc - 0.5f;
+    const float bin_w = (x2 - x1) / P, bin_h = (y2 - y1) / P;
+
+    float macc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) macc[e] = 0.f;
+
+    for (int p = grp; p < P * P; p += 8) {
+        const int ph = p / P, pw = p - ph * P;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (valid_box) {
+#pragma unroll
+            for (int iy = 0; iy < G; ++iy) {
+                const float y = y1 + ph * bin_h + (iy + 0.5f) * bin_h / G;
+                const Tap ty = axis_tap(y, H);
+#pragma unroll
+                for (int ix = 0; ix < G; ++ix) {
+                    const float x = x1 + pw * bin_w + (ix + 0.5f) * bin_w / G;
+                    const Tap tx = axis_tap(x, W);
+                    if (!(ty.ok && tx.ok)) continue;
+                    const half8 v1 = *reinterpret_cast<const half8*>(feat + ((long)ty.lo * W + tx.lo) * (CV * 8) + ln * 8);
+                    const half8 v2 = *reinterpret_cast<const half8*>(feat + ((long)ty.lo * W + tx.hi) * (CV * 8) + ln * 8);
+                    const half8 v3 = *reinterpret_cast<const half8*>(feat + ((long)ty.hi * W + tx.lo) * (CV * 8) + ln * 8);
+                    const half8 v4 = *reinterpret_cast<const half8*>(feat + ((long)ty.hi * W + tx.hi) * (CV * 8) + ln * 8);
+                    const float w1 = ty.wl * tx.wl, w2 = ty.wl * tx.wh, w3 = ty.wh * tx.wl, w4 = ty.wh * tx.wh;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        acc[e] += w1 * (float)v1[e] + w2 * (float)v2[e] + w3 * (float)v3[e] + w4 * (float)v4[e];
+                }
+            }
+        }
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[e] *= 1.f / (G * G);
+            macc[e] += acc[e];
+            o[e] = (half_t)acc[e];
+        }
+        *reinterpret_cast<half8*>(roi_out + ((long)box * (P * P) + p) * (CV * 8) + ln * 8) = o;
+    }
+    if (mean_out) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[grp][ln * 8 + e] = macc[e];
+        __syncthreads();
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += red[g][tid];
+        mean_out[(long)box * 256 + tid] = s / (P * P);
+    }
+}
+
+}  // namespace
+
+int dvid_roialign_launch(const RoiLevels& lv, int channels, const float* boxes, int n_img, int boxes_per_img, half_t* roi_out,
+                         float* mean_out, hipStream_t s) {
+    if (channels != 256) return DVID_ERR_UNSUPPORTED;
+    const int nbox = n_img * boxes_per_img;
+    if (nbox == 0) return DVID_OK;
+    hipLaunchKernelGGL(roialign_kernel, dim3(nbox), dim3(256), 0, s, lv, boxes, boxes_per_img, roi_out, mean_out);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}

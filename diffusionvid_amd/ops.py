@@ -1,0 +1,260 @@
+"""Tensor-level wrappers over the libdvid_hip C ABI (torch supplies device memory and streams only).
+
+Every function launches HIP kernels on the current torch stream; none falls back to torch math.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+
+def _cuda(t, dtype=None):
+    if not t.is_cuda:
+        raise _lib.DvidError("libdvid_hip ops need tensors on the GPU (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def nhwc_from_nchw(x):
+    """fp32 NCHW -> fp16 NHWC."""
+    x = _cuda(x, torch.float32)
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.float16, device=x.device)
+    call("dvid_nhwc_from_nchw", ptr(x), ptr(out), n, h, w, c, stream_ptr())
+    return out
+
+
+def nchw_from_nhwc(x):
+    """fp16 NHWC -> fp32 NCHW."""
+    x = _cuda(x, torch.float16)
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    call("dvid_nchw_from_nhwc", ptr(x), ptr(out), n, h, w, c, stream_ptr())
+    return out
+
+
+def pack_conv_weight(w, cin_pad=0):
+    """OIHW fp32 (or [out,in]) -> fp16 [cout, kpad] with k = (ky*kw+kx)*cin + c (host side repack)."""
+    w = w.detach().float().cpu()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    cout, cin, kh, kw = w.shape
+    cp = cin_pad or cin
+    kreal = kh * kw * cp
+    kpad = (kreal + 63) // 64 * 64
+    packed = torch.zeros((cout, kh * kw, cp), dtype=torch.float32)
+    packed[:, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    out = torch.zeros((cout, kpad), dtype=torch.float16)
+    out[:, :kreal] = packed.reshape(cout, kreal).to(torch.float16)
+    return out, kpad
+
+
+def conv2d_nhwc(x, w_packed, kpad, bias, cout, kh, kw, stride, pad, relu=False, residual=None, residual_mode=0,
+                out_f32=False):
+    """x fp16 NHWC; returns NHWC fp16 (or fp32)."""
+    x = _cuda(x, torch.float16)
+    n, h, wd, cin = x.shape
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (wd + 2 * pad - kw) // stride + 1
+    out = torch.empty((n, ho, wo, cout), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
+    call("dvid_conv2d_nhwc_f16", ptr(x), ptr(w_packed), ptr(bias), ptr(residual), ptr(out), n, h, wd, cin, cout, kh, kw,
+         stride, pad, kpad, int(relu), int(out_f32), residual_mode, stream_ptr())
+    return out
+
+
+def linear(x16, w_packed, kpad, bias, relu=False, out_f32=True):
+    rows, k = x16.shape
+    y = conv2d_nhwc(x16.view(rows, 1, 1, k), w_packed, kpad, bias, w_packed.shape[0], 1, 1, 1, 0, relu=relu, out_f32=out_f32)
+    return y.view(rows, -1)
+
+
+def roialign(feats_nhwc, boxes, height, width, want_mean=False):
+    """feats_nhwc: [p3,p4,p5] fp16 NHWC; boxes fp32 [n, M, 4] -> roi fp16 [n*M, 49, C] (+ mean fp32 [n*M, C])."""
+    p3, p4, p5 = (_cuda(f, torch.float16) for f in feats_nhwc)
+    boxes = _cuda(boxes, torch.float32)
+    n, M = boxes.shape[:2]
+    c = p3.shape[-1]
+    roi = torch.empty((n * M, 49, c), dtype=torch.float16, device=boxes.device)
+    mean = torch.empty((n * M, c), dtype=torch.float32, device=boxes.device) if want_mean else None
+    call("dvid_roialign_v2_multilevel", ptr(p3), ptr(p4), ptr(p5), n, height, width, c, ptr(boxes), M, ptr(roi), ptr(mean),
+         stream_ptr())
+    return (roi, mean) if want_mean else roi
+
+
+def mha_core(q, k, v, nheads):
+    """q [B, Lq, d], k/v [B, Lk, d] fp32 (already projected) -> [B, Lq, d]."""
+    q, k, v = _cuda(q, torch.float32), _cuda(k, torch.float32), _cuda(v, torch.float32)
+    B, lq, d = q.shape
+    lk = k.shape[1]
+    out = torch.empty_like(q)
+    call("dvid_mha_core", ptr(q), ptr(k), ptr(v), ptr(out), B, lq, lk, nheads, d // nheads, d, d, d, lq * d, lk * d, lq * d,
+         stream_ptr())
+    return out
+
+
+def dynconv(roi16, params16, g1, b1, g2, b2):
+    roi16, params16 = _cuda(roi16, torch.float16), _cuda(params16, torch.float16)
+    out = torch.empty_like(roi16)
+    call("dvid_dynconv", ptr(roi16), ptr(params16), ptr(g1), ptr(b1), ptr(g2), ptr(b2), ptr(out), roi16.shape[0], stream_ptr())
+    return out
+
+
+def add_layernorm(x, r, g, b, relu=False):
+    x = _cuda(x, torch.float32)
+    y = torch.empty_like(x)
+    call("dvid_add_layernorm", ptr(x), ptr(r), ptr(g), ptr(b), ptr(y), x.shape[0], x.shape[1], int(relu), stream_ptr())
+    return y
+
+
+def noise_to_boxes(x, snr_scale, img_w, img_h):
+    x = _cuda(x, torch.float32)
+    out = torch.empty_like(x)
+    call("dvid_noise_to_boxes", ptr(x), ptr(out), x.numel() // 4, float(snr_scale), float(img_w), float(img_h), stream_ptr())
+    return out
+
+
+def select_topk_features(logits, feats, k1, k2):
+    """logits [n, M, C], feats [n*M, d] -> ([n*k1, d], [n*k2, d]) in box-index (mask) order."""
+    logits, feats = _cuda(logits, torch.float32), _cuda(feats, torch.float32)
+    n, M, c = logits.shape
+    d = feats.shape[-1]
+    o1 = torch.empty((n * k1, d), dtype=torch.float32, device=feats.device)
+    o2 = torch.empty((n * k2, d), dtype=torch.float32, device=feats.device)
+    call("dvid_select_topk_features", ptr(logits), n, M, c, k1, k2, ptr(feats), d, ptr(o1), ptr(o2), stream_ptr())
+    return o1, o2
+
+
+def postproc_topk_nms(logits, boxes, img_w, img_h, iou=0.5, use_nms=True):
+    """logits [S, n, M, C] (or [n, M, C]), boxes [S, n, M, 4] -> (boxes [n,S*M,4], scores, labels int32, counts int32)."""
+    if logits.dim() == 3:
+        logits, boxes = logits[None], boxes[None]
+    logits, boxes = _cuda(logits, torch.float32), _cuda(boxes, torch.float32)
+    S, n, M, c = logits.shape
+    dev = logits.device
+    ob = torch.empty((n, S * M, 4), dtype=torch.float32, device=dev)
+    osc = torch.empty((n, S * M), dtype=torch.float32, device=dev)
+    ol = torch.empty((n, S * M), dtype=torch.int32, device=dev)
+    oc = torch.empty((n,), dtype=torch.int32, device=dev)
+    scratch = torch.empty((n * S * M * 6,), dtype=torch.float32, device=dev)
+    call("dvid_postproc_topk_nms", ptr(logits), ptr(boxes), S, n, M, c, float(img_w), float(img_h), float(iou), int(use_nms),
+         ptr(ob), ptr(osc), ptr(ol), ptr(oc), ptr(scratch), stream_ptr())
+    return ob, osc, ol, oc
+
+
+def cdist(x):
+    x = _cuda(x, torch.float32)
+    n, d = x.shape
+    out = torch.empty((n, n), dtype=torch.float32, device=x.device)
+    call("dvid_cdist", ptr(x), n, d, ptr(out), stream_ptr())
+    return out
+
+
+def fps_greedy(dist, m, bs_emul=0):
+    dist = _cuda(dist, torch.float32)
+    n = dist.shape[0]
+    idx = torch.empty((m,), dtype=torch.int32, device=dist.device)
+    call("dvid_fps_greedy", ptr(dist), n, m, bs_emul, ptr(idx), stream_ptr())
+    return idx
+
+
+def gather_rows(x, idx):
+    x = _cuda(x, torch.float32)
+    idx = _cuda(idx, torch.int32)
+    out = torch.empty((idx.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    call("dvid_gather_rows", ptr(x), ptr(idx), ptr(out), idx.shape[0], x.shape[1], stream_ptr())
+    return out
+
+
+def update_erase_memory(feats_new, feats_mem, target_size):
+    """diffusion_det.py:841-867 on device: cat -> (cdist -> greedy FPS -> gather) if over target."""
+    merged = feats_new if feats_mem is None else torch.cat([feats_mem, feats_new], dim=0)
+    merged = merged.contiguous()
+    if merged.shape[0] <= target_size:
+        return merged, None
+    idx = fps_greedy(cdist(merged), target_size)
+    return gather_rows(merged, idx), idx
+
+
+class Model:
+    """Owns a dvid_model handle: repacked weights + activation workspace on the current device."""
+
+    def __init__(self, state_dict, *, hidden_dim=256, nheads=8, dim_feedforward=2048, dim_dynamic=64, num_classes=30,
+                 num_cls=1, num_reg=3, num_heads=3, num_heads_cond=1, pooler_resolution=7, sampling_ratio=2,
+                 res_blocks=(3, 4, 23, 3), pixel_mean=(123.675, 116.280, 103.530), pixel_std=(58.395, 57.120, 57.375)):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.DvidError("no HIP device visible: the DiffusionVID hot path runs only on the GPU (no CPU fallback)")
+        cfg = _lib.DvidConfig(hidden_dim, nheads, dim_feedforward, dim_dynamic, num_classes, num_cls, num_reg, num_heads,
+                              num_heads_cond, pooler_resolution, sampling_ratio, (C.c_int * 4)(*res_blocks),
+                              (C.c_float * 3)(*pixel_mean), (C.c_float * 3)(*pixel_std))
+        self.cfg = cfg
+        h = C.c_void_p()
+        _lib.check(lib.dvid_model_create(C.byref(cfg), C.byref(h)), "dvid_model_create")
+        self.handle = h
+        self.hidden_dim, self.num_classes, self.nheads = hidden_dim, num_classes, nheads
+        self.has_backbone = res_blocks[0] > 0
+        wanted = ("head.", "backbone.") if self.has_backbone else ("head.",)
+        for name, t in state_dict.items():
+            if not name.startswith(wanted) or not torch.is_floating_point(t):
+                continue
+            t = t.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(lib.dvid_model_set_tensor(h, name.encode(), t.data_ptr(), shape, t.dim()), f"set_tensor({name})")
+        _lib.check(lib.dvid_model_finalize(h), "dvid_model_finalize")
+        self._ws = None
+
+    def reserve(self, max_frames, height, width, boxes_per_frame):
+        key = (max_frames, height, width, boxes_per_frame)
+        if self._ws != key:
+            call("dvid_workspace_reserve", self.handle, max_frames, height, width, boxes_per_frame)
+            self._ws = key
+
+    def backbone(self, images):
+        """images fp32 NCHW [n,3,H,W] in [0,1] -> (p3, p4, p5) fp16 NHWC."""
+        images = _cuda(images, torch.float32)
+        n, _, h, w = images.shape
+        dev = images.device
+        outs = [torch.empty((n, h >> s, w >> s, self.hidden_dim), dtype=torch.float16, device=dev) for s in (3, 4, 5)]
+        call("dvid_backbone_resnet_fpn", self.handle, ptr(images), n, h, w, ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream_ptr())
+        return outs
+
+    def rcnn_head(self, head_index, feats_nhwc, height, width, boxes, pro_features, t, cond=None, bad_flag=None):
+        """One RCNNHead / RCNNHead_cond pass.  boxes [n, M, 4]; pro_features [n*M, d] or None; t: int64 [n] (CPU)."""
+        boxes = _cuda(boxes, torch.float32)
+        n, M = boxes.shape[:2]
+        dev = boxes.device
+        d = self.hidden_dim
+        logits = torch.empty((n, M, self.num_classes), dtype=torch.float32, device=dev)
+        boxes_out = torch.empty((n, M, 4), dtype=torch.float32, device=dev)
+        obj = torch.empty((n * M, d), dtype=torch.float32, device=dev)
+        t = torch.as_tensor(t, dtype=torch.int64, device="cpu").contiguous()
+        assert t.numel() == n
+        tp = C.cast(t.data_ptr(), C.POINTER(C.c_int64))
+        if pro_features is not None:
+            pro_features = _cuda(pro_features, torch.float32)
+        if cond is not None:
+            cond = _cuda(cond, torch.float32)
+        call("dvid_rcnn_head", self.handle, head_index, int(cond is not None), ptr(feats_nhwc[0]), ptr(feats_nhwc[1]),
+             ptr(feats_nhwc[2]), n, height, width, M, ptr(boxes), ptr(pro_features), tp, ptr(cond), ptr(logits), ptr(boxes_out),
+             ptr(obj), ptr(bad_flag), stream_ptr())
+        return logits, boxes_out, obj
+
+    def global_xattn(self, query, memory):
+        query, memory = _cuda(query, torch.float32), _cuda(memory, torch.float32)
+        out = torch.empty_like(query)
+        call("dvid_global_xattn", self.handle, ptr(query), query.shape[0], ptr(memory), memory.shape[0], ptr(out), stream_ptr())
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().dvid_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,137 @@
+"""Seeded synthetic weights, frames and noise (there is no checkpoint or dataset in the build box).
+
+Shapes and names follow the reference state_dict contract: `backbone.bottom_up.*`,
+`backbone.fpn_*` (detectron2 names) and `head.*` (mega_core/modeling/roi_heads/box_head/box_head.py).
+Head init mirrors DynamicHead._reset_parameters (box_head.py:239-248): xavier_uniform_ for every
+matrix, focal-prior bias on class_logits; norms/biases get small random values so that a kernel
+which ignores an affine term cannot pass parity.  Backbone: He-normal convs with FrozenBN
+statistics chosen so activations stay O(1) through 33 residual blocks (fp16-safe).
+"""
+import math
+
+import torch
+
+
+def _xavier(g, out_f, in_f):
+    bound = math.sqrt(6.0 / (in_f + out_f))
+    return (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound
+
+
+def _bias(g, n, fan_in):
+    b = 1.0 / math.sqrt(fan_in)
+    return (torch.rand(n, generator=g) * 2 - 1) * b
+
+
+def _ln(g, sd, name, d):
+    sd[name + ".weight"] = torch.rand(d, generator=g) * 0.6 + 0.7
+    sd[name + ".bias"] = (torch.rand(d, generator=g) * 2 - 1) * 0.2
+
+
+def make_head_state_dict(seed=0, hidden=256, nheads=8, dim_ff=2048, dim_dynamic=64, num_classes=30, num_cls=1, num_reg=3,
+                         num_heads=3, num_heads_cond=1, pooler=7, prior_prob=0.01, prefix="head."):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    d = hidden
+
+    def linear(name, out_f, in_f, bias=True):
+        sd[name + ".weight"] = _xavier(g, out_f, in_f)
+        if bias:
+            sd[name + ".bias"] = _bias(g, out_f, in_f)
+
+    def mha(name):
+        sd[name + ".in_proj_weight"] = _xavier(g, 3 * d, d)
+        sd[name + ".in_proj_bias"] = (torch.rand(3 * d, generator=g) * 2 - 1) * 0.1
+        sd[name + ".out_proj.weight"] = _xavier(g, d, d)
+        sd[name + ".out_proj.bias"] = (torch.rand(d, generator=g) * 2 - 1) * 0.1
+
+    def head(p, cond):
+        mha(p + ".self_attn")
+        linear(p + ".inst_interact.dynamic_layer", 2 * d * dim_dynamic, d)
+        _ln(g, sd, p + ".inst_interact.norm1", dim_dynamic)
+        _ln(g, sd, p + ".inst_interact.norm2", d)
+        linear(p + ".inst_interact.out_layer", d, d * pooler * pooler)
+        _ln(g, sd, p + ".inst_interact.norm3", d)
+        linear(p + ".linear1", dim_ff, d)
+        linear(p + ".linear2", d, dim_ff)
+        for n in ("norm1", "norm2", "norm3"):
+            _ln(g, sd, f"{p}.{n}", d)
+        linear(p + ".block_time_mlp.1", d if cond else 2 * d, 4 * d)
+        for i in range(num_cls):
+            linear(f"{p}.cls_module.{3 * i}", d, d, bias=False)
+            _ln(g, sd, f"{p}.cls_module.{3 * i + 1}", d)
+        for i in range(num_reg):
+            linear(f"{p}.reg_module.{3 * i}", d, d, bias=False)
+            _ln(g, sd, f"{p}.reg_module.{3 * i + 1}", d)
+        linear(p + ".class_logits", num_classes, d)
+        sd[p + ".class_logits.bias"] = torch.full((num_classes,), -math.log((1 - prior_prob) / prior_prob))
+        linear(p + ".bboxes_delta", 4, d)
+        if cond:
+            linear(p + ".c_mlp.1", d, d)
+
+    for i in range(num_heads):
+        head(f"{prefix}head_series.{i}", False)
+    for i in range(num_heads_cond):
+        head(f"{prefix}head_series_cond.{i}", True)
+    mha(prefix + "global_attention.0.0")
+    linear(prefix + "time_mlp.1", 4 * d, d)
+    linear(prefix + "time_mlp.3", 4 * d, 4 * d)
+    return sd
+
+
+def make_backbone_state_dict(seed=1, blocks=(3, 4, 23, 3), out_channels=256, prefix="backbone."):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv_bn(name, cout, cin, k, gamma=(0.8, 1.2)):
+        fan_in = cin * k * k
+        sd[name + ".weight"] = torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / fan_in)
+        sd[name + ".norm.weight"] = torch.rand(cout, generator=g) * (gamma[1] - gamma[0]) + gamma[0]
+        sd[name + ".norm.bias"] = (torch.rand(cout, generator=g) * 2 - 1) * 0.1
+        sd[name + ".norm.running_mean"] = (torch.rand(cout, generator=g) * 2 - 1) * 0.1
+        sd[name + ".norm.running_var"] = torch.rand(cout, generator=g) * 0.4 + 0.8
+
+    bu = prefix + "bottom_up."
+    conv_bn(bu + "stem.conv1", 64, 3, 7)
+    cin = 64
+    for s, nb in enumerate(blocks):
+        width, cout = 64 << s, 256 << s
+        for b in range(nb):
+            p = f"{bu}res{s + 2}.{b}"
+            conv_bn(p + ".conv1", width, cin, 1)
+            conv_bn(p + ".conv2", width, width, 3)
+            conv_bn(p + ".conv3", cout, width, 1, gamma=(0.2, 0.4))   # damp the residual branch
+            if b == 0:
+                conv_bn(p + ".shortcut", cout, cin, 1)
+            cin = cout
+    for lvl, c in zip((3, 4, 5), (512, 1024, 2048)):
+        fan = c
+        sd[f"{prefix}fpn_lateral{lvl}.weight"] = (torch.rand(out_channels, c, 1, 1, generator=g) * 2 - 1) * math.sqrt(3.0 / fan)
+        sd[f"{prefix}fpn_lateral{lvl}.bias"] = (torch.rand(out_channels, generator=g) * 2 - 1) * 0.05
+        fan = out_channels * 9
+        sd[f"{prefix}fpn_output{lvl}.weight"] = (torch.rand(out_channels, out_channels, 3, 3, generator=g) * 2 - 1) * math.sqrt(3.0 / fan)
+        sd[f"{prefix}fpn_output{lvl}.bias"] = (torch.rand(out_channels, generator=g) * 2 - 1) * 0.05
+    return sd
+
+
+def make_state_dict(seed=0, blocks=(3, 4, 23, 3), **head_kw):
+    sd = make_head_state_dict(seed, **head_kw)
+    sd.update(make_backbone_state_dict(seed + 1, blocks))
+    return sd
+
+
+def synthetic_frame(index, height=600, width=1000, video=0):
+    """torch.rand(3,600,1000) fp32 in [0,1), seed 1000+i (post-ToTensor domain)."""
+    g = torch.Generator().manual_seed(1000 + index + 100003 * video)
+    return torch.rand(3, height, width, generator=g)
+
+
+_KINDS = {"box_init": 0, "img": 1, "ddim": 2, "renew": 3}
+
+
+def noise_fn(kind, frame_id, step, image, shape, video=0):
+    """Injected N(0,1) draws shared by the CPU oracle and the GPU path (the reference draws them on
+    the device at diffusion_det.py:449,:542,:587,:595).  Keyed by (video, call frame, kind, step,
+    image), not by RNG stream position, so 8-frame batches can be sharded across ranks."""
+    seed = 2000 + ((((video * 100003 + frame_id) * 4 + _KINDS[kind]) * 64 + step) * 64 + image)
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g)

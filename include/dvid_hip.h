@@ -1,0 +1,140 @@
+/* libdvid_hip -- MI355X (gfx950) native DiffusionVID inference hot path, C ABI.
+ *
+ * Drop-in boundary for the reference's per-batch compute (sdroh1027/DiffusionVID).  Every entry
+ * point takes plain device/host pointers and sizes, enqueues work on the HIP stream given
+ * (`stream` = hipStream_t, NULL = default stream), performs no hidden synchronisation and returns
+ * 0 on success (see DVID_* codes; dvid_last_error() has the text).  The Python host side
+ * (diffusionvid_amd/) binds these with ctypes on torch `data_ptr()`s; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo root):
+ *   dvid_backbone_resnet_fpn   detectron2 build_resnet_fpn_backbone called at
+ *                              mega_core/modeling/detector/diffusion_det.py:219,:427 (+ normalizer :301-303,:422)
+ *   dvid_rcnn_head             RCNNHead.forward / RCNNHead_cond.forward, DynamicConv.forward, apply_deltas
+ *                              mega_core/modeling/roi_heads/box_head/box_head.py:495-548, :605-664, :687-711, :550-590
+ *   dvid_roialign_v2_multilevel detectron2 ROIPooler(ROIAlignV2) built at box_head.py:250-271, called :507,:617
+ *   dvid_global_xattn          nn.MultiheadAttention global stage, box_head.py:366-380
+ *   dvid_select_topk_features  box_head.py:304-317
+ *   dvid_noise_to_boxes        diffusion_det.py:657-660
+ *   dvid_postproc_topk_nms     DiffusionDet.inference + detectron2 batched_nms + BoxList.clip_to_image
+ *                              diffusion_det.py:754-839, :607-627; structures/bounding_box.py:214-224
+ *   dvid_cdist / dvid_fps_greedy / dvid_gather_rows
+ *                              update_erase_memory / select_farthest_k_greedy_cuda, diffusion_det.py:841-896;
+ *                              mega_core/csrc/fps.h:15-36 + csrc/cuda/fps.cu:25-185 (`_C.furthest_point_sampling`)
+ *   dvid_model_set_tensor      DetectronCheckpointer.load name contract, mega_core/utils/model_serialization.py:12-73
+ *
+ * Layouts: images fp32 NCHW in [0,1] (what the reference model receives); feature maps fp16 NHWC
+ * (channels fastest); boxes fp32 xyxy absolute pixels; object features fp32 [rows, hidden].
+ */
+#ifndef DVID_HIP_H
+#define DVID_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVID_OK 0
+#define DVID_ERR_ARG 1
+#define DVID_ERR_HIP 2
+#define DVID_ERR_UNSUPPORTED 3
+#define DVID_ERR_STATE 4
+
+typedef struct dvid_model dvid_model;
+
+typedef struct dvid_config {
+    int hidden_dim;        /* MODEL.DiffusionDet.HIDDEN_DIM      (256) */
+    int nheads;            /* MODEL.DiffusionDet.NHEADS          (8)   */
+    int dim_feedforward;   /* MODEL.DiffusionDet.DIM_FEEDFORWARD (2048) */
+    int dim_dynamic;       /* MODEL.DiffusionDet.DIM_DYNAMIC     (64)  */
+    int num_classes;       /* MODEL.DiffusionDet.NUM_CLASSES     (30)  */
+    int num_cls;           /* MODEL.DiffusionDet.NUM_CLS         (1)   */
+    int num_reg;           /* MODEL.DiffusionDet.NUM_REG         (3)   */
+    int num_heads;         /* MODEL.DiffusionDet.NUM_HEADS       (3)   head_series */
+    int num_heads_cond;    /* MODEL.DiffusionDet.NUM_HEADS_LOCAL (1)   head_series_cond */
+    int pooler_resolution; /* MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION (7) */
+    int sampling_ratio;    /* MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO (2) */
+    int res_blocks[4];     /* bottleneck blocks per stage, {3,4,23,3} for R-101; all 0 = no backbone */
+    float pixel_mean[3];   /* MODEL.PIXEL_MEAN (0..255 scale) */
+    float pixel_std[3];
+} dvid_config;
+
+const char* dvid_last_error(void);
+int dvid_version(void);
+
+/* ---- model: weights (host fp32 in, repacked fp16 on device) + workspace ---------------------- */
+int dvid_model_create(const dvid_config* cfg, dvid_model** out);
+int dvid_model_destroy(dvid_model* m);
+/* state_dict entry, reference parameter names ("backbone.bottom_up.res2.0.conv1.weight",
+ * "head.head_series.0.inst_interact.dynamic_layer.weight", ...); data is copied. */
+int dvid_model_set_tensor(dvid_model* m, const char* name, const float* data, const int64_t* shape, int ndim);
+/* fold FrozenBN, repack to MFMA operand layouts, upload.  Fails (DVID_ERR_STATE) naming the first
+ * missing tensor. */
+int dvid_model_finalize(dvid_model* m);
+/* (re)allocate the activation workspace for batches of up to max_frames frames of height x width
+ * (multiples of 32) and boxes_per_frame boxes. */
+int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width, int boxes_per_frame);
+
+/* ---- stages -------------------------------------------------------------------------------- */
+/* images: fp32 NCHW [n,3,height,width] in [0,1] (zero padded, un-normalised).  Outputs fp16 NHWC
+ * p3 [n,h/8,w/8,256], p4 [n,h/16,w/16,256], p5 [n,h/32,w/32,256]. */
+int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
+                             void* stream);
+
+/* One RCNNHead (cond == NULL) or RCNNHead_cond pass.  head_index indexes head_series, or
+ * head_series_cond when is_cond.  t: host int64 [n_frames] diffusion timesteps.
+ * pro_features may be NULL (-> mean of the RoI features).  Outputs: logits [R,num_classes],
+ * boxes [R,4], obj_features [R,hidden] (fp32, R = n_frames*boxes_per_frame).
+ * bad_box_flag (device int, may be NULL) is OR-ed with 1 if any predicted box has x2<x1 or y2<y1
+ * (the reference's AssertionError at box_head.py:588, reported without a host sync). */
+int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, const void* p4, const void* p5, int n_frames,
+                   int height, int width, int boxes_per_frame, const float* boxes, const float* pro_features,
+                   const int64_t* t, const float* cond, float* logits, float* boxes_out, float* obj_features,
+                   int* bad_box_flag, void* stream);
+
+/* cond[R,hidden] = MHA(query = obj_features[R,hidden], key = value = memory[lk,hidden]) */
+int dvid_global_xattn(dvid_model* m, const float* query, int rows, const float* memory, int lk, float* out, void* stream);
+
+/* ---- stand-alone ops (also used by the parity tests) -------------------------------------- */
+int dvid_roialign_v2_multilevel(const void* p3, const void* p4, const void* p5, int n_frames, int height, int width,
+                                int channels, const float* boxes, int boxes_per_frame, void* roi_out /* fp16 [R,49,C] */,
+                                float* mean_out /* [R,C] or NULL */, void* stream);
+int dvid_select_topk_features(const float* logits, int n_frames, int m, int num_classes, int k1, int k2, const float* feats,
+                              int hidden, float* out_k1, float* out_k2, void* stream);
+int dvid_noise_to_boxes(const float* x, float* boxes, int n, float snr_scale, float img_w, float img_h, void* stream);
+/* logits [nsets, n_frames, m, c], boxes [nsets, n_frames, m, 4]; outputs [n_frames, nsets*m, ...] sorted by
+ * descending score, first counts[f] entries valid.  scratch: >= n_frames*nsets*m*24 bytes. */
+int dvid_postproc_topk_nms(const float* logits, const float* boxes, int nsets, int n_frames, int m, int c, float img_w,
+                           float img_h, float iou_threshold, int use_nms, float* out_boxes, float* out_scores,
+                           int* out_labels, int* out_counts, void* scratch, void* stream);
+int dvid_cdist(const float* x, int n, int d, float* dist, void* stream);
+/* bs_emul: block size of the reference CUDA launch to emulate for tie-breaking (0 = fps.cu's own rule) */
+int dvid_fps_greedy(const float* dist, int n, int m, int bs_emul, int* idx, void* stream);
+int dvid_gather_rows(const float* x, const int* idx, float* y, int m, int d, void* stream);
+/* NHWC fp16 conv / linear (implicit GEMM on MFMA): w is [cout][kpad] fp16 with k = (ky*kw+kx)*cin + c,
+ * kpad = round_up(kh*kw*cin, 64).  residual_mode: 0 none, 1 same shape, 2 nearest-x2 upsample. */
+int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const void* residual, void* out, int n, int h,
+                         int wd, int cin, int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int out_f32,
+                         int residual_mode, void* stream);
+int dvid_mha_core(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int head_dim,
+                  int q_ld, int kv_ld, int out_ld, int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream);
+int dvid_dynconv(const void* roi, const void* params, const float* g1, const float* b1, const float* g2, const float* b2,
+                 void* out, int rows, void* stream);
+int dvid_add_layernorm(const float* x, const float* r, const float* g, const float* b, float* y, int rows, int d, int relu,
+                       void* stream);
+int dvid_nhwc_from_nchw(const float* in, void* out_f16, int n, int h, int w, int c, void* stream);
+int dvid_nchw_from_nhwc(const void* in_f16, float* out, int n, int h, int w, int c, void* stream);
+int dvid_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* When enabled, every igemm launch is bracketed by HIP events on its stream; dvid_profile_read
+ * synchronises those events and returns totals since the last reset. */
+int dvid_profile_enable(int on);
+int dvid_profile_reset(void);
+int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

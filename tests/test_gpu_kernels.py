@@ -1,0 +1,336 @@
+"""Per-kernel parity: HIP kernels (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Tolerances.  Kernels compute fp16 x fp16 -> fp32 on MFMA and store fp16 or fp32.  The oracle is fed
+the SAME fp16-rounded operands in fp32, so what remains is accumulation order (fp32) and the final
+fp16 store (2^-11 relative): fp16 outputs rtol 2e-3 (+ atol 2e-3 of the output RMS), fp32 outputs
+rtol 1e-3/atol 1e-3 of RMS unless stated.  Index outputs (top-k / NMS keep sets / FPS picks) are
+compared exactly on inputs without near-ties.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import backbone_r101, head as ohead, memory as omem, postproc as opost, roi_align as oroi, schedule as osch  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dv():
+    from diffusionvid_amd import ops
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return ops
+
+
+REPORT = []
+
+
+def check(name, got, want, rtol, atol_rms):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float32)
+    want = want.detach().float().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want, dtype=np.float32)
+    assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
+    rms = float(np.sqrt(np.mean(want.astype(np.float64) ** 2))) + 1e-12
+    err = np.abs(got - want)
+    bound = atol_rms * rms + rtol * np.abs(want)
+    worst = float((err / bound).max()) if err.size else 0.0
+    line = f"{name}: max_abs={err.max():.3e} rms_ref={rms:.3e} worst/bound={worst:.3f} nan={int(np.isnan(got).sum())}"
+    REPORT.append(line)
+    print(line)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write(line + "\n")
+    assert not np.isnan(got).any(), f"{name}: NaN in output"
+    assert worst <= 1.0, line
+
+
+def h16(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(n=2, h=20, w=28, cin=64, cout=128, k=3, stride=1, pad=1, relu=True, res=1),
+    dict(n=2, h=21, w=27, cin=128, cout=64, k=3, stride=2, pad=1, relu=False, res=0),
+    dict(n=3, h=16, w=24, cin=256, cout=256, k=1, stride=1, pad=0, relu=True, res=1),
+    dict(n=1, h=16, w=24, cin=128, cout=512, k=1, stride=2, pad=0, relu=False, res=0),
+    dict(n=2, h=38, w=64, cin=256, cout=1024, k=1, stride=1, pad=0, relu=True, res=1),   # 128x128 tiles
+    dict(n=1, h=12, w=16, cin=512, cout=256, k=1, stride=1, pad=0, relu=False, res=2),   # FPN lateral + upsample add
+])
+def test_igemm_conv(dv, cfg):
+    g = torch.Generator().manual_seed(1)
+    n, h, w, cin, cout, k = cfg["n"], cfg["h"], cfg["w"], cfg["cin"], cfg["cout"], cfg["k"]
+    x = h16(torch.randn(n, cin, h, w, generator=g))
+    wt = h16(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k))
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, wt, bias, stride=cfg["stride"], padding=cfg["pad"])
+    res = None
+    if cfg["res"] == 1:
+        res = h16(torch.randn(ref.shape, generator=g))
+        ref = ref + res
+    elif cfg["res"] == 2:
+        res = h16(torch.randn(n, cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g))
+        ref = ref + F.interpolate(res, scale_factor=2.0, mode="nearest")
+    if cfg["relu"]:
+        ref = F.relu(ref)
+    wp, kpad = dv.pack_conv_weight(wt)
+    xd = dv.nhwc_from_nchw(x.cuda())
+    resd = dv.nhwc_from_nchw(res.cuda()) if res is not None else None
+    out = dv.conv2d_nhwc(xd, wp.cuda(), kpad, bias.cuda(), cout, k, k, cfg["stride"], cfg["pad"], relu=cfg["relu"],
+                         residual=resd, residual_mode=cfg["res"])
+    check(f"igemm_conv{cfg}", dv.nchw_from_nhwc(out), ref, 2e-3, 2e-3)
+
+
+def test_igemm_stem(dv):
+    g = torch.Generator().manual_seed(2)
+    x = h16(torch.randn(2, 3, 64, 96, generator=g))
+    wt = h16(torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147))
+    bias = torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, wt, bias, stride=2, padding=3))
+    wp, kpad = dv.pack_conv_weight(wt, cin_pad=8)
+    x8 = torch.zeros(2, 8, 64, 96)
+    x8[:, :3] = x
+    out = dv.conv2d_nhwc(dv.nhwc_from_nchw(x8.cuda()), wp.cuda(), kpad, bias.cuda(), 64, 7, 7, 2, 3, relu=True)
+    check("igemm_stem", dv.nchw_from_nhwc(out), ref, 2e-3, 2e-3)
+
+
+@pytest.mark.parametrize("rows,k,nout", [(600, 256, 768), (600, 256, 30), (300, 256, 4), (257, 12544, 256), (600, 2048, 256)])
+def test_igemm_linear_f32(dv, rows, k, nout):
+    g = torch.Generator().manual_seed(3)
+    x = h16(torch.randn(rows, k, generator=g))
+    wt = h16(torch.randn(nout, k, generator=g) / math.sqrt(k))
+    bias = torch.randn(nout, generator=g)
+    ref = F.linear(x, wt, bias)
+    wp, kpad = dv.pack_conv_weight(wt)
+    out = dv.linear(x.cuda().half(), wp.cuda(), kpad, bias.cuda())
+    check(f"igemm_linear[{rows}x{k}->{nout}]", out, ref, 1e-3, 1e-3)
+
+
+def _pyramid(g, n, H, W, c=256):
+    return [h16(torch.randn(n, c, H // s, W // s, generator=g)) for s in (8, 16, 32)]
+
+
+def _boxes(g, n, M, H, W):
+    cxcy = torch.rand(n, M, 2, generator=g) * torch.tensor([W, H]) * 1.2 - torch.tensor([W, H]) * 0.1
+    wh = torch.exp(torch.rand(n, M, 2, generator=g) * 5.5 + 0.3)
+    b = torch.cat([cxcy - wh / 2, cxcy + wh / 2], dim=-1)
+    b[0, 0] = torch.tensor([10.0, 10.0, 10.0, 10.0])          # zero area
+    b[0, 1] = torch.tensor([-50.0, -40.0, W + 80.0, H + 60.0])  # larger than the image
+    b[0, 2] = torch.tensor([W - 3.0, H - 3.0, W + 40.0, H + 40.0])
+    return b
+
+
+def test_roialign_multilevel(dv):
+    g = torch.Generator().manual_seed(4)
+    n, M, H, W = 2, 300, 160, 256
+    feats = _pyramid(g, n, H, W)
+    boxes = _boxes(g, n, M, H, W)
+    ref = oroi.roi_pooler(feats, boxes)                     # [n*M, C, 7, 7]
+    roi, mean = dv.roialign([dv.nhwc_from_nchw(f.cuda()) for f in feats], boxes.cuda(), H, W, want_mean=True)
+    check("roialign", roi.float().view(n * M, 7, 7, 256).permute(0, 3, 1, 2), ref, 2e-3, 2e-3)
+    check("roialign_mean", mean, ref.view(n * M, 256, -1).mean(-1), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("B,lq,lk", [(2, 300, 300), (1, 777, 900), (1, 64, 37)])
+def test_mha_core(dv, B, lq, lk):
+    g = torch.Generator().manual_seed(5)
+    d, nh = 256, 8
+    q, k, v = (torch.randn(B, l, d, generator=g) for l in (lq, lk, lk))
+    qh = q.view(B, lq, nh, 32).transpose(1, 2) / math.sqrt(32)
+    kh, vh = k.view(B, lk, nh, 32).transpose(1, 2), v.view(B, lk, nh, 32).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), dim=-1) @ vh).transpose(1, 2).reshape(B, lq, d)
+    out = dv.mha_core(q.cuda(), k.cuda(), v.cuda(), nh)
+    check(f"mha_core[{B},{lq},{lk}]", out, ref, 1e-3, 1e-3)
+
+
+def test_add_layernorm(dv):
+    g = torch.Generator().manual_seed(6)
+    x, r = torch.randn(601, 256, generator=g) * 3 + 1, torch.randn(601, 256, generator=g)
+    gm, bt = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.2
+    ref = F.relu(F.layer_norm(x + r, (256,), gm, bt))
+    out = dv.add_layernorm(x.cuda(), r.cuda(), gm.cuda(), bt.cuda(), relu=True)
+    check("add_layernorm", out, ref, 1e-4, 1e-4)
+
+
+def _head_setup(seed=0):
+    from diffusionvid_amd.utils import synthetic
+    sd = synthetic.make_head_state_dict(seed)
+    # the GPU path holds GEMM weights in fp16: give the oracle the same rounded matrices
+    sdo = {k: (h16(v) if v.dim() > 1 else v) for k, v in sd.items()}
+    return sd, sdo
+
+
+def test_dynconv(dv):
+    sd, sdo = _head_setup()
+    g = torch.Generator().manual_seed(7)
+    R, d, dd = 64, 256, 64
+    pfx = "head.head_series.0.inst_interact"
+    roi = h16(torch.randn(R, 49, d, generator=g))
+    pro = h16(torch.randn(1, R, d, generator=g))
+    params = h16(F.linear(pro, sdo[pfx + ".dynamic_layer.weight"], sdo[pfx + ".dynamic_layer.bias"]))[0]   # [R, 32768]
+    p1 = params[:, :d * dd].view(R, d, dd)
+    p2 = params[:, d * dd:].view(R, dd, d)
+    f = torch.bmm(roi, p1)
+    f = h16(F.relu(F.layer_norm(f, (dd,), sd[pfx + ".norm1.weight"], sd[pfx + ".norm1.bias"])))
+    f = torch.bmm(f, p2)
+    ref = F.relu(F.layer_norm(f, (d,), sd[pfx + ".norm2.weight"], sd[pfx + ".norm2.bias"]))
+    packed = torch.cat([p1.transpose(1, 2).reshape(R, -1), p2.transpose(1, 2).reshape(R, -1)], dim=1)   # P1T | P2T
+    out = dv.dynconv(roi.cuda().half(), packed.cuda().half(), sd[pfx + ".norm1.weight"].cuda(), sd[pfx + ".norm1.bias"].cuda(),
+                     sd[pfx + ".norm2.weight"].cuda(), sd[pfx + ".norm2.bias"].cuda())
+    check("dynconv", out, ref, 4e-3, 4e-3)
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_rcnn_head(dv, cond):
+    """Whole RCNNHead / RCNNHead_cond pass (box_head.py:495-548 / :605-664) at full dims."""
+    sd, sdo = _head_setup()
+    g = torch.Generator().manual_seed(8)
+    n, M, H, W = 2, 300, 160, 256
+    feats = _pyramid(g, n, H, W)
+    feats = [f * 0.5 for f in feats]
+    boxes = _boxes(g, n, M, H, W)
+    boxes[0, 0] = torch.tensor([10.0, 10.0, 14.0, 13.0])
+    cfg = ohead.HeadCfg()
+    t = torch.tensor([999, 499], dtype=torch.long)
+    time = osch.time_mlp(sd, "head.", t, 256)
+    pfx = "head.head_series_cond.0" if cond else "head.head_series.1"
+    pro = None if cond else torch.randn(1, n * M, 256, generator=g)
+    cnd = torch.randn(n * M, 256, generator=g) if cond else None
+    if cond:
+        pro = torch.randn(1, n * M, 256, generator=g)
+    taps = {}
+    cl, bx, of = ohead.rcnn_head(sdo, pfx, feats, boxes, pro, time, cfg, cond=cnd, taps=taps)
+    model = dv.Model(sd, res_blocks=(0, 0, 0, 0))
+    model.reserve(n, H, W, M)
+    fd = [dv.nhwc_from_nchw(f.cuda()) for f in feats]
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gl, gb, go = model.rcnn_head(0 if cond else 1, fd, H, W, boxes.cuda(), None if pro is None else pro[0].cuda(), t,
+                                 cond=None if cnd is None else cnd.cuda(), bad_flag=flag)
+    tag = "cond" if cond else "plain"
+    # fp16 GEMM operands through ~12 chained layers: activations are LayerNorm-ed O(1) values
+    check(f"rcnn_head[{tag}].obj_features", go, of[0], 2e-2, 2e-2)
+    check(f"rcnn_head[{tag}].logits", gl, cl, 2e-2, 2e-2)
+    bw = (boxes[..., 2:] - boxes[..., :2]).clamp(min=1.0).max(-1).values   # box size sets the pixel scale of the error
+    err = (gb.cpu() - bx).abs().max(-1).values / bw
+    print(f"rcnn_head[{tag}].boxes rel-to-size err max={err.max():.3e}")
+    assert err.max() < 3e-2
+    assert int(flag.item()) == 0
+    # first head: pro_features None -> mean of RoI features
+    cl0, bx0, of0 = ohead.rcnn_head(sdo, "head.head_series.0", feats, boxes, None, time, cfg)
+    gl0, gb0, go0 = model.rcnn_head(0, fd, H, W, boxes.cuda(), None, t)
+    check(f"rcnn_head[{tag}].first.obj_features", go0, of0[0], 2e-2, 2e-2)
+    model.close()
+
+
+def test_global_xattn(dv):
+    sd, sdo = _head_setup()
+    g = torch.Generator().manual_seed(9)
+    R, Lk = 600, 900
+    q = torch.randn(1, R, 256, generator=g)
+    mem = torch.randn(Lk, 256, generator=g)
+    ref = ohead.global_attention(sdo, "head.", h16(q), [h16(mem), None], ohead.HeadCfg())
+    model = dv.Model(sd, res_blocks=(0, 0, 0, 0))
+    model.reserve(2, 64, 64, 300)
+    out = model.global_xattn(q[0].cuda(), mem.cuda())
+    check("global_xattn", out, ref, 5e-3, 5e-3)
+    model.close()
+
+
+def test_noise_to_boxes_and_topk_select(dv):
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(3, 300, 4, generator=g) * 1.5
+    whwh = torch.tensor([[1000.0, 600.0, 1000.0, 600.0]]).repeat(3, 1)
+    ref = osch.noise_to_boxes(x, whwh, 2.0)
+    check("noise_to_boxes", dv.noise_to_boxes(x.cuda(), 2.0, 1000.0, 600.0), ref, 1e-6, 1e-6)
+    logits = torch.randn(3, 300, 30, generator=g)
+    feats = torch.randn(1, 900, 256, generator=g)
+    k1, k2 = ohead.select_topk_features(logits, feats, ohead.HeadCfg())
+    o1, o2 = dv.select_topk_features(logits.cuda(), feats[0].cuda(), 75, 25)
+    assert torch.equal(o1.cpu(), k1) and torch.equal(o2.cpu(), k2)      # pure selection: bit-exact
+
+
+def _separated_logits(g, n, M, C):
+    """Logits whose sigmoid values are pairwise distinct by a wide margin (no rounding-level ties)."""
+    vals = torch.linspace(-9.0, 3.0, n * M * C)
+    perm = torch.randperm(n * M * C, generator=g)
+    return vals[perm].view(n, M, C)
+
+
+def _cluster_boxes(g, n, M, W=1000.0, H=600.0):
+    ctr = torch.rand(n, 12, 2, generator=g) * torch.tensor([W, H])
+    which = torch.randint(0, 12, (n, M), generator=g)
+    c = torch.gather(ctr, 1, which[..., None].expand(-1, -1, 2)) + torch.randn(n, M, 2, generator=g) * 8
+    wh = torch.rand(n, M, 2, generator=g) * 120 + 30
+    return torch.cat([c - wh / 2, c + wh / 2], dim=-1)
+
+
+def test_postproc_x1_exact(dv):
+    g = torch.Generator().manual_seed(11)
+    n, M, C = 4, 300, 30
+    logits = _separated_logits(g, n, M, C)
+    boxes = _cluster_boxes(g, n, M)
+    ref = opost.inference_x1(logits, boxes, (1000, 600), C)
+    ob, osc, ol, oc = dv.postproc_topk_nms(logits.cuda(), boxes.cuda(), 1000.0, 600.0)
+    for b in range(n):
+        k = int(oc[b])
+        assert k == len(ref[b]["scores"]), f"frame {b}: kept {k} vs {len(ref[b]['scores'])}"
+        np.testing.assert_array_equal(ol[b, :k].cpu().numpy(), ref[b]["labels"])
+        np.testing.assert_array_equal(ob[b, :k].cpu().numpy(), ref[b]["boxes"])          # selection + clip: exact
+        np.testing.assert_allclose(osc[b, :k].cpu().numpy(), ref[b]["scores"], rtol=0, atol=2e-7)
+    assert 5 < int(oc.min()) and int(oc.max()) < M      # NMS really suppressed something
+
+
+def test_postproc_ensemble_exact(dv):
+    g = torch.Generator().manual_seed(12)
+    S, n, M, C = 3, 2, 300, 30
+    logits = _separated_logits(g, S * n, M, C).view(S, n, M, C)
+    boxes = _cluster_boxes(g, S * n, M).view(S, n, M, 4)
+    cands = [[opost.topk_candidates(logits[s, b], boxes[s, b], C)[:3] for b in range(n)] for s in range(S)]
+    ref = opost.inference_ensemble(cands, (1000, 600))
+    ob, osc, ol, oc = dv.postproc_topk_nms(logits.cuda(), boxes.cuda(), 1000.0, 600.0)
+    for b in range(n):
+        k = int(oc[b])
+        assert k == len(ref[b]["scores"])
+        np.testing.assert_array_equal(ol[b, :k].cpu().numpy(), ref[b]["labels"])
+        np.testing.assert_array_equal(ob[b, :k].cpu().numpy(), ref[b]["boxes"])
+
+
+def test_cdist_fps_gather(dv):
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(1800, 256, generator=g)
+    D = torch.cdist(x, x, p=2.0)
+    Dg = dv.cdist(x.cuda())
+    off = ~torch.eye(1800, dtype=torch.bool)
+    check("cdist(offdiag)", Dg.cpu()[off], D[off], 1e-5, 1e-5)
+    assert Dg.cpu().diagonal().abs().max() < 0.05       # sqrt of an fp32 cancellation residue, as in torch
+    # FPS on the SAME matrix: integer picks are exact
+    ref = omem.fps_kernel_order(D.numpy(), 900)
+    idx = dv.fps_greedy(D.cuda(), 900)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    got = dv.gather_rows(x.cuda(), idx)
+    assert torch.equal(got.cpu(), x[torch.from_numpy(ref.astype(np.int64))])
+    # tie-heavy matrix: exercises fps.cu's thread-mapping tie rule
+    rng = np.random.RandomState(0)
+    Dt = torch.from_numpy(rng.randint(0, 4, size=(600, 600)).astype(np.float32))
+    np.testing.assert_array_equal(dv.fps_greedy(Dt.cuda(), 150).cpu().numpy(), omem.fps_kernel_order(Dt.numpy(), 150))
+
+
+def test_backbone_small(dv):
+    """Reduced-depth ResNet-FPN (same kernels, same graph) on 2 frames of 128x192 vs the CPU oracle."""
+    from diffusionvid_amd.utils import synthetic
+    blocks = (1, 2, 2, 1)
+    sd = synthetic.make_state_dict(0, blocks=blocks)
+    g = torch.Generator().manual_seed(14)
+    imgs = torch.rand(2, 3, 128, 192, generator=g)
+    cfg_mean, cfg_std = (123.675, 116.280, 103.530), (58.395, 57.120, 57.375)
+    ref = backbone_r101.backbone_r101_fpn(backbone_r101.normalizer(imgs, cfg_mean, cfg_std), sd, "backbone.", blocks)
+    model = dv.Model(sd, res_blocks=blocks)
+    model.reserve(2, 128, 192, 300)
+    p3, p4, p5 = model.backbone(imgs.cuda())
+    for name, got in (("p3", p3), ("p4", p4), ("p5", p5)):
+        # fp16 activations + fp16 folded-BN weights through ~20 conv layers
+        check(f"backbone_small.{name}", dv.nchw_from_nhwc(got), ref[name], 3e-2, 3e-2)
+    model.close()
