@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""DiffusionVID-R101 x1 inference throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path over one synthetic video: L = 304 frames of 1000x600
+(padded to 608x1024), i.e. 24 global + 8 local frames through backbone + 3 heads and the
+farthest-point memory pruning once, then 38 batches of 8 frames through backbone -> 3x RCNNHead ->
+global cross-attention -> RCNNHead_cond -> top-k/NMS, with the reference's per-item call protocol
+(304 model() calls, 38 of which do work).  Frames are resident in HBM before the timed region.
+value = frames emitted by all ranks / max-over-ranks wall time (barrier + device sync on both sides).
+N > 1: one process per GPU, each rank owns whole videos (weak scaling, no data-path collective); the
+single RCCL gather of the predictions to rank 0 is inside the timed region.
+
+Extra objects on the JSON line:
+  roofline     the dominant kernel is the implicit-GEMM MFMA conv/linear kernel (igemm_kernel<...>);
+               achieved = algorithmic FLOP of all its launches / summed launch durations, measured with
+               HIP events on the launch stream in an instrumented repeat of one step right after the
+               timed region; peak = 2500 TFLOP/s dense fp16 MFMA (MI355X_MICROARCH.md).
+  cpu_baseline the CPU oracle (oracle/, PyTorch CPU fp32, a port of the reference path) timed on the host
+               cores of this box on ONE steady-state batch of 8 frames at the same size.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from diffusionvid_amd import _lib  # noqa: E402
+from diffusionvid_amd.config import get_cfg  # noqa: E402
+from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset  # noqa: E402
+from diffusionvid_amd.engine import inference as engine  # noqa: E402
+from diffusionvid_amd.modeling.detector import build_detection_model  # noqa: E402
+from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
+
+PEAK_FP16_TFLOPS = 2500.0
+
+
+def run_video(model, ds, device):
+    results = {}
+    for idx in range(len(ds)):
+        images, _, ids = ds[idx]
+        out = model(images)
+        if out:
+            results.update({i: o for i, o in zip(ids, out)})
+    return results
+
+
+def cpu_baseline(cfg, sd, frames, height, width):
+    """Oracle (CPU port) on one steady-state 8-frame batch; returns dict for the JSON line."""
+    from oracle import backbone_r101, detector as odet
+    # pick the thread count that is actually fastest on this host (256 OpenMP threads on small ops can
+    # be an order of magnitude slower than 32): one-frame backbone probe per candidate
+    best_t, best_dt = None, None
+    with torch.no_grad():
+        for nt in sorted({min(c, os.cpu_count()) for c in (16, 32, 64, 128, os.cpu_count())}):
+            torch.set_num_threads(nt)
+            t0 = time.perf_counter()
+            backbone_r101.resnet_bottom_up(backbone_r101.normalizer(frames[0], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD), sd,
+                                           "backbone.bottom_up.", (3, 4, 6, 3))
+            d = time.perf_counter() - t0
+            if best_dt is None or d < best_dt:
+                best_t, best_dt = nt, d
+    torch.set_num_threads(best_t)
+    ocfg = odet.DetCfg()
+    oracle = odet.OracleDiffusionDet(sd, ocfg, synthetic.noise_fn)
+    from collections import deque
+    g = torch.Generator().manual_seed(7)
+    oracle.local_img_queue = []
+    oracle.mem = [torch.randn(900, 256, generator=g), torch.randn(150, 256, generator=g)]
+    oracle.feats = deque(maxlen=8)
+    oracle.classes_300, oracle.proposals_300, oracle.proposals_feat_300 = deque(maxlen=8), deque(maxlen=8), deque(maxlen=8)
+    nb = len(frames)
+    item = {"cur": frames[0], "image_size": (height, width), "ref_l": frames, "ref_g": [], "frame_category": 1,
+            "frame_id": 8, "start_id": 0, "end_id": 8 + nb - 1, "seg_len": 8 + nb, "last_queue_id": 15}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = oracle.forward(item)
+    dt = time.perf_counter() - t0
+    assert len(out) == nb
+    return {"value": round(nb / dt, 4), "unit": "frames/sec", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(),
+            "kind": "port",
+            "sample": "1 steady-state call on %d frames 1000x600 (R101-FPN + 3 RCNNHead + global attention + RCNNHead_cond "
+                      "+ top-k/NMS; per-video init excluded), CPU oracle fp32, %.1f s wall, %d threads (fastest of a "
+                      "16..%d probe)" % (nb, dt, torch.get_num_threads(), os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=304, help="frames per synthetic video")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the DiffusionVID hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        comm.init_dist("nccl")
+
+    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16"],
+                  os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+    cfg.freeze()
+    model = build_detection_model(cfg).to(device).eval()
+    model.noise_fn = synthetic.noise_fn
+    H, W, L = 600, 1000, args.frames
+    ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank)
+    ds.preload()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            run_video(model, ds, device)
+        barrier()
+        t0 = time.perf_counter()
+        frames = 0
+        results = {}
+        for s in range(args.steps):
+            r = run_video(model, ds, device)
+            frames += len(r)
+            results.update({k + s * L + rank * args.steps * L: v.to("cpu") for k, v in r.items()})
+        merged = engine.gather_predictions(results, max_det=300, device=device) if world > 1 else results
+        barrier()
+        dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    ff = torch.tensor([frames], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+    dt, total_frames = float(tt.item()), float(ff.item())
+
+    # ---- roofline of the dominant kernel: instrumented repeat of one step -------------------------
+    roofline = None
+    lib = _lib.load()
+    lib.dvid_profile_reset()
+    lib.dvid_profile_enable(1)
+    with torch.no_grad():
+        run_video(model, ds, device)
+    torch.cuda.synchronize()
+    ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    _lib.check(lib.dvid_profile_read(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), "dvid_profile_read")
+    lib.dvid_profile_enable(0)
+    if os.environ.get("DVID_PROFILE_DUMP") and rank == 0:
+        lib.dvid_profile_dump(os.environ["DVID_PROFILE_DUMP"].encode())
+    lib.dvid_profile_reset()
+    if ms.value > 0:
+        achieved = fl.value / (ms.value * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, fp16 MFMA)",
+                    "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": int(nl.value), "avg_launch_us": round(ms.value * 1e3 / max(1, nl.value), 2),
+                    "kernel_ms_per_step": round(ms.value, 2), "alg_gflop_per_launch": round(fl.value / max(1, nl.value) / 1e9, 3)}
+
+    if rank == 0:
+        line = {
+            "metric": "frames/sec (1000x600) DiffusionVID-R101 x1",
+            "value": round(total_frames / dt, 2), "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "ResNet-101 DiffusionVID x1 fp16, 300 boxes, 1 DDIM step; one step = one synthetic "
+                                   "%d-frame 1000x600 video per GPU (24 global + %d local frames, %d batches of 8)"
+                                   % (L, L, (L + 7) // 8),
+                       "frames_per_step_per_gpu": L, "infer_batch": 8, "parallelism": "videos sharded across ranks"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            frames8 = [ds.frame(0, i).tensors.cpu() for i in range(8, 12)]
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, frames8, H, W)
+            line["gpu_over_cpu"] = round(line["value"] / max(line["cpu_baseline"]["value"], 1e-9), 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

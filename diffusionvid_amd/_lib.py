@@ -41,6 +41,7 @@ SIGNATURES = {
     "dvid_select_topk_features": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                           c_void_p]),
     "dvid_noise_to_boxes": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p]),
+    "dvid_ddim_renew_step": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_float] * 9 + [c_void_p]),
     "dvid_postproc_topk_nms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvid_cdist": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "dvid_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "dvid_profile_enable": (c_int, [c_int]),
     "dvid_profile_reset": (c_int, []),
+    "dvid_profile_dump": (c_int, [C.c_char_p]),
     "dvid_profile_read": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int64)]),
 }
 

@@ -95,6 +95,61 @@ __global__ __launch_bounds__(256) void topk_mask_kernel(const float* __restrict_
     }
 }
 
+
+// One workgroup per frame.  diffusion_det.py:559-596 (box renewal + DDIM step, eta = 1) with
+// :666-672 (x_start from the predicted boxes; NB divided by the frame size for every frame) and
+// :649-653 (predict_noise_from_start).  Kept boxes are compacted in index order; the j-th kept box
+// consumes noise row j; the tail is replenished with fresh N(0,1) rows.
+__global__ __launch_bounds__(256) void ddim_renew_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                          const float* __restrict__ xt, const float* __restrict__ noise,
+                                                          const float* __restrict__ fresh, float* __restrict__ out, int m, int c,
+                                                          float w, float h, float scale, float sra, float srm1, float sqrt_an,
+                                                          float cc, float sigma, float thr) {
+    extern __shared__ int pos[];   // [m] compacted slot or -1
+    __shared__ int s_remain;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < m; i += blockDim.x) {
+        const float* lp = logits + ((long)f * m + i) * c;
+        float mx = -INFINITY;
+        for (int j = 0; j < c; ++j) mx = fmaxf(mx, 1.f / (1.f + expf(-lp[j])));
+        pos[i] = mx > thr ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int p = 0;
+        for (int i = 0; i < m; ++i) {
+            const int k = pos[i];
+            pos[i] = k ? p : -1;
+            p += k;
+        }
+        s_remain = p;
+    }
+    __syncthreads();
+    const int remain = s_remain;
+    const float whwh[4] = {w, h, w, h};
+    for (int i = tid; i < m; i += blockDim.x) {
+        const int slot = pos[i];
+        if (slot >= 0) {
+            const float4v b = *reinterpret_cast<const float4v*>(boxes + ((long)f * m + i) * 4);
+            const float4v x = *reinterpret_cast<const float4v*>(xt + ((long)f * m + i) * 4);
+            const float4v nz = *reinterpret_cast<const float4v*>(noise + ((long)f * m + slot) * 4);
+            const float n0 = b[0] / whwh[0], n1 = b[1] / whwh[1], n2 = b[2] / whwh[2], n3 = b[3] / whwh[3];
+            float xs[4] = {(n0 + n2) / 2.f, (n1 + n3) / 2.f, n2 - n0, n3 - n1};
+            float4v o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = fminf(fmaxf((xs[e] * 2.f - 1.f) * scale, -scale), scale);
+                const float pn = (sra * x[e] - v) / srm1;
+                o[e] = v * sqrt_an + cc * pn + sigma * nz[e];
+            }
+            *reinterpret_cast<float4v*>(out + ((long)f * m + slot) * 4) = o;
+        }
+        if (i >= remain)
+            *reinterpret_cast<float4v*>(out + ((long)f * m + i) * 4) =
+                *reinterpret_cast<const float4v*>(fresh + ((long)f * m + (i - remain)) * 4);
+    }
+}
+
 }  // namespace
 
 int dvid_noise_to_boxes_launch(const float* x, float* boxes, int n, float scale, float w, float h, hipStream_t s) {
@@ -119,6 +174,16 @@ int dvid_topk_mask_launch(const float* logits, int n_img, int m, int c, int k1, 
     if (d % 4 || k2 > k1 || k1 > m) return DVID_ERR_ARG;
     const size_t smem = (size_t)m * 12;
     hipLaunchKernelGGL(topk_mask_kernel, dim3(n_img), dim3(256), smem, s, logits, m, c, k1, k2, feats, d, out1, out2);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_ddim_renew_launch(const float* logits, const float* boxes, const float* xt, const float* noise, const float* fresh,
+                           float* out, int n_img, int m, int c, float w, float h, float scale, float sra, float srm1, float sqrt_an,
+                           float cc, float sigma, float thr, hipStream_t s) {
+    if (n_img == 0) return DVID_OK;
+    hipLaunchKernelGGL(ddim_renew_kernel, dim3(n_img), dim3(256), (size_t)m * 4, s, logits, boxes, xt, noise, fresh, out, m, c, w, h,
+                       scale, sra, srm1, sqrt_an, cc, sigma, thr);
     LAUNCH_CHECK();
     return DVID_OK;
 }

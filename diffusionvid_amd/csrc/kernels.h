@@ -56,6 +56,10 @@ int dvid_noise_to_boxes_launch(const float* x, float* boxes, int n, float scale,
 int dvid_topk_mask_launch(const float* logits, int n_img, int m, int c, int k1, int k2, const float* feats, int d, float* out1,
                           float* out2, hipStream_t s);
 
+int dvid_ddim_renew_launch(const float* logits, const float* boxes, const float* xt, const float* noise, const float* fresh,
+                           float* out, int n_img, int m, int c, float w, float h, float scale, float sra, float srm1, float sqrt_an,
+                           float cc, float sigma, float thr, hipStream_t s);
+
 // postproc.hip
 int dvid_topk_candidates_launch(const float* logits, const float* boxes, int n_img, int nsets, int m, int c, float* cand_boxes,
                                 float* cand_scores, int* cand_labels, hipStream_t s);

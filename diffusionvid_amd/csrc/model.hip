@@ -41,6 +41,7 @@ void set_err(const char* fmt, ...) {
 struct ProfRec {
     hipEvent_t a, b;
     double flop;
+    int M, N, K, taps, stride, res_mode;
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -57,6 +58,12 @@ int igemm(const IgemmParams& p, hipStream_t s) {
         HIP_TRY(hipEventCreate(&r.b));
     }
     r.flop = 2.0 * p.M * (double)p.Cout * (double)p.alg_k;
+    r.M = p.M;
+    r.N = p.Cout;
+    r.K = p.Kpad;
+    r.taps = p.ntaps;
+    r.stride = p.stride;
+    r.res_mode = p.res_mode;
     HIP_TRY(hipEventRecord(r.a, s));
     const int rc = dvid_igemm_launch(p, s);
     HIP_TRY(hipEventRecord(r.b, s));
@@ -734,6 +741,16 @@ int dvid_noise_to_boxes(const float* x, float* boxes, int n, float snr_scale, fl
     return DVID_OK;
 }
 
+int dvid_ddim_renew_step(const float* logits, const float* boxes, const float* x_t, const float* noise, const float* fresh,
+                         float* x_next, int n_frames, int mm, int c, float img_w, float img_h, float snr_scale,
+                         float sqrt_recip_ac, float sqrt_recipm1_ac, float sqrt_ac_next, float coef_c, float sigma, float keep_thr,
+                         void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_ddim_renew_launch(logits, boxes, x_t, noise, fresh, x_next, n_frames, mm, c, img_w, img_h, snr_scale, sqrt_recip_ac,
+                               sqrt_recipm1_ac, sqrt_ac_next, coef_c, sigma, keep_thr, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
 int dvid_postproc_topk_nms(const float* logits, const float* boxes, int nsets, int n_frames, int mm, int c, float img_w, float img_h,
                            float iou_threshold, int use_nms, float* out_boxes, float* out_scores, int* out_labels, int* out_counts,
                            void* scratch, void* stream) {
@@ -847,6 +864,22 @@ int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launc
     if (igemm_ms) *igemm_ms = ms;
     if (igemm_flop) *igemm_flop = fl;
     if (igemm_launches) *igemm_launches = (int64_t)g_prof.size();
+    return DVID_OK;
+}
+
+// one CSV line per recorded igemm launch: M,N,K,taps,stride,res_mode,ms,tflops
+int dvid_profile_dump(const char* path) {
+    g_err[0] = 0;
+    FILE* f = fopen(path, "w");
+    if (!f) FAIL(DVID_ERR_ARG, "cannot open %s", path);
+    fprintf(f, "M,N,K,taps,stride,res_mode,ms,tflops\n");
+    for (auto& r : g_prof) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%.5f,%.2f\n", r.M, r.N, r.K, r.taps, r.stride, r.res_mode, t, r.flop / (t * 1e-3) / 1e12);
+    }
+    fclose(f);
     return DVID_OK;
 }
 

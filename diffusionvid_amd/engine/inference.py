@@ -1,0 +1,106 @@
+"""Inference loop and result gathering (mirror of mega_core/engine/inference.py:22-181).
+
+`compute_on_dataset` keeps the reference's conventions: one dataset item per call, wall time
+around `model(images)` with a device sync (inference.py:30, :70-73), outputs moved to the CPU and
+zipped with the item's image ids (:75, :91-93).  Multi-GPU: ranks own disjoint video ranges and
+never talk during inference; at the end ONE collective gathers fixed-layout tensors
+[frames, max_det, 6] (+ per-frame counts and ids) to rank 0 -- over RCCL/xGMI each non-root rank
+has its own link to root -- replacing the reference's pickled byte all_gather to every rank
+(mega_core/utils/comm.py:54-94).
+"""
+import time
+
+import torch
+import torch.distributed as dist
+
+from ..structures.bounding_box import BoxList
+from ..utils import comm
+
+
+def compute_on_dataset(model, dataset, indices, device, timer=None):
+    model.eval()
+    results = {}
+    cpu = torch.device("cpu")
+    for idx in indices:
+        images, _, image_ids = dataset[idx]
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            output = model(images)
+            if device.type != "cpu":
+                torch.cuda.synchronize()
+            if timer is not None:
+                timer.append(time.perf_counter() - t0)
+            output = [o.to(cpu) for o in output]
+        results.update({img_id: r for img_id, r in zip(image_ids, output)})
+    return results
+
+
+def pack_predictions(results, max_det):
+    """dict{id: BoxList} -> (ids [n] int64, counts [n] int32, dets [n, max_det, 6] fp32 = box4, score, label,
+    sizes [n,2] int32)."""
+    ids = sorted(results.keys())
+    n = len(ids)
+    dets = torch.zeros((n, max_det, 6), dtype=torch.float32)
+    counts = torch.zeros((n,), dtype=torch.int32)
+    sizes = torch.zeros((n, 2), dtype=torch.int32)
+    for j, i in enumerate(ids):
+        bl = results[i]
+        k = len(bl)
+        counts[j] = k
+        sizes[j, 0], sizes[j, 1] = bl.size
+        if k:
+            dets[j, :k, :4] = bl.bbox
+            dets[j, :k, 4] = bl.get_field("scores")
+            dets[j, :k, 5] = bl.get_field("labels").to(torch.float32)
+    return torch.tensor(ids, dtype=torch.int64), counts, dets, sizes
+
+
+def unpack_predictions(ids, counts, dets, sizes):
+    out = {}
+    for j, i in enumerate(ids.tolist()):
+        k = int(counts[j])
+        bl = BoxList(dets[j, :k, :4].clone(), (int(sizes[j, 0]), int(sizes[j, 1])), mode="xyxy")
+        bl.add_field("scores", dets[j, :k, 4].clone())
+        bl.add_field("labels", dets[j, :k, 5].to(torch.int64))
+        out[i] = bl
+    return out
+
+
+def gather_predictions(results, max_det, device=None):
+    """Gather every rank's {image_id: BoxList} on rank 0 (returns None elsewhere)."""
+    world = comm.get_world_size()
+    if world == 1:
+        return results
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    ids, counts, dets, sizes = pack_predictions(results, max_det)
+    n_local = torch.tensor([ids.numel()], dtype=torch.int64, device=dev)
+    all_n = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(all_n, n_local)                       # 8 bytes per rank: shard sizes
+    n_max = int(max(int(x.item()) for x in all_n))
+
+    def pad(t):
+        p = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype)
+        p[: t.shape[0]] = t
+        return p.to(dev)
+
+    payload = [pad(ids), pad(counts), pad(dets), pad(sizes)]
+    rank = comm.get_rank()
+    gathered = []
+    for t in payload:                                     # the data collective: gather to rank 0
+        bufs = [torch.zeros_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, gather_list=bufs, dst=0)
+        gathered.append(bufs)
+    if rank != 0:
+        return None
+    merged = {}
+    for r in range(world):
+        n = int(all_n[r].item())
+        merged.update(unpack_predictions(gathered[0][r][:n].cpu(), gathered[1][r][:n].cpu(), gathered[2][r][:n].cpu(),
+                                         gathered[3][r][:n].cpu()))
+    return merged
+
+
+def predictions_list(merged):
+    """dict -> list indexed by dataset image id, as torch.save'd to predictions.pth (inference.py:101-115)."""
+    ids = sorted(merged.keys())
+    return [merged[i] for i in ids]

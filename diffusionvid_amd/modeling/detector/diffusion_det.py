@@ -1,0 +1,317 @@
+"""DiffusionDet meta-architecture -- host-side mirror of
+mega_core/modeling/detector/diffusion_det.py:188-896 (inference only) driving libdvid_hip.
+
+Surface kept for `tools/test_net.py`-style callers: `DiffusionDet(cfg)`, `nn.Module` with the
+reference's state_dict names (backbone.bottom_up.*, backbone.fpn_*, head.*, diffusion buffers),
+`.to(device)`, `.eval()`, `forward(images: dict, targets=None) -> list[BoxList]` with the input
+keys of vid_mega.py:236-248, `[]` on calls whose frame_id is not a multiple of INPUT.INFER_BATCH,
+ValueError for targets at test time, AssertionError for degenerate predicted boxes.
+
+The video state machine (per-video reset, local frame queue, once-per-video global memory,
+DDIM loop, ensemble) is sequenced here; every numerical step is a HIP kernel launched through
+`ops` on the current stream.  Random draws go through `self.noise_fn(kind, frame_id, step, image,
+shape)` when set (parity/bench), else torch.randn on the device like the reference.
+"""
+import math
+from collections import deque
+
+import torch
+from torch import nn
+
+from ... import ops
+from ...structures.bounding_box import BoxList
+from ...structures.image_list import to_image_list
+from ...utils import synthetic
+from ..roi_heads.box_head.box_head import DynamicHead
+
+_DEPTH_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    """cosine schedule, fp64 (diffusion_det.py:50-61)."""
+    x = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64)
+    ac = torch.cos(((x / timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    return torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
+
+
+def _register_nested(root, name, tensor, buffer=False):
+    """Registers `tensor` under the dotted `name` so state_dict keys match the reference's."""
+    parts = name.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, nn.Module())
+        mod = getattr(mod, p)
+    if buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class DiffusionDet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        d = cfg.MODEL.DiffusionDet
+        mega = cfg.MODEL.VID.MEGA
+        self.global_enable = mega.GLOBAL.ENABLE
+        self.all_frame_interval = mega.ALL_FRAME_INTERVAL
+        self.key_frame_location = mega.KEY_FRAME_LOCATION
+        self.local_box_enable = cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.ENABLE
+        self.mem_management_size_test = mega.MEMORY_MANAGEMENT_SIZE_TEST
+        self.in_features = cfg.MODEL.ROI_HEADS.IN_FEATURES
+        self.num_classes = d.NUM_CLASSES
+        self.num_proposals = d.NUM_PROPOSALS
+        self.hidden_dim = d.HIDDEN_DIM
+        self.num_heads = d.NUM_HEADS
+        self.infer_batch = cfg.INPUT.INFER_BATCH
+        self.size_divisibility = 32
+        if list(self.in_features) != ["p3", "p4", "p5"]:
+            raise NotImplementedError("ROI_HEADS.IN_FEATURES must be [p3, p4, p5] (configs/vid_*_DiffusionVID.yaml)")
+        if cfg.MODEL.BACKBONE.NAME != "build_resnet_fpn_backbone":
+            raise NotImplementedError("backbone '%s' is not built yet (ResNet-FPN only this round)" % cfg.MODEL.BACKBONE.NAME)
+        if cfg.MODEL.RESNETS.DEPTH not in _DEPTH_BLOCKS or cfg.MODEL.RESNETS.STRIDE_IN_1X1:
+            raise NotImplementedError("ResNet depth %s / STRIDE_IN_1X1 unsupported" % cfg.MODEL.RESNETS.DEPTH)
+        self.res_blocks = getattr(cfg.MODEL.RESNETS, "BLOCKS_OVERRIDE", None) or _DEPTH_BLOCKS[cfg.MODEL.RESNETS.DEPTH]
+
+        # diffusion constants (diffusion_det.py:222-267); registered so checkpoints load unchanged
+        timesteps = 1000
+        betas = cosine_beta_schedule(timesteps)
+        alphas = 1.0 - betas
+        alphas_cumprod = torch.cumprod(alphas, dim=0).to(torch.float32)
+        alphas_cumprod_prev = torch.nn.functional.pad(alphas_cumprod[:-1], (1, 0), value=1.0)
+        self.num_timesteps = timesteps
+        self.sampling_timesteps = d.SAMPLE_STEP
+        assert self.sampling_timesteps <= timesteps
+        self.ddim_sampling_eta = 1.0
+        self.scale = d.SNR_SCALE
+        self.box_renewal = True
+        self.use_ensemble = True
+        self.use_nms = d.USE_NMS
+        self.use_focal = d.USE_FOCAL
+        if not self.use_focal:
+            raise NotImplementedError("only the focal-loss (sigmoid) inference branch is built (USE_FOCAL: True)")
+        posterior_variance = betas * (1.0 - alphas_cumprod_prev) / (1.0 - alphas_cumprod)
+        for name, val in (
+                ("betas", betas), ("alphas_cumprod", alphas_cumprod), ("alphas_cumprod_prev", alphas_cumprod_prev),
+                ("sqrt_alphas_cumprod", torch.sqrt(alphas_cumprod)),
+                ("sqrt_one_minus_alphas_cumprod", torch.sqrt(1.0 - alphas_cumprod)),
+                ("log_one_minus_alphas_cumprod", torch.log(1.0 - alphas_cumprod)),
+                ("sqrt_recip_alphas_cumprod", torch.sqrt(1.0 / alphas_cumprod)),
+                ("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / alphas_cumprod - 1)),
+                ("posterior_variance", posterior_variance),
+                ("posterior_log_variance_clipped", torch.log(posterior_variance.clamp(min=1e-20))),
+                ("posterior_mean_coef1", betas * torch.sqrt(alphas_cumprod_prev) / (1.0 - alphas_cumprod)),
+                ("posterior_mean_coef2", (1.0 - alphas_cumprod_prev) * torch.sqrt(alphas) / (1.0 - alphas_cumprod))):
+            self.register_buffer(name, val)
+
+        # parameters under the reference's names; seeded random init (the reference also starts from
+        # random init before DetectronCheckpointer.load)
+        sd = synthetic.make_state_dict(0, blocks=self.res_blocks, hidden=d.HIDDEN_DIM, nheads=d.NHEADS,
+                                       dim_ff=d.DIM_FEEDFORWARD, dim_dynamic=d.DIM_DYNAMIC, num_classes=d.NUM_CLASSES,
+                                       num_cls=d.NUM_CLS, num_reg=d.NUM_REG, num_heads=d.NUM_HEADS,
+                                       num_heads_cond=d.NUM_HEADS_LOCAL, pooler=cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION,
+                                       prior_prob=d.PRIOR_PROB)
+        self.head = DynamicHead(cfg, None, engine_provider=self._get_engine)
+        self.num_heads_local = self.head.num_heads_local
+        self.top_k = self.head.top_k
+        for name, t in sd.items():
+            _register_nested(self, name, t, buffer=name.endswith(("running_mean", "running_var")))
+        self._engine = None
+        self.noise_fn = None
+        self.debug_taps = None      # dict -> receives intermediates (parity tests)
+        self.video_index = 0
+        self.demo = False
+
+    # ---- engine (repacked weights on the GPU) -------------------------------------------------
+    def _get_engine(self):
+        if self._engine is None:
+            d = self.cfg.MODEL.DiffusionDet
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._engine = ops.Model(
+                sd, hidden_dim=d.HIDDEN_DIM, nheads=d.NHEADS, dim_feedforward=d.DIM_FEEDFORWARD, dim_dynamic=d.DIM_DYNAMIC,
+                num_classes=d.NUM_CLASSES, num_cls=d.NUM_CLS, num_reg=d.NUM_REG, num_heads=d.NUM_HEADS,
+                num_heads_cond=d.NUM_HEADS_LOCAL, pooler_resolution=self.cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION,
+                sampling_ratio=self.cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO, res_blocks=tuple(self.res_blocks),
+                pixel_mean=tuple(self.cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(self.cfg.MODEL.PIXEL_STD))
+        return self._engine
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        if self._engine is not None:           # weights changed: repack on next use
+            self._engine.close()
+            self._engine = None
+        return out
+
+    def _noise(self, kind, frame_id, step, image, shape):
+        if self.noise_fn is not None:
+            return self.noise_fn(kind, frame_id, step, image, shape).to(self.device, torch.float32)
+        return torch.randn(shape, device=self.device)
+
+    # ---- forward (diffusion_det.py:306-336) ---------------------------------------------------
+    def forward(self, images, targets=None):
+        if self.training:
+            raise NotImplementedError("training is out of scope of the MI355X inference path")
+        images = dict(images)
+        images["cur"] = to_image_list(images["cur"])
+        images["ref_l"] = [to_image_list(image) for image in images["ref_l"]]
+        images["ref_g"] = [to_image_list(image) for image in images["ref_g"]]
+        infos = dict(images)
+        infos.pop("cur")
+        return self._forward_test(images["cur"], infos, targets)
+
+    def _reset_video(self):
+        n = self.all_frame_interval
+        self.local_img_queue = []
+        self.head.proposal_feats_global = [None, None]
+        self.head.proposal_feats_local = [None, None]
+        self.queue = deque(maxlen=n)      # entries: (split_outputs, frame index inside the split)
+        self.video_index += 1
+
+    def model_predictions(self, backbone_feats, images_whwh, x, t, box_extract=0):
+        """diffusion_det.py:655-677.  images_whwh: (w, h) of the un-padded frame (same for all frames)."""
+        w, h = images_whwh
+        x_boxes = ops.noise_to_boxes(x, self.scale, w, h)
+        if box_extract:
+            return self.head(backbone_feats, x_boxes, t, None, box_extract)
+        outputs_class, outputs_coord = self.head(backbone_feats, x_boxes, t, None)
+        return outputs_class, outputs_coord
+
+    def _forward_test(self, imgs, infos, targets=None):
+        if targets is not None and not self.demo:
+            raise ValueError("In testing mode, targets should be None")
+        if infos["frame_category"] == 0:
+            self._reset_video()
+        frame_id, start_id, end_id = infos["frame_id"], infos["start_id"], infos["end_id"]
+        if frame_id % self.infer_batch != 0:
+            self.local_img_queue += infos["ref_l"]
+            return []
+        ref_l = self.local_img_queue + infos["ref_l"]
+        self.local_img_queue = []
+        ref_g = infos["ref_g"]
+        h, w = imgs.image_sizes[0]
+        whwh = (float(w), float(h))
+        eng = self._get_engine()
+        M = self.num_proposals
+
+        # 1. features + extraction pass over [local frames | global frames] in splits of INFER_BATCH
+        if ref_l or ref_g:
+            total = torch.cat([im.tensors for im in ref_l] + [im.tensors for im in ref_g]).to(self.device, torch.float32)
+            eng.reserve(self.infer_batch, total.shape[-2], total.shape[-1], M)
+            len_l = len(ref_l)
+            splits, k1_all, k2_all = [], [], []
+            for bi, chunk in enumerate(total.split(self.infer_batch)):
+                feats = eng.backbone(chunk.contiguous())
+                B = chunk.shape[0]
+                box_init = self._noise("box_init", frame_id, bi, 0, (B, M, 4))
+                t = torch.full((B,), 999, dtype=torch.long)
+                (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init, t, box_extract=bi + 1)
+                splits.append({"feats": feats, "logits": cl, "boxes": bx, "obj": pf[0].view(B, M, self.hidden_dim)})
+                k1_all.append(k1)
+                k2_all.append(k2)
+                if self.debug_taps is not None:
+                    self.debug_taps.setdefault("extract", []).append((cl, bx, pf[0], feats))
+            if len_l > self.infer_batch:
+                raise NotImplementedError("more local frames than INFER_BATCH in one call")
+
+        # 2. global memory, once per video with the shipped config (diffusion_det.py:479-488)
+        if ref_g:
+            g1 = torch.cat(k1_all, dim=0).view(-1, self.top_k[0], self.hidden_dim)[len_l:].reshape(-1, self.hidden_dim)
+            g2 = torch.cat(k2_all, dim=0).view(-1, self.top_k[1], self.hidden_dim)[len_l:].reshape(-1, self.hidden_dim)
+            m0, _ = ops.update_erase_memory(g1, self.head.proposal_feats_global[0], self.mem_management_size_test)
+            m1, _ = ops.update_erase_memory(g2, self.head.proposal_feats_global[1], 150)
+            self.head.proposal_feats_global = [m0, m1]
+            if self.debug_taps is not None:
+                self.debug_taps["memory"] = [m0, m1]
+
+        # 3. local queue (diffusion_det.py:491-506)
+        n_local = len(ref_l)
+        if infos["frame_category"] == 0:
+            lead = self.key_frame_location - (frame_id - start_id)
+            fill_idx = [0] * lead + list(range(n_local)) + [n_local - 1] * (self.all_frame_interval - (lead + n_local))
+        else:
+            fill_idx = list(range(n_local))
+        for i in fill_idx:
+            self.queue.append((splits[0], i))
+
+        # current batch (diffusion_det.py:515-523)
+        batch = min(self.infer_batch, end_id - frame_id + 1)
+        entries = [self.queue[i] for i in range(self.key_frame_location, self.key_frame_location + batch)]
+        feats_cur, cached = self._gather_entries(entries)
+
+        pairs = self._time_pairs()
+        if self.sampling_timesteps == 1:
+            # x1: the randn `img` of diffusion_det.py:542 never reaches the output (the head pops the cached
+            # stages, box_head.py:300-302) and the DDIM update after the single step is dead code (:573-575)
+            self.head.proposals_feat_cur = [[cached[0], cached[1], cached[2].reshape(1, batch * M, self.hidden_dim)]]
+            t = torch.full((batch,), pairs[0][0], dtype=torch.long)
+            img = torch.zeros((batch, M, 4), device=self.device)
+            outputs_class, outputs_coord = self.model_predictions(feats_cur, whwh, img, t)
+            ob, osc, ol, oc = ops.postproc_topk_nms(outputs_class[-1], outputs_coord[-1], w, h, 0.5, self.use_nms)
+            if self.debug_taps is not None:
+                self.debug_taps["final_0"] = (outputs_class[-1], outputs_coord[-1])
+        else:
+            ob, osc, ol, oc = self._ddim_ensemble(feats_cur, whwh, batch, frame_id, pairs, w, h)
+        return self._to_boxlists(ob, osc, ol, oc, (int(w), int(h)))
+
+    # ---- helpers --------------------------------------------------------------------------------
+    def _time_pairs(self):
+        times = torch.linspace(-1, self.num_timesteps - 1, steps=self.sampling_timesteps + 1)
+        times = list(reversed(times.int().tolist()))
+        return list(zip(times[:-1], times[1:]))
+
+    def _gather_entries(self, entries):
+        """Frames of the current batch: contiguous views when they are consecutive frames of one split
+        (the steady state), otherwise an index_select copy (video head/tail duplicates)."""
+        src = entries[0][0]
+        idx = [e[1] for e in entries]
+        same = all(e[0] is src for e in entries)
+        if same and idx == list(range(idx[0], idx[0] + len(idx))):
+            a, b = idx[0], idx[0] + len(idx)
+            return [f[a:b] for f in src["feats"]], (src["logits"][a:b], src["boxes"][a:b], src["obj"][a:b])
+        if not same:
+            raise NotImplementedError("current batch spans several backbone splits (INFER_BATCH != ALL_FRAME_INTERVAL)")
+        sel = torch.tensor(idx, device=self.device)
+        return ([f.index_select(0, sel) for f in src["feats"]],
+                tuple(src[k].index_select(0, sel) for k in ("logits", "boxes", "obj")))
+
+    def _ddim_ensemble(self, feats_cur, whwh, batch, frame_id, pairs, w, h):
+        """SAMPLE_STEP > 1 (diffusion_det.py:551-627): every step re-runs the 3 heads + global attention +
+        cond head on the current noisy boxes, renews low-score boxes, and all but the last step feed the
+        NMS ensemble."""
+        M = self.num_proposals
+        img = self._noise("img", frame_id, 0, 0, (batch, M, 4))
+        ens_logits, ens_boxes = [], []
+        for step, (time, time_next) in enumerate(pairs):
+            t = torch.full((batch,), time, dtype=torch.long)
+            outputs_class, outputs_coord = self.model_predictions(feats_cur, whwh, img, t)
+            if self.debug_taps is not None:
+                self.debug_taps[f"final_{step}"] = (outputs_class[-1], outputs_coord[-1])
+            if time_next < 0:
+                continue            # the last step never reaches the ensemble (diffusion_det.py:573-575)
+            a = self.alphas_cumprod[time].double().cpu()
+            an = self.alphas_cumprod[time_next].double().cpu()
+            sigma = self.ddim_sampling_eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+            c = (1 - an - sigma ** 2).sqrt()
+            noise = torch.stack([self._noise("ddim", frame_id, step, i, (M, 4)) for i in range(batch)])
+            fresh = torch.stack([self._noise("renew", frame_id, step, i, (M, 4)) for i in range(batch)])
+            img = ops.ddim_renew_step(outputs_class[-1], outputs_coord[-1], img, noise, fresh, whwh, self.scale,
+                                      float(self.sqrt_recip_alphas_cumprod[time]), float(self.sqrt_recipm1_alphas_cumprod[time]),
+                                      float(self.alphas_cumprod[time_next].sqrt()), float(c), float(sigma), 0.5)
+            ens_logits.append(outputs_class[-1])
+            ens_boxes.append(outputs_coord[-1])
+        return ops.postproc_topk_nms(torch.stack(ens_logits), torch.stack(ens_boxes), w, h, 0.5, self.use_nms)
+
+    def _to_boxlists(self, ob, osc, ol, oc, size_wh):
+        counts = oc.tolist()                 # the one host sync of a batch (the caller moves results to CPU anyway)
+        self.head.check_boxes_valid()
+        results = []
+        for b, k in enumerate(counts):
+            bl = BoxList(ob[b, :k], size_wh, mode="xyxy")
+            bl.add_field("scores", osc[b, :k])
+            labels = ol[b, :k].to(torch.int64)
+            bl.add_field("labels", labels)
+            results.append(bl)
+        return results

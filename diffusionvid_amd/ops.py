@@ -116,6 +116,19 @@ def noise_to_boxes(x, snr_scale, img_w, img_h):
     return out
 
 
+def ddim_renew_step(logits, boxes, x_t, noise, fresh, whwh, snr_scale, sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_next, coef_c,
+                    sigma, keep_thr=0.5):
+    """Box renewal + DDIM update (diffusion_det.py:559-596); all [n, M, 4] fp32, logits [n, M, C]."""
+    logits, boxes, x_t = _cuda(logits, torch.float32), _cuda(boxes, torch.float32), _cuda(x_t, torch.float32)
+    noise, fresh = _cuda(noise, torch.float32), _cuda(fresh, torch.float32)
+    n, M, c = logits.shape
+    out = torch.empty_like(x_t)
+    call("dvid_ddim_renew_step", ptr(logits), ptr(boxes), ptr(x_t), ptr(noise), ptr(fresh), ptr(out), n, M, c, float(whwh[0]),
+         float(whwh[1]), float(snr_scale), float(sqrt_recip_ac), float(sqrt_recipm1_ac), float(sqrt_ac_next), float(coef_c),
+         float(sigma), float(keep_thr), stream_ptr())
+    return out
+
+
 def select_topk_features(logits, feats, k1, k2):
     """logits [n, M, C], feats [n*M, d] -> ([n*k1, d], [n*k2, d]) in box-index (mask) order."""
     logits, feats = _cuda(logits, torch.float32), _cuda(feats, torch.float32)

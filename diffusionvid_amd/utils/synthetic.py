@@ -119,10 +119,29 @@ def make_state_dict(seed=0, blocks=(3, 4, 23, 3), **head_kw):
     return sd
 
 
-def synthetic_frame(index, height=600, width=1000, video=0):
-    """torch.rand(3,600,1000) fp32 in [0,1), seed 1000+i (post-ToTensor domain)."""
+def synthetic_frame(index, height=600, width=1000, video=0, smooth=False):
+    """torch.rand(3,600,1000) fp32 in [0,1), seed 1000+i (post-ToTensor domain).
+
+    smooth=True gives a low-frequency image instead (bicubic upsampling of a coarse random grid):
+    with white-noise frames and random weights the 3-stage box refinement is chaotic (an fp16 rounding
+    of the feature maps alone moves stage-3 outputs by O(1), measured on the CPU oracle), which makes
+    end-to-end parity meaningless; the end-to-end parity tests therefore use smooth frames."""
     g = torch.Generator().manual_seed(1000 + index + 100003 * video)
-    return torch.rand(3, height, width, generator=g)
+    if not smooth:
+        return torch.rand(3, height, width, generator=g)
+    coarse = torch.rand(1, 3, max(2, height // 32), max(2, width // 32), generator=g)
+    img = torch.nn.functional.interpolate(coarse, size=(height, width), mode="bicubic", align_corners=False)
+    return img[0].clamp_(0, 1)
+
+
+def tame_box_deltas(state_dict, gain=0.1):
+    """Scale every `bboxes_delta` layer (weight and bias) by `gain` -- random-init heads otherwise
+    multiply box sizes by e^(+-2) per stage, unlike a trained model whose refinements shrink."""
+    out = dict(state_dict)
+    for k, v in state_dict.items():
+        if ".bboxes_delta." in k:
+            out[k] = v * gain
+    return out
 
 
 _KINDS = {"box_init": 0, "img": 1, "ddim": 2, "renew": 3}

@@ -16,6 +16,7 @@
  *   dvid_global_xattn          nn.MultiheadAttention global stage, box_head.py:366-380
  *   dvid_select_topk_features  box_head.py:304-317
  *   dvid_noise_to_boxes        diffusion_det.py:657-660
+ *   dvid_ddim_renew_step       box renewal + DDIM update, diffusion_det.py:559-596
  *   dvid_postproc_topk_nms     DiffusionDet.inference + detectron2 batched_nms + BoxList.clip_to_image
  *                              diffusion_det.py:754-839, :607-627; structures/bounding_box.py:214-224
  *   dvid_cdist / dvid_fps_greedy / dvid_gather_rows
@@ -103,6 +104,13 @@ int dvid_roialign_v2_multilevel(const void* p3, const void* p4, const void* p5, 
 int dvid_select_topk_features(const float* logits, int n_frames, int m, int num_classes, int k1, int k2, const float* feats,
                               int hidden, float* out_k1, float* out_k2, void* stream);
 int dvid_noise_to_boxes(const float* x, float* boxes, int n, float snr_scale, float img_w, float img_h, void* stream);
+/* Box renewal + DDIM update (eta = 1) of diffusion_det.py:559-596 (+ :649-653, :666-672): per frame, boxes whose
+ * sigmoid(max logit) > keep_thr are kept (index order), updated as x0*sqrt_ac_next + coef_c*eps + sigma*noise[j],
+ * and the tail is refilled from `fresh`.  All tensors [n_frames, m, 4] (logits [n_frames, m, c]). */
+int dvid_ddim_renew_step(const float* logits, const float* boxes, const float* x_t, const float* noise, const float* fresh,
+                         float* x_next, int n_frames, int m, int c, float img_w, float img_h, float snr_scale,
+                         float sqrt_recip_ac, float sqrt_recipm1_ac, float sqrt_ac_next, float coef_c, float sigma, float keep_thr,
+                         void* stream);
 /* logits [nsets, n_frames, m, c], boxes [nsets, n_frames, m, 4]; outputs [n_frames, nsets*m, ...] sorted by
  * descending score, first counts[f] entries valid.  scratch: >= n_frames*nsets*m*24 bytes. */
 int dvid_postproc_topk_nms(const float* logits, const float* boxes, int nsets, int n_frames, int m, int c, float img_w,
@@ -133,6 +141,8 @@ int dvid_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
 int dvid_profile_enable(int on);
 int dvid_profile_reset(void);
 int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches);
+/* CSV (M,N,K,taps,stride,res_mode,ms,tflops), one line per recorded igemm launch */
+int dvid_profile_dump(const char* path);
 
 #ifdef __cplusplus
 }

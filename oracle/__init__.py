@@ -19,8 +19,7 @@ Pinning status (see tests/golden/README.md):
     (tests/golden/make_golden.py).
   * ROIAlignV2 / level assignment, R101+FPN, batched_nms: third-party code that is not
     under /root/reference and is un-pinned by the reference (INSTALL.md:68-69 clones
-    detectron2 HEAD).  Restated from the published upstream algorithm; cross-checked
-    here against torch's own conv2d/max_pool2d operators and an independent scalar C
-    restatement (oracle/c/roi_align_ref.c, oracle/c/nms_ref.c).  "parity unpinned" for
-    those three pieces in the strict sense of the task statement.
+    detectron2 HEAD).  Restated from the published upstream algorithm (SURVEY.md
+    Appendix A); "parity unpinned" for those three pieces in the strict sense of the
+    task statement.
 """

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import backbone_r101, head, memory, postproc, schedule
+from .head import HeadCfg
 
 
 @dataclass
@@ -36,7 +37,7 @@ class DetCfg:
     pixel_std: tuple = (58.395, 57.120, 57.375)
     in_features: tuple = ("p3", "p4", "p5")
     blocks: tuple = backbone_r101.R101_BLOCKS
-    head: head.HeadCfg = field(default_factory=head.HeadCfg)
+    head: HeadCfg = field(default_factory=HeadCfg)
 
 
 class OracleDiffusionDet:

@@ -1,0 +1,190 @@
+"""End-to-end parity: GPU DiffusionDet (libdvid_hip) vs the CPU oracle state machine on the same
+synthetic video, same weights, same injected noise.
+
+The pipeline is discontinuous (top-k, score>0.5 renewal, NMS, FPS arg-max) and the GPU path holds
+weights/activations in fp16, so the comparison is staged:
+  1. extraction pass (backbone + 3 heads on every local/global frame): logits / boxes / object features
+     within fp16-pipeline tolerance;
+  2. global memory: FPS run by the GPU kernel on the ORACLE's features must return the oracle's rows
+     exactly (integer work), and the GPU's own memory must be the same point set up to near-ties;
+  3. final stage with the oracle's memory injected: logits / boxes within tolerance, detections matched
+     one-to-one by (label, IoU, score).
+Stated tolerances: object features |err| <= 0.08 (LayerNorm-ed, O(1)); logits |err| <= 0.08; boxes
+<= max(0.75 px, 2% of box size); scores |err| <= 5e-3 -- for at least 99% of the boxes (a box that sits
+on a pyramid-level or sample-validity threshold may flip discretely between fp16 and fp32 features).
+
+Conditioning.  With white-noise frames and raw random-init heads the 3-stage refinement is chaotic:
+rounding the CPU oracle's OWN feature maps to fp16 moves its stage-3 features by O(1) (measured,
+see diffusionvid_amd/utils/synthetic.py).  The end-to-end test therefore uses low-frequency frames
+and box-delta layers scaled by 0.1, for which the same experiment stays at ~3e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detector as odet  # noqa: E402
+from oracle import memory as omem  # noqa: E402
+
+
+def _build(sample_step, blocks):
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.DiffusionDet.SAMPLE_STEP", sample_step],
+                  "configs/BASE_RCNN_1gpu.yaml")
+    cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = blocks
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    from diffusionvid_amd.utils import synthetic
+    model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+    return cfg, model.to("cuda").eval()
+
+
+def _oracle_items(ds, idx):
+    images, _, ids = ds[idx]
+    o = {k: v for k, v in images.items() if k not in ("cur", "ref_l", "ref_g")}
+    o["cur"] = images["cur"].tensors.cpu()
+    o["image_size"] = tuple(images["cur"].image_sizes[0])
+    o["ref_l"] = [im.tensors.cpu() for im in images["ref_l"]]
+    o["ref_g"] = [im.tensors.cpu() for im in images["ref_g"]]
+    return images, o, ids
+
+
+def _iou(a, b):
+    x1, y1 = np.maximum(a[0], b[0]), np.maximum(a[1], b[1])
+    x2, y2 = np.minimum(a[2], b[2]), np.minimum(a[3], b[3])
+    inter = max(0.0, x2 - x1) * max(0.0, y2 - y1)
+    ua = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter
+    return inter / ua if ua > 0 else 1.0
+
+
+def _stage_check(tag, gpf, opf, gcl, ocl, gbx, obx, frac_ok=0.99):
+    """per-box errors against the stated bounds; >= frac_ok of the boxes must be inside all of them"""
+    e_cl = (gcl - ocl).abs().amax(-1).reshape(-1)
+    size = (obx[..., 2:] - obx[..., :2]).clamp(min=1).max(-1).values
+    e_bx = ((gbx - obx).abs().max(-1).values / torch.maximum(size * 0.02, torch.tensor(0.75))).reshape(-1)
+    ok = (e_cl <= 0.08) & (e_bx <= 1.0)
+    msg = f"{tag}: |dlogit| median={e_cl.median():.2e} p99={e_cl.quantile(0.99):.2e} max={e_cl.max():.2e}; "
+    msg += f"box err/bound median={e_bx.median():.2e} p99={e_bx.quantile(0.99):.2e} max={e_bx.max():.2e}"
+    if gpf is not None:
+        e_pf = (gpf - opf).abs().amax(-1).reshape(-1)
+        ok &= e_pf <= 0.08
+        msg += f"; |dfeat| median={e_pf.median():.2e} p99={e_pf.quantile(0.99):.2e} max={e_pf.max():.2e}"
+    frac = ok.float().mean().item()
+    print(msg + f"; boxes within bounds {frac:.4f}")
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write(msg + f"; boxes within bounds {frac:.4f}\n")
+    assert frac >= frac_ok, msg
+
+
+def _match_rate(ref, got):
+    """fraction of oracle detections with a GPU detection of the same label, IoU >= 0.9, |dscore| <= 5e-3"""
+    hit = 0
+    gb, gs, gl = got.bbox.cpu().numpy(), got.get_field("scores").cpu().numpy(), got.get_field("labels").cpu().numpy()
+    used = np.zeros(len(gs), bool)
+    for b, s, l in zip(ref["boxes"], ref["scores"], ref["labels"]):
+        cand = np.nonzero((gl == l) & ~used & (np.abs(gs - s) <= 5e-3))[0]
+        best = max(cand, key=lambda j: _iou(b, gb[j]), default=None)
+        if best is not None and _iou(b, gb[best]) >= 0.9:
+            used[best] = True
+            hit += 1
+    return hit / max(1, len(ref["scores"]))
+
+
+@pytest.mark.parametrize("sample_step", [1, 4])
+def test_video_e2e(sample_step):
+    from diffusionvid_amd import ops
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.utils import synthetic
+    blocks = (1, 1, 2, 1)
+    cfg, model = _build(sample_step, blocks)
+    L, H0, W0 = 8, 250, 380                    # padded to 256 x 384 by the size-divisibility rule
+    ds = SyntheticVIDDataset([L], cfg, height=H0, width=W0, device="cuda", smooth=True)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ocfg = odet.DetCfg(sample_step=sample_step, blocks=blocks)
+    ocfg.head.sampling_timesteps = sample_step
+    oracle = odet.OracleDiffusionDet(sd, ocfg, synthetic.noise_fn)
+    model.noise_fn = synthetic.noise_fn
+    model.debug_taps = {}
+
+    # ---- call 0 on both (frame 0: 8 local + 24 global frames) -----------------------------------------
+    images, oitem, ids = _oracle_items(ds, 0)
+    with torch.no_grad():
+        ref_out = oracle.forward(oitem)
+        got_out = model(images)
+    assert len(got_out) == len(ref_out) == L
+
+    # 1. extraction pass
+    ocl, obx, opf = oracle.taps["extract"]
+    gcl = torch.cat([e[0] for e in model.debug_taps["extract"]]).cpu()
+    gbx = torch.cat([e[1] for e in model.debug_taps["extract"]]).cpu()
+    gpf = torch.cat([e[2] for e in model.debug_taps["extract"]]).cpu().view(-1, 300, 256)
+    _stage_check(f"[x{sample_step}] extraction", gpf, opf, gcl, ocl, gbx, obx)
+
+    # 2. memory: GPU FPS on the oracle's candidate features -> identical rows (integer work)
+    for lvl, (k, target) in enumerate(((75, 900), (25, 150))):
+        feats = oracle.taps["extract"][2][L:]        # global frames
+        cls = oracle.taps["extract"][0][L:]
+        from oracle import head as ohead
+        k1, k2 = ohead.select_topk_features(cls, feats.reshape(1, -1, 256), ocfg.head)
+        cand = (k1, k2)[lvl]
+        D = torch.cdist(cand, cand, p=2.0)
+        ref_idx = omem.fps_kernel_order(D.numpy(), target)
+        got_idx = ops.fps_greedy(D.cuda(), target).cpu().numpy()
+        np.testing.assert_array_equal(got_idx, ref_idx)
+    # the GPU's own memory (its own fp16-path features, its own cdist): same size, and close as a point set
+    gm = model.debug_taps["memory"][0].cpu()
+    om = oracle.mem[0]
+    assert gm.shape == om.shape
+    dmin = torch.cdist(om, gm).min(dim=1).values
+    print(f"[x{sample_step}] memory: oracle rows with a GPU row within 0.5: {(dmin < 0.5).float().mean():.3f}")
+    assert (dmin < 0.5).float().mean() > 0.8
+
+    # 3. final stage with the oracle's memory injected
+    model.head.proposal_feats_global = [oracle.mem[0].cuda(), oracle.mem[1].cuda()]
+    model.debug_taps = {}
+    # re-run the final stage only: rebuild the batch from the queue exactly as _forward_test does
+    entries = [model.queue[i] for i in range(L)]
+    feats_cur, cached = model._gather_entries(entries)
+    with torch.no_grad():
+        if sample_step == 1:
+            model.head.proposals_feat_cur = [[cached[0], cached[1], cached[2].reshape(1, L * 300, 256)]]
+            t = torch.full((L,), 999, dtype=torch.long)
+            oc_, ob_ = model.model_predictions(feats_cur, (float(W0), float(H0)), torch.zeros(L, 300, 4, device="cuda"), t)
+            fin_cl, fin_bx = oc_[-1].cpu(), ob_[-1].cpu()
+            ref_cl, ref_bx = oracle.taps["final_0"]
+        else:
+            img = synthetic.noise_fn("img", 0, 0, 0, (L, 300, 4)).cuda()
+            t = torch.full((L,), 999, dtype=torch.long)
+            oc_, ob_ = model.model_predictions(feats_cur, (float(W0), float(H0)), img, t)
+            fin_cl, fin_bx = oc_[-1].cpu(), ob_[-1].cpu()
+            ref_cl, ref_bx = oracle.taps["final_0"]
+    _stage_check(f"[x{sample_step}] final stage (oracle memory)", None, None, fin_cl, ref_cl, fin_bx, ref_bx)
+
+    # detections of the un-modified end-to-end run
+    rates = [_match_rate(r, g) for r, g in zip(ref_out, got_out)]
+    print(f"[x{sample_step}] detections: kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]}; "
+          f"match rates {['%.2f' % r for r in rates]}")
+    assert min(rates) >= 0.9
+    for g in got_out:
+        assert g.mode == "xyxy" and g.size == (W0, H0)
+        assert g.get_field("labels").dtype == torch.int64 and g.get_field("labels").min() >= 1
+        s = g.get_field("scores")
+        assert torch.all(s[:-1] >= s[1:])                       # NMS order: descending score
+        assert g.bbox[:, 0::2].max() <= W0 - 1 and g.bbox[:, 1::2].max() <= H0 - 1 and g.bbox.min() >= 0
+
+
+def test_non_batch_calls_return_empty_and_errors():
+    cfg, model = _build(1, (1, 1, 1, 1))
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    ds = SyntheticVIDDataset([12], cfg, height=120, width=200, device="cuda", smooth=True)
+    outs = []
+    with torch.no_grad():
+        for idx in range(12):
+            outs.append(model(ds[idx][0]))
+    assert [len(o) for o in outs] == [8, 0, 0, 0, 0, 0, 0, 0, 4, 0, 0, 0]     # tail batch: end_id - frame_id + 1 = 4
+    with pytest.raises(ValueError):
+        model(ds[0][0], targets=[None])
