@@ -12,6 +12,8 @@
 // (conflict-free for ds_read_b128 of 16 consecutive rows); epilogue goes through an fp32 LDS
 // tile so bias/residual/ReLU are applied in fp32 and stores are 16 bytes per lane.
 // Blocks are remapped so that each XCD (private L2) owns a contiguous range of tiles.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -275,6 +277,10 @@ int launch(const IgemmParams& p0, hipStream_t s) {
 }  // namespace
 
 int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
+    // v2 (direct-to-LDS staging, igemm2.hip) is the product kernel; DVID_IGEMM_V1=1 selects the
+    // register-staged round-1 kernel below for A/B measurements.
+    static const bool use_v1 = getenv("DVID_IGEMM_V1") != nullptr;
+    if (!use_v1) return dvid_igemm2_launch(p, s);
     if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
     if (p.Kpad % BK != 0 || p.Kpad < BK) return DVID_ERR_ARG;
     const bool smallc = (p.Cin == 8 && p.KH * p.KW > 1);

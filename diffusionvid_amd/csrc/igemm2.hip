@@ -1,0 +1,253 @@
+// Implicit-GEMM convolution / linear layer, version 2: direct-to-LDS staging.
+//
+// Same contract as igemm.hip (out = act(A_im2col . Wt^T + bias + residual), fp16 in, fp32
+// accumulate on v_mfma_f32_32x32x16_f16) with the staging rebuilt around
+// `global_load_lds_dwordx4`: every lane hands the DMA its own 16-byte source address -- the im2col
+// gather, filter-tap bounds and the M/N tails are all resolved in that address (out-of-range lanes
+// point at a 16-byte zero page) -- and the data lands in LDS without touching VGPRs.  The LDS image
+// of a tile is lane-linear (64-byte rows for BK = 32), so bank conflicts are removed by an XOR
+// swizzle applied to the SOURCE chunk index and again on the fragment read:
+// physical 16-byte chunk = logical chunk ^ ((row >> 2) & 3), conflict-free for ds_read_b128.
+// Two LDS stages of (BM+BN)*64 B and a half-tile fp32 epilogue buffer keep a workgroup at <= 33 KB,
+// so 4 workgroups (16 waves) share a CU and hide the DMA latency of each other's K steps.
+#include <stdlib.h>
+
+#include "common.h"
+#include "igemm_epilogue.h"
+#include "kernels.h"
+
+namespace {
+
+// K tile = BKT halves.  BKT = 64 stages full 128-byte lines per row (8 rows per 1-KiB DMA piece, swizzle
+// key (row >> 1) & 7); BKT = 32 stages 64-byte half lines (16 rows per piece, key (row >> 2) & 3) at half the
+// LDS footprint.  Both keys make the four 16-lane groups of ds_read_b128 conflict-free.
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <int BM, int BN, int BKT>
+struct Smem2 {
+    static constexpr int kStage = (BM + BN) * BKT * 2;
+    static constexpr int kCPitch = BN + 4;
+    static constexpr int kCHalf = (BM / 2) * kCPitch * 4;
+    static constexpr int kBytes = (2 * kStage > kCHalf) ? 2 * kStage : kCHalf;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int BKT, bool SMALLC>
+__global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
+    constexpr int ROW_BYTES = BKT * 2;
+    constexpr int CHUNKS = BKT / 8;                 // 16-byte chunks per row
+    constexpr int RPP = 1024 / ROW_BYTES;           // tile rows per 1-KiB DMA piece
+    constexpr int KEY_SHIFT = (BKT == 64) ? 1 : 2;  // swizzle key = (row >> KEY_SHIFT) & (CHUNKS - 1)
+    constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves 2x2)
+    constexpr int A_IT = BM / RPP / 4, B_IT = BN / RPP / 4;   // DMA pieces per wave per K tile
+    constexpr int A_BYTES = BM * ROW_BYTES;
+    constexpr int STAGE = Smem2<BM, BN, BKT>::kStage;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lid = igemm_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_n = lid % p.tiles_n, tile_m = lid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- DMA descriptors: piece j = wave + 4*i covers tile rows [16j, 16j+16), lane -> (row, chunk)
+    const int lrow = lane / CHUNKS;
+    const int pch = lane % CHUNKS;                              // physical chunk this lane fills
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    int a_base[A_IT], a_iy[A_IT], a_ix[A_IT], a_lch[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int row = RPP * (wave + 4 * i) + lrow;
+        a_lch[i] = pch ^ ((row >> KEY_SHIFT) & (CHUNKS - 1));   // logical chunk stored at this position
+        const int m = m0 + row;
+        if (m < p.M) {
+            const int ox = m % p.Wo;
+            const int t = m / p.Wo;
+            const int oy = t % p.Ho;
+            const int img = t / p.Ho;
+            a_iy[i] = oy * p.stride - p.pad;
+            a_ix[i] = ox * p.stride - p.pad;
+            a_base[i] = ((img * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin;
+        } else {
+            a_iy[i] = -(1 << 28);
+            a_ix[i] = 0;
+            a_base[i] = 0;
+        }
+    }
+    int b_off[B_IT];
+    bool b_ok[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = RPP * (wave + 4 * i) + lrow;
+        const int n = n0 + row;
+        b_ok[i] = n < p.Cout;
+        b_off[i] = (b_ok[i] ? n : 0) * p.Kpad + (pch ^ ((row >> KEY_SHIFT) & (CHUNKS - 1))) * 8;
+    }
+
+    // filter-tap walk of the K loop (wave-uniform): k0 = tap * Cin + c0
+    int ky = 0, kx = 0, c0 = 0;
+
+    auto issue = [&](int kt, int stage) {
+        char* sa = smem + stage * STAGE;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int tky = ky, tkx = kx, coff = c0 + a_lch[i] * 8;
+            bool ok = true;
+            if (SMALLC) {                                        // Cin == 8: one tap per 16-byte chunk
+                const int tap = kt * CHUNKS + a_lch[i];
+                ok = tap < p.ntaps;
+                tky = tap / p.KW;
+                tkx = tap - tky * p.KW;
+                coff = 0;
+            }
+            const int iy = a_iy[i] + tky, ix = a_ix[i] + tkx;
+            ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const char* src = ok ? reinterpret_cast<const char*>(p.in + a_base[i] + (tky * p.W + tkx) * p.Cin + coff) : zero;
+            glds16(src, sa + (wave + 4 * i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const char* src = b_ok[i] ? reinterpret_cast<const char*>(p.w + b_off[i] + kt * BKT) : zero;
+            glds16(src, sb + (wave + 4 * i) * 1024);
+        }
+        if (!SMALLC) {
+            c0 += BKT;
+            if (c0 >= p.Cin) {
+                c0 = 0;
+                if (++kx == p.KW) {
+                    kx = 0;
+                    ++ky;
+                }
+            }
+        }
+    };
+
+    float16v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.Kpad / BKT;
+    issue(0, 0);
+    __syncthreads();
+
+    // fragment addressing: row = base32 + (lane & 31); logical chunk = 2*ks + (lane >> 5)
+    constexpr int KS = BKT / 16;
+    const int frow = lane & 31;
+    const int sw = (frow >> KEY_SHIFT) & (CHUNKS - 1);
+    const int fa_off = (wm * (BM / 2) + frow) * ROW_BYTES;
+    const int fb_off = A_BYTES + (wn * (BN / 2) + frow) * ROW_BYTES;
+    int choff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) choff[ks] = ((2 * ks + (lane >> 5)) ^ sw) * 16;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        const char* st = smem + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * ROW_BYTES + choff[ks]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * ROW_BYTES + choff[ks]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();   // drains this wave's DMA (vmcnt) and publishes the next stage
+    }
+
+    // ---- epilogue: two half tiles (rows of wm = 0, then wm = 1) through an fp32 LDS buffer ---------
+    constexpr int CP = Smem2<BM, BN, BKT>::kCPitch;
+    constexpr int VPR = BN / 8;
+    constexpr int ERPP = 256 / VPR;
+    float* Cs = reinterpret_cast<float*>(smem);
+    const int c8 = (tid % VPR) * 8;
+    const int n = n0 + c8;
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = (p.bias && n + e < p.Cout) ? p.bias[n + e] : 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int col = wn * (BN / 2) + j * 32 + (lane & 31);
+                        Cs[row * CP + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        for (int r = tid / VPR; r < BM / 2; r += ERPP) {
+            const int m = m0 + half * (BM / 2) + r;
+            if (m < p.M && n < p.Cout) igemm_store_row8(p, Cs + r * CP + c8, m, n, bias8);
+        }
+    }
+}
+
+template <int BM, int BN, int BKT, bool SMALLC>
+int launch2(const IgemmParams& p0, hipStream_t s) {
+    IgemmParams p = p0;
+    p.tiles_m = ceil_div(p.M, BM);
+    p.tiles_n = ceil_div(p.Cout, BN);
+    constexpr int smem = Smem2<BM, BN, BKT>::kBytes;
+    if (smem > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, SMALLC>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, SMALLC>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+template <int BKT>
+int dispatch2(const IgemmParams& p, hipStream_t s, bool smallc) {
+    if (smallc) return launch2<128, 64, BKT, true>(p, s);
+    // resident workgroups per CU: 4 (BKT 32) / 2 (BKT 64) for the 128x128 tile; prefer the big tile while it
+    // still gives every CU at least ~2 workgroups
+    const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.Cout, 128);
+    if (t128 >= 512 && p.Cout >= 128) return launch2<128, 128, BKT, false>(p, s);
+    const long t12864 = (long)ceil_div(p.M, 128) * ceil_div(p.Cout, 64);
+    if (t12864 >= 512) return launch2<128, 64, BKT, false>(p, s);
+    return launch2<64, 64, BKT, false>(p, s);
+}
+
+}  // namespace
+
+int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
+    static const int bkt_env = getenv("DVID_IGEMM_BK") ? atoi(getenv("DVID_IGEMM_BK")) : 0;
+    if (p.Kpad % 64 != 0 || p.Kpad < 64) return DVID_ERR_ARG;
+    const bool smallc = (p.Cin == 8 && p.KH * p.KW > 1);
+    if (!smallc && (p.Cin % 64 != 0)) return DVID_ERR_UNSUPPORTED;
+    if (p.res_mode == 2 && ((p.Ho | p.Wo) & 1)) return DVID_ERR_ARG;
+    // Long-K layers are bound by the global->LDS staging rate: full 128-byte lines (BKT 64) win.  Short-K
+    // layers (<= 4 K steps) are bound by HBM traffic and the epilogue: the smaller LDS footprint of BKT 32
+    // (4 resident workgroups per CU instead of 2) wins (measured per layer, tools/bench_igemm.py).
+    const int bkt = bkt_env ? bkt_env : (p.Kpad >= 512 ? 64 : 32);
+    return bkt == 32 ? dispatch2<32>(p, s, smallc) : dispatch2<64>(p, s, smallc);
+}

@@ -14,7 +14,8 @@ struct IgemmParams {
     int relu, out_f32, res_mode, res_f32;   // res_mode: 0 none, 1 same shape, 2 nearest-x2 upsample
     int tiles_m, tiles_n;                   // filled by the launcher
 };
-int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);
+int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);   // dispatches to v2 unless DVID_IGEMM_V1 is set
+int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s);
 
 // elementwise.hip
 int dvid_prep_images_launch(const float* nchw, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
