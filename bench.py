@@ -118,6 +118,7 @@ def main():
     cfg.freeze()
     model = build_detection_model(cfg).to(device).eval()
     model.noise_fn = synthetic.noise_fn
+    model.results_on_host = True      # one D2H copy per 8-frame batch (results end up on the host either way)
     H, W, L = 600, 1000, args.frames
     ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank)
     ds.preload()

@@ -131,3 +131,129 @@ int dvid_mha_core_launch(const float* q, const float* k, const float* v, float* 
     LAUNCH_CHECK();
     return DVID_OK;
 }
+
+// =============================================================================================
+// MFMA attention (fp16 operands, fp32 softmax/accumulate), head_dim 32.
+//
+// One wave = 16 queries, one workgroup = 4 waves = 64 queries of one (batch, head).  Per 32 keys:
+//   S^T[key][q] = K[16 keys x 32 dims] . Q^T            two v_mfma_f32_16x16x32_f16 (swapped product, so a
+//                                                        lane holds scores of ONE query: (lane & 15))
+//   online softmax in registers: lane-local max/sum over its 8 keys, 2 xor-shuffles across the four
+//   16-lane groups for the running max; the row sum is reduced across groups once at the end
+//   O^T[d][q] += V^T[16 dims x 32 keys] . P^T           two MFMAs; P^T is built from the S^T accumulators
+//                                                        in registers: MFMA k-slot (group g, j) <-> key
+//                                                        (j < 4 ? 4g + j : 16 + 4g + j - 4), the same slot
+//                                                        map is used for the V^T operand, so no LDS / no
+//                                                        cross-lane traffic is needed for P.
+// K rows and the pre-transposed V^T ([batch][head][32][lk_pad], attn_vt_kernel) are read straight from
+// global memory (L1/L2 resident: 19 KB per (frame, head)).
+// =============================================================================================
+namespace {
+
+// v16 [batch][lk][v_ld] (head h at column h*32) -> vt [batch][nheads][32][lk_pad] (zero padded keys)
+__global__ void attn_vt_kernel(const half_t* __restrict__ v, half_t* __restrict__ vt, int lk, int lk_pad, int v_ld, long v_bs,
+                               int nheads) {
+    __shared__ half_t tile[32][33];
+    const int k0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 256 threads
+    for (int r = ty; r < 32; r += 8) {
+        const int key = k0 + r;
+        tile[r][tx] = key < lk ? v[b * v_bs + (long)key * v_ld + h * 32 + tx] : (half_t)0.f;
+    }
+    __syncthreads();
+    half_t* dst = vt + ((long)(b * nheads + h) * 32) * lk_pad;
+    for (int r = ty; r < 32; r += 8) {
+        const int key = k0 + tx;
+        if (key < lk_pad) dst[(long)r * lk_pad + key] = tile[tx][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void mha_mfma_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k,
+                                                        const half_t* __restrict__ vt, half_t* __restrict__ out, int lq, int lk,
+                                                        int lk_pad, int q_ld, int k_ld, int out_ld, long q_bs, long k_bs,
+                                                        long out_bs, int nheads, float scaling) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    if (q0 >= lq) return;                                          // whole wave out of range (no barriers below)
+    const int qrow = min(q0 + qi, lq - 1);
+    const half8 qf = *reinterpret_cast<const half8*>(q + b * q_bs + (long)qrow * q_ld + h * 32 + g * 8);   // B operand of S^T
+    const half_t* kb = k + b * k_bs + h * 32 + g * 8;
+    const half_t* vb = vt + ((long)(b * nheads + h) * 32) * lk_pad;
+
+    float4v o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};   // O^T rows d = 4g + r (o0) and 16 + 4g + r (o1), column = query
+    float m = -1e30f, l = 0.f;
+    for (int k0 = 0; k0 < lk; k0 += 32) {
+        // ---- scores for keys k0 .. k0+31 (two 16-key tiles) ----
+        const int ka = min(k0 + qi, lk - 1), kbi = min(k0 + 16 + qi, lk - 1);       // A operand rows (clamped; masked below)
+        const half8 kf0 = *reinterpret_cast<const half8*>(kb + (long)ka * k_ld);
+        const half8 kf1 = *reinterpret_cast<const half8*>(kb + (long)kbi * k_ld);
+        float4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf, s0, 0, 0, 0);          // rows = keys k0 + 4g + r
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf, s1, 0, 0, 0);          // rows = keys k0 + 16 + 4g + r
+        float sc[8];
+        float cmax = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = (k0 + 4 * g + r < lk) ? s0[r] * scaling : -1e30f;
+            sc[4 + r] = (k0 + 16 + 4 * g + r < lk) ? s1[r] * scaling : -1e30f;
+            cmax = fmaxf(cmax, fmaxf(sc[r], sc[4 + r]));
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float mn = fmaxf(m, cmax);
+        const float f = __expf(m - mn);
+        float psum = 0.f;
+        half8 pf;                                                   // B operand of O^T: k-slot j <-> sc[j]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float pj = (sc[j] > -1e29f) ? __expf(sc[j] - mn) : 0.f;
+            psum += pj;
+            pf[j] = (half_t)pj;
+        }
+        l = l * f + psum;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0[r] *= f;
+            o1[r] *= f;
+        }
+        // ---- V^T operand: row d = (lane & 15) (+16), k-slots = keys k0+4g..+3 and k0+16+4g..+3 ----
+        const half_t* v0 = vb + (long)qi * lk_pad + k0 + 4 * g;
+        const half_t* v1 = v0 + 16L * lk_pad;
+        const half4 a00 = *reinterpret_cast<const half4*>(v0), a01 = *reinterpret_cast<const half4*>(v0 + 16);
+        const half4 a10 = *reinterpret_cast<const half4*>(v1), a11 = *reinterpret_cast<const half4*>(v1 + 16);
+        const half8 vf0 = {a00[0], a00[1], a00[2], a00[3], a01[0], a01[1], a01[2], a01[3]};
+        const half8 vf1 = {a10[0], a10[1], a10[2], a10[3], a11[0], a11[1], a11[2], a11[3]};
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf0, pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1, pf, o1, 0, 0, 0);
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (q0 + qi >= lq) return;
+    const float inv = 1.f / l;
+    half_t* op = out + b * out_bs + (long)(q0 + qi) * out_ld + h * 32 + 4 * g;
+    const half4 w0 = {(half_t)(o0[0] * inv), (half_t)(o0[1] * inv), (half_t)(o0[2] * inv), (half_t)(o0[3] * inv)};
+    const half4 w1 = {(half_t)(o1[0] * inv), (half_t)(o1[1] * inv), (half_t)(o1[2] * inv), (half_t)(o1[3] * inv)};
+    *reinterpret_cast<half4*>(op) = w0;
+    *reinterpret_cast<half4*>(op + 16) = w1;
+}
+
+}  // namespace
+
+// q16/k16/v16: fp16, head h at columns [h*32, h*32+32) of each row; vt_scratch: >= batch*nheads*32*lk_pad halves,
+// lk_pad = round_up(lk, 32) + 32.
+int dvid_mha_mfma_launch(const half_t* q, const half_t* k, const half_t* v, half_t* out, half_t* vt_scratch, int batch, int lq,
+                         int lk, int nheads, int q_ld, int kv_ld, int out_ld, long q_bs, long kv_bs, long out_bs, hipStream_t s) {
+    if (lq == 0 || batch == 0) return DVID_OK;
+    if (lk <= 0 || (q_ld & 7) || (kv_ld & 7) || (out_ld & 3)) return DVID_ERR_ARG;
+    const int lk_pad = (lk + 31) / 32 * 32 + 32;
+    hipLaunchKernelGGL(attn_vt_kernel, dim3(lk_pad / 32, nheads, batch), dim3(256), 0, s, v, vt_scratch, lk, lk_pad, kv_ld, kv_bs, nheads);
+    LAUNCH_CHECK();
+    const float scaling = 1.0f / sqrtf((float)DH);
+    hipLaunchKernelGGL(mha_mfma_kernel, dim3(ceil_div(lq, 64), nheads, batch), dim3(256), 0, s, q, k, vt_scratch, out, lq, lk, lk_pad,
+                       q_ld, kv_ld, out_ld, q_bs, kv_bs, out_bs, nheads, scaling);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}

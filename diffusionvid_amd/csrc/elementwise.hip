@@ -92,7 +92,7 @@ __global__ void nhwc_from_nchw_kernel(const float* __restrict__ in, half_t* __re
 template <int MAXV>
 __global__ void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ g,
                                      const float* __restrict__ b, float* __restrict__ y32, half_t* __restrict__ y16, int rows, int d,
-                                     int relu) {
+                                     int relu, int nsplit, long split_stride, const float* __restrict__ xbias) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -104,6 +104,9 @@ __global__ void add_layernorm_kernel(const float* __restrict__ x, const float* _
         const int j = lane + i * 64;
         if (j < nv) {
             v[i] = *reinterpret_cast<const float4v*>(x + (long)row * d + j * 4);
+            for (int sp = 1; sp < nsplit; ++sp)      // split-K partial slabs of the producing GEMM
+                v[i] += *reinterpret_cast<const float4v*>(x + sp * split_stride + (long)row * d + j * 4);
+            if (xbias) v[i] += *reinterpret_cast<const float4v*>(xbias + j * 4);
             if (r) v[i] += *reinterpret_cast<const float4v*>(r + (long)row * d + j * 4);
             sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
@@ -215,14 +218,14 @@ int dvid_nhwc_from_nchw_launch(const float* in, half_t* out, int n, int h, int w
 }
 
 int dvid_add_layernorm_launch(const float* x, const float* r, const float* g, const float* b, float* y32, half_t* y16, int rows,
-                              int d, int relu, hipStream_t s) {
+                              int d, int relu, hipStream_t s, int nsplit, long split_stride, const float* xbias) {
     if (d % 4 || d > 1024) return DVID_ERR_ARG;
     const int wpb = 4;
     const dim3 grid(ceil_div(rows, wpb)), block(64 * wpb);
     if (d <= 256)
-        hipLaunchKernelGGL(add_layernorm_kernel<1>, grid, block, 0, s, x, r, g, b, y32, y16, rows, d, relu);
+        hipLaunchKernelGGL(add_layernorm_kernel<1>, grid, block, 0, s, x, r, g, b, y32, y16, rows, d, relu, nsplit, split_stride, xbias);
     else
-        hipLaunchKernelGGL(add_layernorm_kernel<4>, grid, block, 0, s, x, r, g, b, y32, y16, rows, d, relu);
+        hipLaunchKernelGGL(add_layernorm_kernel<4>, grid, block, 0, s, x, r, g, b, y32, y16, rows, d, relu, nsplit, split_stride, xbias);
     LAUNCH_CHECK();
     return DVID_OK;
 }

@@ -24,20 +24,29 @@ namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
 
-template <int BM, int BN, int BKT>
+template <int BM, int BN, int BKT, int NSTAGE>
 struct Smem2 {
     static constexpr int kStage = (BM + BN) * BKT * 2;
     static constexpr int kCPitch = BN + 4;
     static constexpr int kCHalf = (BM / 2) * kCPitch * 4;
-    static constexpr int kBytes = (2 * kStage > kCHalf) ? 2 * kStage : kCHalf;
+    static constexpr int kBytes = (NSTAGE * kStage > kCHalf) ? NSTAGE * kStage : kCHalf;
 };
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int BKT, bool SMALLC>
+// NSTAGE 2: one DMA tile in flight, `__syncthreads()` per K step (the compiler drains vmcnt there).
+// NSTAGE 3: ring of three stages, two DMA tiles in flight across a raw `s_barrier`; each wave waits with a
+//           COUNTED `s_waitcnt vmcnt(P)` (P = its DMA pieces per tile) so only the tile about to be read has
+//           landed, and re-fills the stage freed by the previous step right after the barrier.
+template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC>
 __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
     constexpr int ROW_BYTES = BKT * 2;
     constexpr int CHUNKS = BKT / 8;                 // 16-byte chunks per row
@@ -46,14 +55,16 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
     constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves 2x2)
     constexpr int A_IT = BM / RPP / 4, B_IT = BN / RPP / 4;   // DMA pieces per wave per K tile
     constexpr int A_BYTES = BM * ROW_BYTES;
-    constexpr int STAGE = Smem2<BM, BN, BKT>::kStage;
+    constexpr int STAGE = Smem2<BM, BN, BKT, NSTAGE>::kStage;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int lid = igemm_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int split = p.splitk > 1 ? (int)blockIdx.x / ntiles : 0;       // wave-uniform
+    const int lid = igemm_xcd_remap((int)blockIdx.x - split * ntiles, ntiles);
     const int tile_n = lid % p.tiles_n, tile_m = lid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -91,8 +102,17 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
         b_off[i] = (b_ok[i] ? n : 0) * p.Kpad + (pch ^ ((row >> KEY_SHIFT) & (CHUNKS - 1))) * 8;
     }
 
-    // filter-tap walk of the K loop (wave-uniform): k0 = tap * Cin + c0
+    // K range of this workgroup (split-K) and the filter-tap walk of the K loop (wave-uniform): k0 = tap*Cin + c0
+    const int nk_all = p.Kpad / BKT;
+    const int nk = p.splitk > 1 ? nk_all / p.splitk : nk_all;
+    const int kt0 = split * nk;
     int ky = 0, kx = 0, c0 = 0;
+    if (!SMALLC && kt0) {
+        const int tap = (kt0 * BKT) / p.Cin;
+        c0 = kt0 * BKT - tap * p.Cin;
+        ky = tap / p.KW;
+        kx = tap - ky * p.KW;
+    }
 
     auto issue = [&](int kt, int stage) {
         char* sa = smem + stage * STAGE;
@@ -138,9 +158,24 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.Kpad / BKT;
-    issue(0, 0);
-    __syncthreads();
+    // ---- residual prefetch: issued before the K loop so its HBM latency hides under it -------------
+    constexpr int VPR = BN / 8;
+    constexpr int ERPP = 256 / VPR;
+    constexpr int EROWS = (BM / 2) / ERPP;
+    const int c8 = (tid % VPR) * 8;
+    const int n = n0 + c8;
+    const bool pre_ok = p.res_mode == 1 && !p.res_f32 && (p.Cout & 7) == 0;
+    half8 rpre[2][EROWS];
+    if (pre_ok) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int e = 0; e < EROWS; ++e) {
+                const int m = m0 + half * (BM / 2) + tid / VPR + e * ERPP;
+                const bool ok = m < p.M && n < p.Cout;
+                rpre[half][e] = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.res) + (ok ? (long)m * p.Cout + n : 0));
+            }
+    }
 
     // fragment addressing: row = base32 + (lane & 31); logical chunk = 2*ks + (lane >> 5)
     constexpr int KS = BKT / 16;
@@ -152,10 +187,8 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) choff[ks] = ((2 * ks + (lane >> 5)) ^ sw) * 16;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-        const char* st = smem + cur * STAGE;
+    auto compute = [&](int stage) {
+        const char* st = smem + stage * STAGE;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             half8 fa[TM], fb[TN];
@@ -169,16 +202,37 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();   // drains this wave's DMA (vmcnt) and publishes the next stage
+    };
+
+    if (NSTAGE == 2) {
+        issue(kt0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) issue(kt0 + kt + 1, cur ^ 1);
+            compute(cur);
+            __syncthreads();   // drains this wave's DMA (vmcnt) and publishes the next stage
+        }
+    } else {
+        constexpr int P = A_IT + B_IT;          // DMA instructions per wave per K tile
+        issue(kt0, 0);
+        if (nk > 1) issue(kt0 + 1, 1);
+        int cs = 0, is = 2;                     // stage being computed / stage to refill
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) wait_vmcnt<P>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();       // tile kt visible to all waves; stage `is` no longer read
+            if (kt + 2 < nk) issue(kt0 + kt + 2, is);
+            compute(cs);
+            cs = (cs == NSTAGE - 1) ? 0 : cs + 1;
+            is = (is == NSTAGE - 1) ? 0 : is + 1;
+        }
+        __syncthreads();                        // all waves done with the ring before it becomes the C buffer
     }
 
     // ---- epilogue: two half tiles (rows of wm = 0, then wm = 1) through an fp32 LDS buffer ---------
-    constexpr int CP = Smem2<BM, BN, BKT>::kCPitch;
-    constexpr int VPR = BN / 8;
-    constexpr int ERPP = 256 / VPR;
+    constexpr int CP = Smem2<BM, BN, BKT, NSTAGE>::kCPitch;
     float* Cs = reinterpret_cast<float*>(smem);
-    const int c8 = (tid % VPR) * 8;
-    const int n = n0 + c8;
+    if (p.splitk > 1) p.out = reinterpret_cast<float*>(p.out) + split * p.split_stride;
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = (p.bias && n + e < p.Cout) ? p.bias[n + e] : 0.f;
@@ -198,42 +252,45 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
                     }
         }
         __syncthreads();
-        for (int r = tid / VPR; r < BM / 2; r += ERPP) {
+#pragma unroll
+        for (int e = 0; e < EROWS; ++e) {
+            const int r = tid / VPR + e * ERPP;
             const int m = m0 + half * (BM / 2) + r;
-            if (m < p.M && n < p.Cout) igemm_store_row8(p, Cs + r * CP + c8, m, n, bias8);
+            if (m < p.M && n < p.Cout) igemm_store_row8(p, Cs + r * CP + c8, m, n, bias8, pre_ok, rpre[half][e]);
         }
     }
 }
 
-template <int BM, int BN, int BKT, bool SMALLC>
+template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC>
 int launch2(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.Cout, BN);
-    constexpr int smem = Smem2<BM, BN, BKT>::kBytes;
+    constexpr int smem = Smem2<BM, BN, BKT, NSTAGE>::kBytes;
     if (smem > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, SMALLC>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, SMALLC>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, SMALLC>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p);
+    const int nsplit = p.splitk > 1 ? p.splitk : 1;
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, SMALLC>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(256), smem, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
 }
 
-template <int BKT>
+template <int BKT, int NSTAGE>
 int dispatch2(const IgemmParams& p, hipStream_t s, bool smallc) {
-    if (smallc) return launch2<128, 64, BKT, true>(p, s);
-    // resident workgroups per CU: 4 (BKT 32) / 2 (BKT 64) for the 128x128 tile; prefer the big tile while it
-    // still gives every CU at least ~2 workgroups
-    const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.Cout, 128);
-    if (t128 >= 512 && p.Cout >= 128) return launch2<128, 128, BKT, false>(p, s);
-    const long t12864 = (long)ceil_div(p.M, 128) * ceil_div(p.Cout, 64);
-    if (t12864 >= 512) return launch2<128, 64, BKT, false>(p, s);
-    return launch2<64, 64, BKT, false>(p, s);
+    if (smallc) return launch2<128, 64, BKT, NSTAGE, true>(p, s);
+    // prefer the big tile while it still gives every CU ~2 workgroups
+    const int ns = p.splitk > 1 ? p.splitk : 1;
+    const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.Cout, 128) * ns;
+    if (t128 >= 512 && p.Cout >= 128) return launch2<128, 128, BKT, NSTAGE, false>(p, s);
+    const long t12864 = (long)ceil_div(p.M, 128) * ceil_div(p.Cout, 64) * ns;
+    if (t12864 >= 512) return launch2<128, 64, BKT, NSTAGE, false>(p, s);
+    return launch2<64, 64, BKT, NSTAGE, false>(p, s);
 }
 
 }  // namespace
@@ -245,9 +302,13 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
     const bool smallc = (p.Cin == 8 && p.KH * p.KW > 1);
     if (!smallc && (p.Cin % 64 != 0)) return DVID_ERR_UNSUPPORTED;
     if (p.res_mode == 2 && ((p.Ho | p.Wo) & 1)) return DVID_ERR_ARG;
+    if (p.splitk > 1 && (!p.out_f32 || p.bias || p.relu || p.res_mode || smallc || (p.Kpad / 64) % p.splitk)) return DVID_ERR_ARG;
     // Long-K layers are bound by the global->LDS staging rate: full 128-byte lines (BKT 64) win.  Short-K
     // layers (<= 4 K steps) are bound by HBM traffic and the epilogue: the smaller LDS footprint of BKT 32
     // (4 resident workgroups per CU instead of 2) wins (measured per layer, tools/bench_igemm.py).
+    static const int nst_env = getenv("DVID_IGEMM_STAGES") ? atoi(getenv("DVID_IGEMM_STAGES")) : 0;
     const int bkt = bkt_env ? bkt_env : (p.Kpad >= 512 ? 64 : 32);
-    return bkt == 32 ? dispatch2<32>(p, s, smallc) : dispatch2<64>(p, s, smallc);
+    const int nst = nst_env ? nst_env : 2;
+    if (bkt == 32) return nst == 3 ? dispatch2<32, 3>(p, s, smallc) : dispatch2<32, 2>(p, s, smallc);
+    return nst == 3 ? dispatch2<64, 3>(p, s, smallc) : dispatch2<64, 2>(p, s, smallc);
 }

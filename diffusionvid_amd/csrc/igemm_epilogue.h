@@ -5,8 +5,10 @@
 #include "common.h"
 #include "kernels.h"
 
+// `pre`: residual vector already fetched by the caller (res_mode 1, fp16, Cout % 8 == 0) when use_pre.
 __device__ __forceinline__ void igemm_store_row8(const IgemmParams& p, const float* __restrict__ cs, int m, int n,
-                                                 const float (&bias8)[8]) {
+                                                 const float (&bias8)[8], bool use_pre = false,
+                                                 half8 pre = half8{0, 0, 0, 0, 0, 0, 0, 0}) {
     float v[8];
     const float4v lo = *reinterpret_cast<const float4v*>(cs);
     const float4v hi = *reinterpret_cast<const float4v*>(cs + 4);
@@ -16,7 +18,10 @@ __device__ __forceinline__ void igemm_store_row8(const IgemmParams& p, const flo
         v[e + 4] = hi[e] + bias8[e + 4];
     }
     const bool vec_ok = (p.Cout & 7) == 0;
-    if (p.res_mode) {
+    if (use_pre) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)pre[e];
+    } else if (p.res_mode) {
         long ridx;
         if (p.res_mode == 1) {
             ridx = (long)m * p.Cout + n;

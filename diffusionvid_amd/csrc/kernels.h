@@ -12,6 +12,8 @@ struct IgemmParams {
     int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int M, Kpad, ntaps, ldc, alg_k;
     int relu, out_f32, res_mode, res_f32;   // res_mode: 0 none, 1 same shape, 2 nearest-x2 upsample
+    int splitk;                             // > 1: K split over `splitk` workgroups per tile, fp32 partials (no bias/relu/residual)
+    long split_stride;                      //       written to out + split * split_stride (elements)
     int tiles_m, tiles_n;                   // filled by the launcher
 };
 int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);   // dispatches to v2 unless DVID_IGEMM_V1 is set
@@ -24,8 +26,10 @@ int dvid_maxpool3x3s2_launch(const half_t* in, half_t* out, int n, int h, int w,
 int dvid_nchw_from_nhwc_launch(const half_t* in, float* out, int n, int h, int w, int c, hipStream_t s);
 int dvid_nhwc_from_nchw_launch(const float* in, half_t* out, int n, int h, int w, int c, hipStream_t s);
 // y = LN(x + r) * g + b, rows of D (= 256 or 64-multiple <= 1024); writes fp32 and/or fp16 copies
+// x may be `nsplit` split-K partial slabs (x + s * split_stride) plus a per-column bias `xbias` (or nsplit 1, null)
 int dvid_add_layernorm_launch(const float* x, const float* r, const float* g, const float* b, float* y32, half_t* y16,
-                              int rows, int d, int relu, hipStream_t s);
+                              int rows, int d, int relu, hipStream_t s, int nsplit = 1, long split_stride = 0,
+                              const float* xbias = nullptr);
 int dvid_f32_to_f16_launch(const float* x, half_t* y, long n, hipStream_t s);
 // fc = x * (scale[frame] + 1) + shift  (shift per frame [B,D] or per row [R,D])
 int dvid_modulate_launch(const float* x, const float* scale, int scale_ld, const float* shift, int shift_per_row, int shift_ld,
@@ -45,6 +49,10 @@ int dvid_roialign_launch(const RoiLevels& lv, int channels, const float* boxes, 
 int dvid_mha_core_launch(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads,
                          int head_dim, int q_ld, int kv_ld, int out_ld, long q_bs, long kv_bs, long out_bs, half_t* out16,
                          hipStream_t s);
+
+// MFMA variant: fp16 q/k/v (head h at columns h*32..), fp16 out; vt_scratch >= batch*nheads*32*(round_up(lk,32)+32) halves
+int dvid_mha_mfma_launch(const half_t* q, const half_t* k, const half_t* v, half_t* out, half_t* vt_scratch, int batch, int lq,
+                         int lk, int nheads, int q_ld, int kv_ld, int out_ld, long q_bs, long kv_bs, long out_bs, hipStream_t s);
 
 // dynconv.hip
 int dvid_dynconv_launch(const half_t* roi, const half_t* params, const float* g1, const float* b1, const float* g2,

@@ -154,7 +154,7 @@ struct dvid_model {
     // workspace
     int ws_frames = 0, ws_h = 0, ws_w = 0, ws_boxes = 0;
     DevBuf img8, bufX, bufY, bufT1, bufT2, bufSC, c3, c4, c5, lat[3];
-    DevBuf roi, params, dyn, qkv, attn16, f32a, f32b, f32c, f32d, h16a, h16b, hid16, ss, deltas, kvproj, mem16;
+    DevBuf roi, params, dyn, qkv, attn16, f32a, f32b, f32c, f32d, h16a, h16b, hid16, ss, deltas, kvproj, mem16, splitk, vt;
     std::map<int, std::vector<int64_t>> ss_keys;  // per head slot: t vector of the uploaded scale/shift table
 
     int upload(const void* host, size_t bytes, void** dev) {
@@ -316,7 +316,7 @@ int make_head(dvid_model* m, const std::string& pfx, bool cond, HeadW* h) {
 }
 
 int conv_run(const ConvW& w, const half_t* in, int n, int h, int wd, void* out, int relu, int out_f32, const void* res,
-             int res_mode, int res_f32, hipStream_t s, int* ho_out = nullptr, int* wo_out = nullptr, int ldc = 0) {
+             int res_mode, int res_f32, hipStream_t s, int* ho_out = nullptr, int* wo_out = nullptr, int ldc = 0, int splitk = 1) {
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.in = in;
@@ -343,6 +343,11 @@ int conv_run(const ConvW& w, const half_t* in, int n, int h, int wd, void* out, 
     p.out_f32 = out_f32;
     p.res_mode = res_mode;
     p.res_f32 = res_f32;
+    if (splitk > 1) {               // fp32 partial slabs; bias/activation are applied by the consumer
+        p.splitk = splitk;
+        p.split_stride = (long)p.M * p.ldc;
+        p.bias = nullptr;
+    }
     if (ho_out) *ho_out = p.Ho;
     if (wo_out) *wo_out = p.Wo;
     return igemm(p, s);
@@ -410,7 +415,7 @@ int dvid_model_destroy(dvid_model* m) {
     for (void* p : m->owned) (void)hipFree(p);
     DevBuf* bufs[] = {&m->img8, &m->bufX, &m->bufY, &m->bufT1, &m->bufT2, &m->bufSC, &m->c3, &m->c4, &m->c5, &m->lat[0],
                       &m->lat[1], &m->lat[2], &m->roi, &m->params, &m->dyn, &m->qkv, &m->attn16, &m->f32a, &m->f32b, &m->f32c,
-                      &m->f32d, &m->h16a, &m->h16b, &m->hid16, &m->ss, &m->deltas, &m->kvproj, &m->mem16};
+                      &m->f32d, &m->h16a, &m->h16b, &m->hid16, &m->ss, &m->deltas, &m->kvproj, &m->mem16, &m->splitk, &m->vt};
     for (DevBuf* b : bufs) b->release();
     delete m;
     return DVID_OK;
@@ -521,6 +526,8 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
     TRY(m->hid16.ensure(R * m->cfg.dim_feedforward * 2));
     TRY(m->ss.ensure((size_t)(m->cfg.num_heads + m->cfg.num_heads_cond) * n * 2 * d * 4));
     TRY(m->deltas.ensure(R * 4 * 4));
+    TRY(m->splitk.ensure(R * d * 4 * 8));
+    TRY(m->vt.ensure((size_t)n * m->cfg.nheads * 32 * (((size_t)boxes_per_frame + 31) / 32 * 32 + 32) * 2));          // up to 8 split-K slabs of an [R, d] fp32 output
     m->ws_frames = max_frames;
     m->ws_h = height;
     m->ws_w = width;
@@ -640,10 +647,10 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
     const float* pro = pro_features ? pro_features : pro32;
     // --- self attention + norm1 ---
     TRY(dvid_f32_to_f16_launch(pro, m->h16a.as<half_t>(), (long)R * d, s));
-    TRY(linear_run(hw.in_proj, m->h16a.as<half_t>(), R, m->qkv.p, 0, 1, s));
-    const float* qkv = m->qkv.as<float>();
-    TRY(dvid_mha_core_launch(qkv, qkv + d, qkv + 2 * d, nullptr, n_frames, M, M, m->cfg.nheads, d / m->cfg.nheads, 3 * d, 3 * d, d,
-                             (long)M * 3 * d, (long)M * 3 * d, (long)M * d, m->attn16.as<half_t>(), s));
+    TRY(linear_run(hw.in_proj, m->h16a.as<half_t>(), R, m->qkv.p, 0, 0, s));          // fp16 q|k|v, MFMA operands
+    const half_t* qkv = m->qkv.as<half_t>();
+    TRY(dvid_mha_mfma_launch(qkv, qkv + d, qkv + 2 * d, m->attn16.as<half_t>(), m->vt.as<half_t>(), n_frames, M, M, m->cfg.nheads,
+                             3 * d, 3 * d, d, (long)M * 3 * d, (long)M * 3 * d, (long)M * d, s));
     TRY(linear_run(hw.out_proj, m->attn16.as<half_t>(), R, m->f32b.p, 0, 1, s));
     float* x1 = m->f32c.as<float>();
     TRY(dvid_add_layernorm_launch(pro, m->f32b.as<float>(), hw.norm1.g, hw.norm1.b, x1, m->h16a.as<half_t>(), R, d, 0, s));
@@ -651,8 +658,17 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
     TRY(linear_run(hw.dynamic_layer, m->h16a.as<half_t>(), R, m->params.p, 0, 0, s));
     TRY(dvid_dynconv_launch(m->roi.as<half_t>(), m->params.as<half_t>(), hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b,
                             m->dyn.as<half_t>(), R, s));
-    TRY(linear_run(hw.out_layer, m->dyn.as<half_t>(), R, m->f32b.p, 0, 1, s));
-    TRY(dvid_add_layernorm_launch(m->f32b.as<float>(), nullptr, hw.dc_norm3.g, hw.dc_norm3.b, m->f32b.as<float>(), nullptr, R, d, 1, s));
+    // out_layer: K = 49*d = 12544 on only R x d outputs -> split K over 7 workgroups per tile; the partial slabs
+    // and the bias are summed inside the norm3 kernel that consumes them.
+    const int osplit = ((hw.out_layer.kpad / 64) % 7 == 0) ? 7 : 1;
+    if (osplit > 1) {
+        TRY(conv_run(hw.out_layer, m->dyn.as<half_t>(), R, 1, 1, m->splitk.p, 0, 1, nullptr, 0, 0, s, nullptr, nullptr, 0, osplit));
+        TRY(dvid_add_layernorm_launch(m->splitk.as<float>(), nullptr, hw.dc_norm3.g, hw.dc_norm3.b, m->f32b.as<float>(), nullptr, R, d, 1,
+                                      s, osplit, (long)R * d, hw.out_layer.bias));
+    } else {
+        TRY(linear_run(hw.out_layer, m->dyn.as<half_t>(), R, m->f32b.p, 0, 1, s));
+        TRY(dvid_add_layernorm_launch(m->f32b.as<float>(), nullptr, hw.dc_norm3.g, hw.dc_norm3.b, m->f32b.as<float>(), nullptr, R, d, 1, s));
+    }
     float* obj = m->f32d.as<float>();
     TRY(dvid_add_layernorm_launch(x1, m->f32b.as<float>(), hw.norm2.g, hw.norm2.b, obj, m->h16a.as<half_t>(), R, d, 0, s));
     // --- FFN + norm3 ---
@@ -700,11 +716,12 @@ int dvid_global_xattn(dvid_model* m, const float* query, int rows, const float* 
     TRY(m->mem16.ensure((size_t)lk * d * 2));
     TRY(dvid_f32_to_f16_launch(query, m->h16a.as<half_t>(), (long)rows * d, s));
     TRY(dvid_f32_to_f16_launch(memory, m->mem16.as<half_t>(), (long)lk * d, s));
-    TRY(linear_run(m->gq, m->h16a.as<half_t>(), rows, m->f32b.p, 0, 1, s));
-    TRY(linear_run(m->gkv, m->mem16.as<half_t>(), lk, m->kvproj.p, 0, 1, s));
-    const float* kv = m->kvproj.as<float>();
-    TRY(dvid_mha_core_launch(m->f32b.as<float>(), kv, kv + d, nullptr, 1, rows, lk, m->cfg.nheads, d / m->cfg.nheads, d, 2 * d, d, 0, 0,
-                             0, m->attn16.as<half_t>(), s));
+    TRY(linear_run(m->gq, m->h16a.as<half_t>(), rows, m->h16b.p, 0, 0, s));
+    TRY(linear_run(m->gkv, m->mem16.as<half_t>(), lk, m->kvproj.p, 0, 0, s));
+    const half_t* kv = m->kvproj.as<half_t>();
+    TRY(m->vt.ensure((size_t)m->cfg.nheads * 32 * (((size_t)lk + 31) / 32 * 32 + 32) * 2));
+    TRY(dvid_mha_mfma_launch(m->h16b.as<half_t>(), kv, kv + d, m->attn16.as<half_t>(), m->vt.as<half_t>(), 1, rows, lk, m->cfg.nheads,
+                             d, 2 * d, d, 0, 0, 0, s));
     TRY(linear_run(m->gout, m->attn16.as<half_t>(), rows, out, 0, 1, s));
     return DVID_OK;
 }
@@ -807,6 +824,15 @@ int dvid_mha_core(const float* q, const float* k, const float* v, float* out, in
     g_err[0] = 0;
     TRY(dvid_mha_core_launch(q, k, v, out, batch, lq, lk, nheads, head_dim, q_ld, kv_ld, out_ld, q_bs, kv_bs, out_bs, nullptr,
                              reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_mha_f16(const void* q, const void* k, const void* v, void* out, void* vt_scratch, int batch, int lq, int lk, int nheads,
+                 int q_ld, int kv_ld, int out_ld, int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_mha_mfma_launch(reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k), reinterpret_cast<const half_t*>(v),
+                             reinterpret_cast<half_t*>(out), reinterpret_cast<half_t*>(vt_scratch), batch, lq, lk, nheads, q_ld, kv_ld,
+                             out_ld, q_bs, kv_bs, out_bs, reinterpret_cast<hipStream_t>(stream)));
     return DVID_OK;
 }
 

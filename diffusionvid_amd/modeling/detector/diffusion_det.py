@@ -122,6 +122,9 @@ class DiffusionDet(nn.Module):
         self._engine = None
         self.noise_fn = None
         self.debug_taps = None      # dict -> receives intermediates (parity tests)
+        # True: a batch's detections come back with ONE device->host copy and the BoxLists hold CPU tensors
+        # (what engine/inference.py does next anyway, there with ~3 copies per frame); False: GPU tensors
+        self.results_on_host = False
         self.video_index = 0
         self.demo = False
 
@@ -305,6 +308,10 @@ class DiffusionDet(nn.Module):
         return ops.postproc_topk_nms(torch.stack(ens_logits), torch.stack(ens_boxes), w, h, 0.5, self.use_nms)
 
     def _to_boxlists(self, ob, osc, ol, oc, size_wh):
+        flat = getattr(ob, "_dvid_flat", None)
+        if self.results_on_host and flat is not None:
+            n, cap = osc.shape
+            ob, osc, ol, oc = ops.split_detection_buffer(flat.cpu(), n, cap)      # single D2H copy + sync
         counts = oc.tolist()                 # the one host sync of a batch (the caller moves results to CPU anyway)
         self.head.check_boxes_valid()
         results = []

@@ -95,6 +95,25 @@ def mha_core(q, k, v, nheads):
     return out
 
 
+def mha_f16(q, k, v, nheads):
+    """MFMA attention: q [B, Lq, d], k/v [B, Lk, d] (fp32 or fp16, rounded to fp16) -> fp16 [B, Lq, d]."""
+    def h(t):
+        t = _cuda(t)
+        if t.dtype == torch.float16:
+            return t
+        o = torch.empty(t.shape, dtype=torch.float16, device=t.device)
+        call("dvid_f32_to_f16", ptr(t), ptr(o), t.numel(), stream_ptr())
+        return o
+    q, k, v = h(q), h(k), h(v)
+    B, lq, d = q.shape
+    lk = k.shape[1]
+    out = torch.empty_like(q)
+    vt = torch.empty((B * nheads * 32 * ((lk + 31) // 32 * 32 + 32),), dtype=torch.float16, device=q.device)
+    call("dvid_mha_f16", ptr(q), ptr(k), ptr(v), ptr(out), ptr(vt), B, lq, lk, nheads, d, d, d, lq * d, lk * d, lq * d,
+         stream_ptr())
+    return out
+
+
 def dynconv(roi16, params16, g1, b1, g2, b2):
     roi16, params16 = _cuda(roi16, torch.float16), _cuda(params16, torch.float16)
     out = torch.empty_like(roi16)
@@ -147,13 +166,23 @@ def postproc_topk_nms(logits, boxes, img_w, img_h, iou=0.5, use_nms=True):
     logits, boxes = _cuda(logits, torch.float32), _cuda(boxes, torch.float32)
     S, n, M, c = logits.shape
     dev = logits.device
-    ob = torch.empty((n, S * M, 4), dtype=torch.float32, device=dev)
-    osc = torch.empty((n, S * M), dtype=torch.float32, device=dev)
-    ol = torch.empty((n, S * M), dtype=torch.int32, device=dev)
-    oc = torch.empty((n,), dtype=torch.int32, device=dev)
+    ob, osc, ol, oc = split_detection_buffer(torch.empty((n * S * M * 6 + n,), dtype=torch.float32, device=dev), n, S * M)
     scratch = torch.empty((n * S * M * 6,), dtype=torch.float32, device=dev)
     call("dvid_postproc_topk_nms", ptr(logits), ptr(boxes), S, n, M, c, float(img_w), float(img_h), float(iou), int(use_nms),
          ptr(ob), ptr(osc), ptr(ol), ptr(oc), ptr(scratch), stream_ptr())
+    return ob, osc, ol, oc
+
+
+def split_detection_buffer(buf, n, cap):
+    """The four post-processing outputs are views of ONE flat fp32 buffer [boxes | scores | labels(int32) |
+    counts(int32)], so a caller can bring a whole batch to the host with a single D2H copy
+    (`split_detection_buffer(ob.untyped... ` see DiffusionDet._to_boxlists)."""
+    a, b = n * cap * 4, n * cap * 5
+    ob = buf[:a].view(n, cap, 4)
+    osc = buf[a:b].view(n, cap)
+    ol = buf[b:b + n * cap].view(torch.int32).view(n, cap)
+    oc = buf[b + n * cap:b + n * cap + n].view(torch.int32)
+    ob._dvid_flat = buf            # keep the flat buffer reachable from the first view
     return ob, osc, ol, oc
 
 

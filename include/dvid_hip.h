@@ -127,6 +127,10 @@ int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const
                          int residual_mode, void* stream);
 int dvid_mha_core(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int head_dim,
                   int q_ld, int kv_ld, int out_ld, int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream);
+/* MFMA attention, head_dim 32: fp16 q/k/v with head h at columns [32h, 32h+32) of each row, fp16 out;
+ * vt_scratch: >= batch*nheads*32*(round_up(lk,32)+32) halves (receives V transposed per head). */
+int dvid_mha_f16(const void* q, const void* k, const void* v, void* out, void* vt_scratch, int batch, int lq, int lk, int nheads,
+                 int q_ld, int kv_ld, int out_ld, int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream);
 int dvid_dynconv(const void* roi, const void* params, const float* g1, const float* b1, const float* g2, const float* b2,
                  void* out, int rows, void* stream);
 int dvid_add_layernorm(const float* x, const float* r, const float* g, const float* b, float* y, int rows, int d, int relu,

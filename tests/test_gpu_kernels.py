@@ -146,6 +146,20 @@ def test_mha_core(dv, B, lq, lk):
     check(f"mha_core[{B},{lq},{lk}]", out, ref, 1e-3, 1e-3)
 
 
+@pytest.mark.parametrize("B,lq,lk", [(2, 300, 300), (1, 777, 900), (1, 64, 37), (3, 17, 1)])
+def test_mha_mfma(dv, B, lq, lk):
+    """MFMA attention: fp16 operands (oracle gets the same rounded q/k/v), fp32 softmax, fp16 output."""
+    g = torch.Generator().manual_seed(55)
+    d, nh = 256, 8
+    q, k, v = (h16(torch.randn(B, l, d, generator=g)) for l in (lq, lk, lk))
+    qh = q.view(B, lq, nh, 32).transpose(1, 2) / math.sqrt(32)
+    kh, vh = k.view(B, lk, nh, 32).transpose(1, 2), v.view(B, lk, nh, 32).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), dim=-1) @ vh).transpose(1, 2).reshape(B, lq, d)
+    out = dv.mha_f16(q.cuda(), k.cuda(), v.cuda(), nh)
+    # P is rounded to fp16 before the PV product (as apex O1's fp16 bmm does): ~1e-3 relative
+    check(f"mha_mfma[{B},{lq},{lk}]", out, ref, 4e-3, 4e-3)
+
+
 def test_add_layernorm(dv):
     g = torch.Generator().manual_seed(6)
     x, r = torch.randn(601, 256, generator=g) * 3 + 1, torch.randn(601, 256, generator=g)
