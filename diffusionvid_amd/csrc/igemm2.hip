@@ -72,76 +72,95 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
     const int lrow = lane / CHUNKS;
     const int pch = lane % CHUNKS;                              // physical chunk this lane fills
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
-    int a_base[A_IT], a_iy[A_IT], a_ix[A_IT], a_lch[A_IT];
+    // Per DMA piece the lane keeps ONE precomputed source pointer (tap (0,0), its own chunk) and a bitmask of the
+    // filter taps that fall inside the image for its output pixel; a K step then costs a bit test, a 64-bit add of
+    // a wave-uniform byte offset and a select against the zero page (the per-step bounds/address arithmetic of the
+    // first version was ~10 VALU per MFMA and made the waves issue-bound, profiles/r01_pmc_res4.txt).
+    const char* a_ptr[A_IT];
+    unsigned a_mask[A_IT];
+    int a_iy[A_IT], a_ix[A_IT], a_lch[A_IT];       // only used by the SMALLC (stem) path
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int row = RPP * (wave + 4 * i) + lrow;
         a_lch[i] = pch ^ ((row >> KEY_SHIFT) & (CHUNKS - 1));   // logical chunk stored at this position
         const int m = m0 + row;
+        a_mask[i] = 0u;
+        a_ptr[i] = zero;
+        a_iy[i] = -(1 << 28);
+        a_ix[i] = 0;
         if (m < p.M) {
             const int ox = m % p.Wo;
             const int t = m / p.Wo;
             const int oy = t % p.Ho;
             const int img = t / p.Ho;
-            a_iy[i] = oy * p.stride - p.pad;
-            a_ix[i] = ox * p.stride - p.pad;
-            a_base[i] = ((img * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin;
-        } else {
-            a_iy[i] = -(1 << 28);
-            a_ix[i] = 0;
-            a_base[i] = 0;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            a_iy[i] = iy0;
+            a_ix[i] = ix0;
+            a_ptr[i] = reinterpret_cast<const char*>(p.in + ((long)(img * p.H + iy0) * p.W + ix0) * p.Cin + (SMALLC ? 0 : a_lch[i] * 8));
+            if (!SMALLC) {
+                for (int t2 = 0; t2 < p.ntaps; ++t2) {
+                    const int ty = t2 / p.KW, tx = t2 - ty * p.KW;
+                    if ((unsigned)(iy0 + ty) < (unsigned)p.H && (unsigned)(ix0 + tx) < (unsigned)p.W) a_mask[i] |= 1u << t2;
+                }
+            }
         }
     }
-    int b_off[B_IT];
-    bool b_ok[B_IT];
+    const char* b_ptr[B_IT];
+    int b_step[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int row = RPP * (wave + 4 * i) + lrow;
         const int n = n0 + row;
-        b_ok[i] = n < p.Cout;
-        b_off[i] = (b_ok[i] ? n : 0) * p.Kpad + (pch ^ ((row >> KEY_SHIFT) & (CHUNKS - 1))) * 8;
+        const bool ok = n < p.Cout;
+        b_ptr[i] = ok ? reinterpret_cast<const char*>(p.w + (long)n * p.Kpad + (pch ^ ((row >> KEY_SHIFT) & (CHUNKS - 1))) * 8) : zero;
+        b_step[i] = ok ? BKT * 2 : 0;
     }
 
     // K range of this workgroup (split-K) and the filter-tap walk of the K loop (wave-uniform): k0 = tap*Cin + c0
     const int nk_all = p.Kpad / BKT;
     const int nk = p.splitk > 1 ? nk_all / p.splitk : nk_all;
     const int kt0 = split * nk;
-    int ky = 0, kx = 0, c0 = 0;
+    int ky = 0, kx = 0, c0 = 0, tap = 0;
     if (!SMALLC && kt0) {
-        const int tap = (kt0 * BKT) / p.Cin;
+        tap = (kt0 * BKT) / p.Cin;
         c0 = kt0 * BKT - tap * p.Cin;
         ky = tap / p.KW;
         kx = tap - ky * p.KW;
     }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) b_ptr[i] += (long)kt0 * b_step[i];
 
     auto issue = [&](int kt, int stage) {
         char* sa = smem + stage * STAGE;
         char* sb = sa + A_BYTES;
+        if (SMALLC) {                                            // Cin == 8: one tap per 16-byte chunk
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            int tky = ky, tkx = kx, coff = c0 + a_lch[i] * 8;
-            bool ok = true;
-            if (SMALLC) {                                        // Cin == 8: one tap per 16-byte chunk
-                const int tap = kt * CHUNKS + a_lch[i];
-                ok = tap < p.ntaps;
-                tky = tap / p.KW;
-                tkx = tap - tky * p.KW;
-                coff = 0;
+            for (int i = 0; i < A_IT; ++i) {
+                const int tp = kt * CHUNKS + a_lch[i];
+                const int tky = tp / p.KW, tkx = tp - tky * p.KW;
+                const int iy = a_iy[i] + tky, ix = a_ix[i] + tkx;
+                const bool ok = tp < p.ntaps && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const char* src = ok ? a_ptr[i] + (long)((tky * p.W + tkx) * p.Cin) * 2 : zero;
+                glds16(src, sa + (wave + 4 * i) * 1024);
             }
-            const int iy = a_iy[i] + tky, ix = a_ix[i] + tkx;
-            ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const char* src = ok ? reinterpret_cast<const char*>(p.in + a_base[i] + (tky * p.W + tkx) * p.Cin + coff) : zero;
-            glds16(src, sa + (wave + 4 * i) * 1024);
+        } else {
+            const long koff = (long)((ky * p.W + kx) * p.Cin + c0) * 2;          // wave-uniform byte offset of this K tile
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const char* src = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + koff : zero;
+                glds16(src, sa + (wave + 4 * i) * 1024);
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const char* src = b_ok[i] ? reinterpret_cast<const char*>(p.w + b_off[i] + kt * BKT) : zero;
-            glds16(src, sb + (wave + 4 * i) * 1024);
+            glds16(b_ptr[i], sb + (wave + 4 * i) * 1024);
+            b_ptr[i] += b_step[i];
         }
         if (!SMALLC) {
             c0 += BKT;
             if (c0 >= p.Cin) {
                 c0 = 0;
+                ++tap;
                 if (++kx == p.KW) {
                     kx = 0;
                     ++ky;

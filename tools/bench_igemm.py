@@ -64,11 +64,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--only", type=str, default="", help="substring filter on layer names")
     args = ap.parse_args()
     dev = "cuda"
     tot_ms = tot_fl = 0.0
     print(f"{'layer':28s} {'M':>8s} {'N':>6s} {'K':>6s} {'ms':>8s} {'TFLOP/s':>8s} {'GB/s':>8s} {'MB':>8s}")
     for name, n, h, w, cin, cout, k, stride, pad, res, cin_real in layers(args.batch):
+        if args.only and args.only not in name:
+            continue
         x = torch.randn(n, h, w, cin, device=dev).half()
         wt = torch.randn(cout, cin, k, k) * 0.05
         wp, kpad = ops.pack_conv_weight(wt)
@@ -89,9 +92,12 @@ def main():
         tot_ms += ms * mult
         tot_fl += fl * mult
         print(f"{name:28s} {M:8d} {cout:6d} {k*k*cin:6d} {ms:8.4f} {fl/ms/1e9:8.1f} {by/ms/1e6:8.0f} {by/1e6:8.1f}")
-    print(f"backbone total (weighted): {tot_ms:.3f} ms per {args.batch} frames, {tot_fl/tot_ms/1e9:.1f} TFLOP/s")
+    if tot_ms:
+        print(f"backbone total (weighted): {tot_ms:.3f} ms per {args.batch} frames, {tot_fl/tot_ms/1e9:.1f} TFLOP/s")
     rows = args.batch * 300
     for name, m, k, nout in head_layers(rows):
+        if args.only and args.only not in "head." + name:
+            continue
         x = torch.randn(m, k, device=dev).half()
         wp, kpad = ops.pack_conv_weight(torch.randn(nout, k) * 0.05)
         wp = wp.to(dev)
