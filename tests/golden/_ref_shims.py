@@ -197,6 +197,8 @@ def install():
     detectron2.modeling.Backbone = torch.nn.Module
     import detectron2.modeling.backbone
     detectron2.modeling.backbone.Backbone = torch.nn.Module
+    import detectron2.modeling.backbone.backbone
+    detectron2.modeling.backbone.backbone.Backbone = torch.nn.Module
     import timm.models.layers
     timm.models.layers.DropPath = _DropPath
     timm.models.layers.Mlp = _Mlp

@@ -209,6 +209,33 @@ def g10_sampler():
          parts=np.array(parts, dtype=np.int64))
 
 
+def g8_swin():
+    """SwinTransformer body at a reduced config (embed 16, depths 2-2-2-1): padding to window multiples,
+    shifted windows + mask, odd-size PatchMerging, per-output norms (swintransformer.py:464-648)."""
+    from mega_core.modeling.backbone.swintransformer import SwinTransformer
+    torch.manual_seed(80)
+    m = SwinTransformer(embed_dim=16, depths=[2, 2, 2, 1], num_heads=[1, 2, 4, 8], window_size=7, drop_path_rate=0.0,
+                        out_indices=(1, 2, 3))
+    m.eval()
+    g = torch.Generator().manual_seed(81)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():          # default init (std .02, zero bias, unit norms) hides bugs
+            if "relative_position_bias_table" in name:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.5)
+            elif name.endswith("norm.weight") or ".norm1.weight" in name or ".norm2.weight" in name or name.startswith("norm") and name.endswith("weight"):
+                prm.copy_(torch.rand(prm.shape, generator=g) + 0.5)
+            elif name.endswith("bias"):
+                prm.copy_((torch.rand(prm.shape, generator=g) - 0.5) * 0.4)
+            elif prm.dim() >= 2:
+                fan_in = prm[0].numel()
+                prm.copy_(torch.randn(prm.shape, generator=g) / fan_in ** 0.5)
+    x = torch.randn(2, 3, 102, 158, generator=g)
+    with torch.no_grad():
+        out = m(x)
+    sd = {"sd.backbone.bottom_up." + k: v for k, v in m.state_dict().items() if "relative_position_index" not in k and "attn_mask" not in k}
+    save("g8_swin", x=x, swin1=out["swin1"], swin2=out["swin2"], swin3=out["swin3"], **sd)
+
+
 if __name__ == "__main__":
     # The reference targets torch 1.8 (INSTALL.md:3-13) where nn.MultiheadAttention.forward IS
     # F.multi_head_attention_forward; keep torch 2.x's fused inference fast path out of the goldens.
@@ -221,5 +248,6 @@ if __name__ == "__main__":
     g5_dynamic_head(h)
     g6_noise_transforms()
     g7_greedy_perm()
+    g8_swin()
     g9_structures()
     g10_sampler()

@@ -139,3 +139,14 @@ def test_fps_tie_rule_matches_kernel_emulation():
         old = int(dists_i[0])
         idx.append(old)
     np.testing.assert_array_equal(memory.fps_kernel_order(D, m, bs), np.asarray(idx, np.int32))
+
+
+def test_g8_swin_body():
+    """oracle/swin.py vs the reference SwinTransformer (padding to window multiples, shifted windows with the
+    -100 mask, odd-size PatchMerging, per-output LayerNorm): same torch ops in the same order -> exact."""
+    from oracle import swin
+    z = golden("g8_swin")
+    sd = golden_sd(z)
+    out = swin.swin_body(T(z["x"]), sd, "backbone.bottom_up.", embed_dim=16, depths=(2, 2, 2, 1), num_heads=(1, 2, 4, 8))
+    for k in ("swin1", "swin2", "swin3"):
+        close(out[k], z[k], rtol=1e-6, atol=1e-6)
