@@ -20,6 +20,8 @@ class DvidConfig(C.Structure):
         ("num_classes", c_int), ("num_cls", c_int), ("num_reg", c_int), ("num_heads", c_int),
         ("num_heads_cond", c_int), ("pooler_resolution", c_int), ("sampling_ratio", c_int),
         ("res_blocks", c_int * 4), ("pixel_mean", c_float * 3), ("pixel_std", c_float * 3),
+        ("backbone_type", c_int), ("swin_embed_dim", c_int), ("swin_depths", c_int * 4), ("swin_heads", c_int * 4),
+        ("swin_window", c_int),
     ]
 
 
@@ -33,6 +35,7 @@ SIGNATURES = {
     "dvid_model_finalize": (c_int, [c_void_p]),
     "dvid_workspace_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "dvid_backbone_resnet_fpn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dvid_backbone_swin_fpn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvid_rcnn_head": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                c_void_p, C.POINTER(c_int64), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvid_global_xattn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),

@@ -257,3 +257,153 @@ int dvid_mha_mfma_launch(const half_t* q, const half_t* k, const half_t* v, half
     LAUNCH_CHECK();
     return DVID_OK;
 }
+
+// =============================================================================================
+// Swin (shifted-)window attention, window 7x7 (49 tokens), head_dim 32, MFMA.
+// Replaces WindowAttention.forward + the pad / roll / window_partition / window_reverse plumbing of
+// SwinTransformerBlock.forward (mega_core/modeling/backbone/swintransformer.py:135-176, :236-270):
+// the window <-> token mapping (padding to multiples of 7, cyclic shift by 3) is resolved in the gather
+// addresses, padded positions behave as tokens whose q/k/v equal the qkv bias (the reference pads the
+// normalised activations with zeros BEFORE the qkv Linear), the relative-position bias comes from a
+// per-layer [heads][49][49] fp32 table, and the SW-MSA mask (-100 between different shift regions,
+// swintransformer.py:387-406) is recomputed from the positions' region ids.
+// One workgroup = one (window, head): K and V^T of the 49 keys (padded to 64) are staged in LDS,
+// each of the 4 waves owns 16 queries; same swapped-product / register-resident P scheme as mha_mfma.
+// =============================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void swin_window_attn_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ qkv_bias16,
+                                                                const float* __restrict__ relbias, half_t* __restrict__ out, int H,
+                                                                int W, int C, int nheads, int shift, float scaling) {
+    constexpr int WS = 7, NT = 49;
+    __shared__ __attribute__((aligned(16))) half_t Ks[64 * 32];      // [key][32 dims]
+    __shared__ __attribute__((aligned(16))) half_t Vt[32 * 72];      // [dim][key], pitch 72 halves
+    __shared__ int tok[64];                                          // token row or -1 (padded position)
+    __shared__ int region[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y;
+    const int Hp = (H + WS - 1) / WS * WS, Wp = (W + WS - 1) / WS * WS;
+    const int nwx = Wp / WS, nwy = Hp / WS;
+    int wid = blockIdx.x;
+    const int wx = wid % nwx;
+    wid /= nwx;
+    const int wy = wid % nwy;
+    const int b = wid / nwy;
+
+    if (tid < 64) {
+        int t = -1, reg = 0;
+        if (tid < NT) {
+            const int py = tid / WS, px = tid - py * WS;
+            const int ys = wy * WS + py, xs = wx * WS + px;                  // coordinates in the shifted, padded map
+            int y = ys + shift, x = xs + shift;                              // source coordinates before the roll
+            if (y >= Hp) y -= Hp;
+            if (x >= Wp) x -= Wp;
+            if (y < H && x < W) t = (b * H + y) * W + x;
+            if (shift > 0) {
+                const int hr = ys < Hp - WS ? 0 : (ys < Hp - shift ? 1 : 2);
+                const int wr = xs < Wp - WS ? 0 : (xs < Wp - shift ? 1 : 2);
+                reg = hr * 3 + wr;
+            }
+        }
+        tok[tid] = t;
+        region[tid] = reg;
+    }
+    __syncthreads();
+    // ---- stage K rows and V^T: thread -> (key, 16-byte chunk) ----
+    {
+        const int key = tid >> 2, ch = tid & 3;
+        half8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < NT) {
+            const int t = tok[key];
+            const half_t* src = t >= 0 ? qkv + (long)t * 3 * C : qkv_bias16;
+            kv = *reinterpret_cast<const half8*>(src + C + h * 32 + ch * 8);
+            vv = *reinterpret_cast<const half8*>(src + 2 * C + h * 32 + ch * 8);
+        }
+        *reinterpret_cast<half8*>(Ks + key * 32 + ch * 8) = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * 72 + key] = vv[e];
+    }
+    __syncthreads();
+
+    const int qi = lane & 15, g = lane >> 4;
+    const int qpos = wave * 16 + qi;                                   // query position inside the window (>= 49: idle)
+    const int qp = min(qpos, NT - 1);
+    const int tq = tok[qp];
+    const half_t* qsrc = tq >= 0 ? qkv + (long)tq * 3 * C : qkv_bias16;
+    const half8 qf = *reinterpret_cast<const half8*>(qsrc + h * 32 + g * 8);
+    const float* brow = relbias + ((long)h * NT + qp) * NT;
+    const int qreg = region[qp];
+
+    float4v o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    float m = -1e30f, l = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < 64; k0 += 32) {
+        const half8 kf0 = *reinterpret_cast<const half8*>(Ks + (k0 + qi) * 32 + g * 8);
+        const half8 kf1 = *reinterpret_cast<const half8*>(Ks + (k0 + 16 + qi) * 32 + g * 8);
+        float4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf, s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf, s1, 0, 0, 0);
+        float sc[8];
+        float cmax = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int key = k0 + (r < 4 ? 4 * g + r : 16 + 4 * g + (r - 4));
+            float v = -1e30f;
+            if (key < NT) {
+                v = (r < 4 ? s0[r] : s1[r - 4]) * scaling + brow[key];
+                if (shift > 0 && region[key] != qreg) v += -100.0f;
+            }
+            sc[r] = v;
+            cmax = fmaxf(cmax, v);
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float mn = fmaxf(m, cmax);
+        const float f = __expf(m - mn);
+        float psum = 0.f;
+        half8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float pj = (sc[j] > -1e29f) ? __expf(sc[j] - mn) : 0.f;
+            psum += pj;
+            pf[j] = (half_t)pj;
+        }
+        l = l * f + psum;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0[r] *= f;
+            o1[r] *= f;
+        }
+        const half_t* v0 = Vt + qi * 72 + k0 + 4 * g;
+        const half_t* v1 = v0 + 16 * 72;
+        const half4 a00 = *reinterpret_cast<const half4*>(v0), a01 = *reinterpret_cast<const half4*>(v0 + 16);
+        const half4 a10 = *reinterpret_cast<const half4*>(v1), a11 = *reinterpret_cast<const half4*>(v1 + 16);
+        const half8 vf0 = {a00[0], a00[1], a00[2], a00[3], a01[0], a01[1], a01[2], a01[3]};
+        const half8 vf1 = {a10[0], a10[1], a10[2], a10[3], a11[0], a11[1], a11[2], a11[3]};
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf0, pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1, pf, o1, 0, 0, 0);
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qpos >= NT || tq < 0) return;                                  // padded positions produce no output
+    const float inv = 1.f / l;
+    half_t* op = out + (long)tq * C + h * 32 + 4 * g;
+    const half4 w0 = {(half_t)(o0[0] * inv), (half_t)(o0[1] * inv), (half_t)(o0[2] * inv), (half_t)(o0[3] * inv)};
+    const half4 w1 = {(half_t)(o1[0] * inv), (half_t)(o1[1] * inv), (half_t)(o1[2] * inv), (half_t)(o1[3] * inv)};
+    *reinterpret_cast<half4*>(op) = w0;
+    *reinterpret_cast<half4*>(op + 16) = w1;
+}
+
+}  // namespace
+
+// qkv fp16 [B*H*W, 3C] (q | k | v, head h at columns 32h..), relbias fp32 [nheads][49][49], out fp16 [B*H*W, C]
+int dvid_swin_window_attn_launch(const half_t* qkv, const half_t* qkv_bias16, const float* relbias, half_t* out, int batch, int H,
+                                 int W, int C, int nheads, int shift, hipStream_t s) {
+    if (C != nheads * 32) return DVID_ERR_UNSUPPORTED;
+    const int nwy = (H + 6) / 7, nwx = (W + 6) / 7;
+    hipLaunchKernelGGL(swin_window_attn_kernel, dim3(batch * nwy * nwx, nheads), dim3(256), 0, s, qkv, qkv_bias16, relbias, out, H, W, C,
+                       nheads, shift, 1.0f / sqrtf(32.f));
+    LAUNCH_CHECK();
+    return DVID_OK;
+}

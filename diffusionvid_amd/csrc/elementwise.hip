@@ -146,6 +146,64 @@ __global__ void add_layernorm_kernel(const float* __restrict__ x, const float* _
     }
 }
 
+// Swin PatchMerging front half (swintransformer.py:296-319): gather the 2x2 neighbourhood
+// [x(2i,2j) | x(2i+1,2j) | x(2i,2j+1) | x(2i+1,2j+1)] (zeros beyond an odd H/W), LayerNorm over 4C, fp16 out.
+// One wave per output token; the bias-free reduction Linear(4C -> 2C) that follows is an igemm launch.
+template <int MAXV>
+__global__ void patch_merge_ln_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                      half_t* __restrict__ y16, int B, int H, int W, int C) {
+    const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+    const long tok = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tok >= (long)B * H2 * W2) return;
+    const int lane = threadIdx.x & 63;
+    const int ox = tok % W2;
+    const long t2 = tok / W2;
+    const int oy = t2 % H2;
+    const int img = t2 / H2;
+    const int nv = C;              // float4 vectors in the 4C-wide row
+    const int cv = C >> 2;         // float4 vectors per source token
+    float4v v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = lane + i * 64;
+        v[i] = (float4v){0.f, 0.f, 0.f, 0.f};
+        if (j < nv) {
+            const int part = j / cv, c4 = j - part * cv;
+            const int y = 2 * oy + (part & 1), xx = 2 * ox + (part >> 1);
+            if (y < H && xx < W) v[i] = *reinterpret_cast<const float4v*>(x + (((long)img * H + y) * W + xx) * C + c4 * 4);
+            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const int d = 4 * C;
+    const float mean = wave_sum(sum) / d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = lane + i * 64;
+        if (j < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[i][e] - mean;
+                sq += t * t;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = lane + i * 64;
+        if (j < nv) {
+            const float4v gg = *reinterpret_cast<const float4v*>(g + j * 4);
+            const float4v bb = *reinterpret_cast<const float4v*>(b + j * 4);
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (half_t)((v[i][e] - mean) * rstd * gg[e] + bb[e]);
+            *reinterpret_cast<half4*>(y16 + tok * d + j * 4) = h;
+        }
+    }
+}
+
 __global__ void f32_to_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y, long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
@@ -250,6 +308,15 @@ int dvid_modulate_launch(const float* x, const float* scale, int scale_ld, const
     const long n4 = (long)rows * d / 4;
     hipLaunchKernelGGL(modulate_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, scale, scale_ld, shift, shift_per_row,
                        shift_ld, y16, n4, rows_per_frame, d);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_patch_merge_ln_launch(const float* x, const float* g, const float* b, half_t* y16, int B, int H, int W, int C, hipStream_t s) {
+    if (C % 4 || C > 512) return DVID_ERR_UNSUPPORTED;
+    const long ntok = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+    const int wpb = 4;
+    hipLaunchKernelGGL(patch_merge_ln_kernel<8>, dim3((unsigned)((ntok + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, x, g, b, y16, B, H, W, C);
     LAUNCH_CHECK();
     return DVID_OK;
 }

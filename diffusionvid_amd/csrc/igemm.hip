@@ -280,7 +280,7 @@ int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
     // v2 (direct-to-LDS staging, igemm2.hip) is the product kernel; DVID_IGEMM_V1=1 selects the
     // register-staged round-1 kernel below for A/B measurements.
     static const bool use_v1 = getenv("DVID_IGEMM_V1") != nullptr;
-    if (!use_v1 || p.splitk > 1) return dvid_igemm2_launch(p, s);
+    if (!use_v1 || p.splitk > 1 || p.relu == 2) return dvid_igemm2_launch(p, s);
     if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
     if (p.Kpad % BK != 0 || p.Kpad < BK) return DVID_ERR_ARG;
     const bool smallc = (p.Cin == 8 && p.KH * p.KW > 1);

@@ -11,7 +11,7 @@ struct IgemmParams {
     void* out;           // [M][ldc] fp16 (or fp32 if out_f32)
     int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int M, Kpad, ntaps, ldc, alg_k;
-    int relu, out_f32, res_mode, res_f32;   // res_mode: 0 none, 1 same shape, 2 nearest-x2 upsample
+    int relu, out_f32, res_mode, res_f32;   // relu: 0 none, 1 ReLU, 2 exact GELU; res_mode: 0 none, 1 same shape, 2 nearest-x2 upsample
     int splitk;                             // > 1: K split over `splitk` workgroups per tile, fp32 partials (no bias/relu/residual)
     long split_stride;                      //       written to out + split * split_stride (elements)
     int tiles_m, tiles_n;                   // filled by the launcher
@@ -53,6 +53,10 @@ int dvid_mha_core_launch(const float* q, const float* k, const float* v, float* 
 // MFMA variant: fp16 q/k/v (head h at columns h*32..), fp16 out; vt_scratch >= batch*nheads*32*(round_up(lk,32)+32) halves
 int dvid_mha_mfma_launch(const half_t* q, const half_t* k, const half_t* v, half_t* out, half_t* vt_scratch, int batch, int lq,
                          int lk, int nheads, int q_ld, int kv_ld, int out_ld, long q_bs, long kv_bs, long out_bs, hipStream_t s);
+
+int dvid_swin_window_attn_launch(const half_t* qkv, const half_t* qkv_bias16, const float* relbias, half_t* out, int batch, int H,
+                                 int W, int C, int nheads, int shift, hipStream_t s);
+int dvid_patch_merge_ln_launch(const float* x, const float* g, const float* b, half_t* y16, int B, int H, int W, int C, hipStream_t s);
 
 // dynconv.hip
 int dvid_dynconv_launch(const half_t* roi, const half_t* params, const float* g1, const float* b1, const float* g2,

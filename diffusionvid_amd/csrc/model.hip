@@ -128,6 +128,19 @@ struct Block {
     ConvW c1, c2, c3, sc;
     bool has_sc = false;
 };
+struct SwinBlockW {
+    LNW norm1, norm2;
+    ConvW qkv, proj, fc1, fc2;
+    half_t* qkv_bias16 = nullptr;   // q/k/v of a padded window position = the qkv bias
+    float* relbias = nullptr;       // [heads][49][49] relative-position bias, gathered from the table at load
+};
+struct SwinStageW {
+    std::vector<SwinBlockW> blocks;
+    int dim = 0, heads = 0;
+    bool has_down = false, has_out = false;
+    LNW down_norm, out_norm;
+    ConvW down_red;
+};
 
 half_t f2h(float f) { return (half_t)f; }
 
@@ -144,6 +157,10 @@ struct dvid_model {
     ConvW stem;
     std::vector<Block> blocks[4];
     ConvW lateral[3], output[3];  // index 0 -> level 3
+    // Swin backbone (backbone_type 1)
+    ConvW swin_patch;
+    LNW swin_patch_norm;
+    SwinStageW swin[4];
     // head
     std::vector<HeadW> heads;       // head_series
     std::vector<HeadW> heads_cond;  // head_series_cond
@@ -154,6 +171,7 @@ struct dvid_model {
     // workspace
     int ws_frames = 0, ws_h = 0, ws_w = 0, ws_boxes = 0;
     DevBuf img8, bufX, bufY, bufT1, bufT2, bufSC, c3, c4, c5, lat[3];
+    DevBuf sw_x, sw_x2, sw_ln16, sw_qkv16, sw_attn16, sw_h16;   // Swin token buffers
     DevBuf roi, params, dyn, qkv, attn16, f32a, f32b, f32c, f32d, h16a, h16b, hid16, ss, deltas, kvproj, mem16, splitk, vt;
     std::map<int, std::vector<int64_t>> ss_keys;  // per head slot: t vector of the uploaded scale/shift table
 
@@ -358,6 +376,19 @@ int linear_run(const ConvW& w, const half_t* in, int rows, void* out, int relu, 
     return conv_run(w, in, rows, 1, 1, out, relu, out_f32, nullptr, 0, 0, s);
 }
 
+// detectron2 FPN.forward over three levels (strides 8/16/32): lateral 1x1 (+ nearest-x2 top-down sum fused in the
+// epilogue), 3x3 output conv.  Inputs: m->c3/c4/c5 fp16 NHWC; sh/sw = their heights/widths.
+int run_fpn(dvid_model* m, int n, const int* sh, const int* sw, void* p3, void* p4, void* p5, hipStream_t s) {
+    void* pout[3] = {p3, p4, p5};
+    const half_t* cin[3] = {m->c3.as<half_t>(), m->c4.as<half_t>(), m->c5.as<half_t>()};
+    for (int l = 2; l >= 0; --l) {
+        const void* res = (l < 2) ? m->lat[l + 1].p : nullptr;
+        TRY(conv_run(m->lateral[l], cin[l], n, sh[l], sw[l], m->lat[l].p, 0, 0, res, res ? 2 : 0, 0, s));
+        TRY(conv_run(m->output[l], m->lat[l].as<half_t>(), n, sh[l], sw[l], pout[l], 0, 0, nullptr, 0, 0, s));
+    }
+    return DVID_OK;
+}
+
 float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // box_head.py:218-223 + :734-741 on the host (a handful of distinct t values per config)
@@ -413,7 +444,7 @@ int dvid_model_create(const dvid_config* cfg, dvid_model** out) {
 int dvid_model_destroy(dvid_model* m) {
     if (!m) return DVID_OK;
     for (void* p : m->owned) (void)hipFree(p);
-    DevBuf* bufs[] = {&m->img8, &m->bufX, &m->bufY, &m->bufT1, &m->bufT2, &m->bufSC, &m->c3, &m->c4, &m->c5, &m->lat[0],
+    DevBuf* bufs[] = {&m->img8, &m->bufX, &m->bufY, &m->bufT1, &m->bufT2, &m->bufSC, &m->c3, &m->c4, &m->c5, &m->lat[0], &m->sw_x, &m->sw_x2, &m->sw_ln16, &m->sw_qkv16, &m->sw_attn16, &m->sw_h16,
                       &m->lat[1], &m->lat[2], &m->roi, &m->params, &m->dyn, &m->qkv, &m->attn16, &m->f32a, &m->f32b, &m->f32c,
                       &m->f32d, &m->h16a, &m->h16b, &m->hid16, &m->ss, &m->deltas, &m->kvproj, &m->mem16, &m->splitk, &m->vt};
     for (DevBuf* b : bufs) b->release();
@@ -437,8 +468,8 @@ int dvid_model_finalize(dvid_model* m) {
     if (!m) FAIL(DVID_ERR_ARG, "null model");
     if (m->finalized) return DVID_OK;
     const dvid_config& c = m->cfg;
-    m->has_backbone = c.res_blocks[0] > 0;
-    if (m->has_backbone) {
+    m->has_backbone = c.backbone_type == 1 ? c.swin_depths[0] > 0 : c.res_blocks[0] > 0;
+    if (m->has_backbone && c.backbone_type == 0) {
         const std::string bu = "backbone.bottom_up.";
         TRY(make_conv_bn(m, bu + "stem.conv1", 2, 3, 8, &m->stem));
         for (int s = 0; s < 4; ++s) {
@@ -454,6 +485,59 @@ int dvid_model_finalize(dvid_model* m) {
                 if (blk.has_sc) TRY(make_conv_bn(m, p + ".shortcut", stride, 0, 0, &blk.sc));
             }
         }
+    }
+    if (m->has_backbone && c.backbone_type == 1) {
+        if (c.swin_window != 7) FAIL(DVID_ERR_UNSUPPORTED, "Swin window size %d (only 7 is built)", c.swin_window);
+        const std::string bu = "backbone.bottom_up.";
+        {
+            NEED(pw, bu + "patch_embed.proj.weight");
+            NEED(pb, bu + "patch_embed.proj.bias");
+            if (pw->shape[2] != 4 || pw->shape[3] != 4) FAIL(DVID_ERR_UNSUPPORTED, "patch size must be 4");
+            TRY(make_conv(m, *pw, {}, pb->v, 4, 0, 8, nullptr, &m->swin_patch));
+            TRY(make_ln(m, bu + "patch_embed.norm", &m->swin_patch_norm));
+        }
+        // relative position index of a 7x7 window (swintransformer.py:122-131)
+        int relidx[49][49];
+        for (int i = 0; i < 49; ++i)
+            for (int j = 0; j < 49; ++j) relidx[i][j] = ((i / 7 - j / 7) + 6) * 13 + ((i % 7 - j % 7) + 6);
+        for (int st = 0; st < 4; ++st) {
+            SwinStageW& S = m->swin[st];
+            S.dim = c.swin_embed_dim << st;
+            S.heads = c.swin_heads[st];
+            if (S.dim != S.heads * 32) FAIL(DVID_ERR_UNSUPPORTED, "Swin stage %d: head dim %d != 32", st, S.dim / S.heads);
+            S.blocks.resize(c.swin_depths[st]);
+            for (int b = 0; b < c.swin_depths[st]; ++b) {
+                const std::string p = bu + "layers." + std::to_string(st) + ".blocks." + std::to_string(b);
+                SwinBlockW& B = S.blocks[b];
+                TRY(make_ln(m, p + ".norm1", &B.norm1));
+                TRY(make_ln(m, p + ".norm2", &B.norm2));
+                TRY(make_linear(m, p + ".attn.qkv", true, &B.qkv));
+                TRY(make_linear(m, p + ".attn.proj", true, &B.proj));
+                TRY(make_linear(m, p + ".mlp.fc1", true, &B.fc1));
+                TRY(make_linear(m, p + ".mlp.fc2", true, &B.fc2));
+                NEED(qb, p + ".attn.qkv.bias");
+                std::vector<half_t> qb16(qb->v.size());
+                for (size_t i = 0; i < qb16.size(); ++i) qb16[i] = f2h(qb->v[i]);
+                TRY(m->upload(qb16.data(), qb16.size() * sizeof(half_t), reinterpret_cast<void**>(&B.qkv_bias16)));
+                NEED(tb, p + ".attn.relative_position_bias_table");
+                if (tb->shape[0] != 169 || tb->shape[1] != S.heads) FAIL(DVID_ERR_ARG, "%s: bad bias table shape", p.c_str());
+                std::vector<float> rb((size_t)S.heads * 49 * 49);
+                for (int h = 0; h < S.heads; ++h)
+                    for (int i = 0; i < 49; ++i)
+                        for (int j = 0; j < 49; ++j) rb[((size_t)h * 49 + i) * 49 + j] = tb->v[(size_t)relidx[i][j] * S.heads + h];
+                TRY(upload_f32(m, rb, &B.relbias));
+            }
+            S.has_down = st < 3;
+            if (S.has_down) {
+                const std::string p = bu + "layers." + std::to_string(st) + ".downsample";
+                TRY(make_ln(m, p + ".norm", &S.down_norm));
+                TRY(make_linear(m, p + ".reduction", false, &S.down_red));
+            }
+            S.has_out = st >= 1;                       // out_indices (1, 2, 3)
+            if (S.has_out) TRY(make_ln(m, bu + "norm" + std::to_string(st), &S.out_norm));
+        }
+    }
+    if (m->has_backbone) {
         for (int l = 0; l < 3; ++l) {
             const std::string lat = "backbone.fpn_lateral" + std::to_string(l + 3);
             const std::string outn = "backbone.fpn_output" + std::to_string(l + 3);
@@ -497,7 +581,21 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
     if (height % 32 || width % 32) FAIL(DVID_ERR_ARG, "height/width must be multiples of 32 (got %dx%d)", height, width);
     const size_t n = max_frames;
     const size_t px4 = (size_t)(height / 4) * (width / 4);
-    if (m->has_backbone) {
+    if (m->has_backbone && m->cfg.backbone_type == 1) {
+        const size_t C0 = m->cfg.swin_embed_dim, M0 = n * px4;      // stage-0 tokens; M*C halves per stage
+        TRY(m->img8.ensure(n * height * width * 8 * 2));
+        TRY(m->sw_x.ensure(M0 * C0 * 4));
+        TRY(m->sw_x2.ensure(M0 * C0 * 4 / 2));
+        TRY(m->sw_ln16.ensure(M0 * C0 * 2));
+        TRY(m->sw_qkv16.ensure(M0 * C0 * 3 * 2));
+        TRY(m->sw_attn16.ensure(M0 * C0 * 2));
+        TRY(m->sw_h16.ensure(M0 * C0 * 4 * 2));
+        TRY(m->c3.ensure(n * (px4 / 4) * (C0 * 2) * 2));
+        TRY(m->c4.ensure(n * (px4 / 16) * (C0 * 4) * 2));
+        TRY(m->c5.ensure(n * (px4 / 64) * (C0 * 8) * 2));
+        for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2));
+    }
+    if (m->has_backbone && m->cfg.backbone_type == 0) {
         TRY(m->img8.ensure(n * height * width * 8 * 2));
         const size_t big = n * px4 * 256 * 2;  // largest activation: res2 output (also >= stem output)
         TRY(m->bufX.ensure(big));
@@ -538,7 +636,8 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
 int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
                              void* stream) {
     g_err[0] = 0;
-    if (!m || !m->finalized || !m->has_backbone) FAIL(DVID_ERR_STATE, "model not finalized or built without a backbone");
+    if (!m || !m->finalized || !m->has_backbone || m->cfg.backbone_type != 0)
+        FAIL(DVID_ERR_STATE, "model not finalized or built without a ResNet backbone");
     if (n > m->ws_frames || height != m->ws_h || width != m->ws_w)
         FAIL(DVID_ERR_STATE, "workspace reserved for %d frames of %dx%d, got %d of %dx%d", m->ws_frames, m->ws_h, m->ws_w, n,
              height, width);
@@ -581,15 +680,63 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
         sh[st] = h;
         sw[st] = w;
     }
-    // FPN (detectron2 FPN.forward): top-down from res5
-    void* pout[3] = {p3, p4, p5};
-    const half_t* cin[3] = {m->c3.as<half_t>(), m->c4.as<half_t>(), m->c5.as<half_t>()};
-    for (int l = 2; l >= 0; --l) {
-        const void* res = (l < 2) ? m->lat[l + 1].p : nullptr;
-        TRY(conv_run(m->lateral[l], cin[l], n, sh[l + 1], sw[l + 1], m->lat[l].p, 0, 0, res, res ? 2 : 0, 0, s));
-        TRY(conv_run(m->output[l], m->lat[l].as<half_t>(), n, sh[l + 1], sw[l + 1], pout[l], 0, 0, nullptr, 0, 0, s));
+    return run_fpn(m, n, sh + 1, sw + 1, p3, p4, p5, s);
+}
+
+int dvid_backbone_swin_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
+                           void* stream) {
+    g_err[0] = 0;
+    if (!m || !m->finalized || !m->has_backbone || m->cfg.backbone_type != 1) FAIL(DVID_ERR_STATE, "model has no Swin backbone");
+    if (n > m->ws_frames || height != m->ws_h || width != m->ws_w)
+        FAIL(DVID_ERR_STATE, "workspace reserved for %d frames of %dx%d, got %d of %dx%d", m->ws_frames, m->ws_h, m->ws_w, n,
+             height, width);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float mean[3], inv_std[3];
+    for (int i = 0; i < 3; ++i) {
+        mean[i] = m->cfg.pixel_mean[i] / 255.f;
+        inv_std[i] = 1.f / (m->cfg.pixel_std[i] / 255.f);
     }
-    return DVID_OK;
+    TRY(dvid_prep_images_launch(images, m->img8.as<half_t>(), n, height, width, mean, inv_std, s));
+    // patch embedding: 4x4/4 conv (implicit GEMM on NHWC8) -> fp32 tokens -> LayerNorm  (swintransformer.py:441-458)
+    int H = height, W = width;
+    float* x = m->sw_x.as<float>();
+    float* x2 = m->sw_x2.as<float>();
+    TRY(conv_run(m->swin_patch, m->img8.as<half_t>(), n, H, W, x, 0, 1, nullptr, 0, 0, s, &H, &W));
+    TRY(dvid_add_layernorm_launch(x, nullptr, m->swin_patch_norm.g, m->swin_patch_norm.b, x, nullptr, n * H * W, m->swin[0].dim, 0, s));
+    half_t* ln16 = m->sw_ln16.as<half_t>();
+    half_t* qkv16 = m->sw_qkv16.as<half_t>();
+    half_t* attn16 = m->sw_attn16.as<half_t>();
+    half_t* h16 = m->sw_h16.as<half_t>();
+    half_t* stage_out[4] = {nullptr, m->c3.as<half_t>(), m->c4.as<half_t>(), m->c5.as<half_t>()};
+    int sh[4], sw[4];
+    for (int st = 0; st < 4; ++st) {
+        const SwinStageW& S = m->swin[st];
+        const int C = S.dim, M = n * H * W;
+        for (size_t b = 0; b < S.blocks.size(); ++b) {
+            const SwinBlockW& B = S.blocks[b];
+            const int shift = (b % 2 == 0) ? 0 : 3;                                             // window_size // 2
+            TRY(dvid_add_layernorm_launch(x, nullptr, B.norm1.g, B.norm1.b, nullptr, ln16, M, C, 0, s));
+            TRY(linear_run(B.qkv, ln16, M, qkv16, 0, 0, s));
+            TRY(dvid_swin_window_attn_launch(qkv16, B.qkv_bias16, B.relbias, attn16, n, H, W, C, S.heads, shift, s));
+            TRY(conv_run(B.proj, attn16, M, 1, 1, x, 0, 1, x, 1, 1, s));                         // x += proj(attn)   (fp32 stream)
+            TRY(dvid_add_layernorm_launch(x, nullptr, B.norm2.g, B.norm2.b, nullptr, ln16, M, C, 0, s));
+            TRY(linear_run(B.fc1, ln16, M, h16, 2, 0, s));                                       // GELU epilogue
+            TRY(conv_run(B.fc2, h16, M, 1, 1, x, 0, 1, x, 1, 1, s));                             // x += fc2(...)
+        }
+        sh[st] = H;
+        sw[st] = W;
+        if (S.has_out) TRY(dvid_add_layernorm_launch(x, nullptr, S.out_norm.g, S.out_norm.b, nullptr, stage_out[st], M, C, 0, s));
+        if (S.has_down) {
+            TRY(dvid_patch_merge_ln_launch(x, S.down_norm.g, S.down_norm.b, h16, n, H, W, C, s));
+            H = (H + 1) / 2;
+            W = (W + 1) / 2;
+            TRY(linear_run(S.down_red, h16, n * H * W, x2, 0, 1, s));
+            float* t = x;
+            x = x2;
+            x2 = t;
+        }
+    }
+    return run_fpn(m, n, sh + 1, sw + 1, p3, p4, p5, s);
 }
 
 int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, const void* p4, const void* p5, int n_frames,

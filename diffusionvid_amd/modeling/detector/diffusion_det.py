@@ -25,6 +25,14 @@ from ...utils import synthetic
 from ..roi_heads.box_head.box_head import DynamicHead
 
 _DEPTH_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+# size2config of mega_core/modeling/backbone/swintransformer.py:655-712 (window-7 variants; head dim 32 in all of them)
+_SWIN_SIZES = {
+    "T": dict(embed_dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), window=7),
+    "S": dict(embed_dim=96, depths=(2, 2, 18, 2), heads=(3, 6, 12, 24), window=7),
+    "B": dict(embed_dim=128, depths=(2, 2, 18, 2), heads=(4, 8, 16, 32), window=7),
+    "B-22k": dict(embed_dim=128, depths=(2, 2, 18, 2), heads=(4, 8, 16, 32), window=7),
+    "L-22k": dict(embed_dim=192, depths=(2, 2, 18, 2), heads=(6, 12, 24, 48), window=7),
+}
 
 
 def cosine_beta_schedule(timesteps, s=0.008):
@@ -70,11 +78,20 @@ class DiffusionDet(nn.Module):
         self.size_divisibility = 32
         if list(self.in_features) != ["p3", "p4", "p5"]:
             raise NotImplementedError("ROI_HEADS.IN_FEATURES must be [p3, p4, p5] (configs/vid_*_DiffusionVID.yaml)")
-        if cfg.MODEL.BACKBONE.NAME != "build_resnet_fpn_backbone":
-            raise NotImplementedError("backbone '%s' is not built yet (ResNet-FPN only this round)" % cfg.MODEL.BACKBONE.NAME)
-        if cfg.MODEL.RESNETS.DEPTH not in _DEPTH_BLOCKS or cfg.MODEL.RESNETS.STRIDE_IN_1X1:
-            raise NotImplementedError("ResNet depth %s / STRIDE_IN_1X1 unsupported" % cfg.MODEL.RESNETS.DEPTH)
-        self.res_blocks = getattr(cfg.MODEL.RESNETS, "BLOCKS_OVERRIDE", None) or _DEPTH_BLOCKS[cfg.MODEL.RESNETS.DEPTH]
+        self.swin = None
+        if cfg.MODEL.BACKBONE.NAME == "build_swintransformer_fpn_backbone":
+            if cfg.MODEL.SWIN.SIZE not in _SWIN_SIZES:
+                raise NotImplementedError("Swin size %r is not built (window-7 sizes only)" % cfg.MODEL.SWIN.SIZE)
+            if tuple(cfg.MODEL.SWIN.OUT_FEATURES) != (1, 2, 3):
+                raise NotImplementedError("MODEL.SWIN.OUT_FEATURES must be (1, 2, 3)")
+            self.swin = dict(getattr(cfg.MODEL.SWIN, "CONFIG_OVERRIDE", None) or _SWIN_SIZES[cfg.MODEL.SWIN.SIZE])
+            self.res_blocks = (0, 0, 0, 0)
+        elif cfg.MODEL.BACKBONE.NAME == "build_resnet_fpn_backbone":
+            if cfg.MODEL.RESNETS.DEPTH not in _DEPTH_BLOCKS or cfg.MODEL.RESNETS.STRIDE_IN_1X1:
+                raise NotImplementedError("ResNet depth %s / STRIDE_IN_1X1 unsupported" % cfg.MODEL.RESNETS.DEPTH)
+            self.res_blocks = getattr(cfg.MODEL.RESNETS, "BLOCKS_OVERRIDE", None) or _DEPTH_BLOCKS[cfg.MODEL.RESNETS.DEPTH]
+        else:
+            raise NotImplementedError("backbone '%s' is not built" % cfg.MODEL.BACKBONE.NAME)
 
         # diffusion constants (diffusion_det.py:222-267); registered so checkpoints load unchanged
         timesteps = 1000
@@ -109,7 +126,7 @@ class DiffusionDet(nn.Module):
 
         # parameters under the reference's names; seeded random init (the reference also starts from
         # random init before DetectronCheckpointer.load)
-        sd = synthetic.make_state_dict(0, blocks=self.res_blocks, hidden=d.HIDDEN_DIM, nheads=d.NHEADS,
+        sd = synthetic.make_state_dict(0, blocks=self.res_blocks, swin=self.swin, hidden=d.HIDDEN_DIM, nheads=d.NHEADS,
                                        dim_ff=d.DIM_FEEDFORWARD, dim_dynamic=d.DIM_DYNAMIC, num_classes=d.NUM_CLASSES,
                                        num_cls=d.NUM_CLS, num_reg=d.NUM_REG, num_heads=d.NUM_HEADS,
                                        num_heads_cond=d.NUM_HEADS_LOCAL, pooler=cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION,
@@ -138,7 +155,10 @@ class DiffusionDet(nn.Module):
                 num_classes=d.NUM_CLASSES, num_cls=d.NUM_CLS, num_reg=d.NUM_REG, num_heads=d.NUM_HEADS,
                 num_heads_cond=d.NUM_HEADS_LOCAL, pooler_resolution=self.cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION,
                 sampling_ratio=self.cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO, res_blocks=tuple(self.res_blocks),
-                pixel_mean=tuple(self.cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(self.cfg.MODEL.PIXEL_STD))
+                pixel_mean=tuple(self.cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(self.cfg.MODEL.PIXEL_STD),
+                **({} if self.swin is None else dict(backbone="swin", swin_embed_dim=self.swin["embed_dim"],
+                                                      swin_depths=tuple(self.swin["depths"]), swin_heads=tuple(self.swin["heads"]),
+                                                      swin_window=self.swin["window"])))
         return self._engine
 
     def load_state_dict(self, state_dict, strict=True):

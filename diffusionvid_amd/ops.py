@@ -225,19 +225,23 @@ class Model:
 
     def __init__(self, state_dict, *, hidden_dim=256, nheads=8, dim_feedforward=2048, dim_dynamic=64, num_classes=30,
                  num_cls=1, num_reg=3, num_heads=3, num_heads_cond=1, pooler_resolution=7, sampling_ratio=2,
-                 res_blocks=(3, 4, 23, 3), pixel_mean=(123.675, 116.280, 103.530), pixel_std=(58.395, 57.120, 57.375)):
+                 res_blocks=(3, 4, 23, 3), pixel_mean=(123.675, 116.280, 103.530), pixel_std=(58.395, 57.120, 57.375),
+                 backbone="resnet", swin_embed_dim=128, swin_depths=(2, 2, 18, 2), swin_heads=(4, 8, 16, 32), swin_window=7):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.DvidError("no HIP device visible: the DiffusionVID hot path runs only on the GPU (no CPU fallback)")
         cfg = _lib.DvidConfig(hidden_dim, nheads, dim_feedforward, dim_dynamic, num_classes, num_cls, num_reg, num_heads,
                               num_heads_cond, pooler_resolution, sampling_ratio, (C.c_int * 4)(*res_blocks),
-                              (C.c_float * 3)(*pixel_mean), (C.c_float * 3)(*pixel_std))
+                              (C.c_float * 3)(*pixel_mean), (C.c_float * 3)(*pixel_std),
+                              1 if backbone == "swin" else 0, swin_embed_dim, (C.c_int * 4)(*swin_depths),
+                              (C.c_int * 4)(*swin_heads), swin_window)
+        self.backbone_kind = backbone
         self.cfg = cfg
         h = C.c_void_p()
         _lib.check(lib.dvid_model_create(C.byref(cfg), C.byref(h)), "dvid_model_create")
         self.handle = h
         self.hidden_dim, self.num_classes, self.nheads = hidden_dim, num_classes, nheads
-        self.has_backbone = res_blocks[0] > 0
+        self.has_backbone = (swin_depths[0] > 0) if backbone == "swin" else (res_blocks[0] > 0)
         wanted = ("head.", "backbone.") if self.has_backbone else ("head.",)
         for name, t in state_dict.items():
             if not name.startswith(wanted) or not torch.is_floating_point(t):
@@ -260,7 +264,8 @@ class Model:
         n, _, h, w = images.shape
         dev = images.device
         outs = [torch.empty((n, h >> s, w >> s, self.hidden_dim), dtype=torch.float16, device=dev) for s in (3, 4, 5)]
-        call("dvid_backbone_resnet_fpn", self.handle, ptr(images), n, h, w, ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream_ptr())
+        fn = "dvid_backbone_swin_fpn" if self.backbone_kind == "swin" else "dvid_backbone_resnet_fpn"
+        call(fn, self.handle, ptr(images), n, h, w, ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream_ptr())
         return outs
 
     def rcnn_head(self, head_index, feats_nhwc, height, width, boxes, pro_features, t, cond=None, bad_flag=None):

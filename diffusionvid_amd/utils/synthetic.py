@@ -113,9 +113,56 @@ def make_backbone_state_dict(seed=1, blocks=(3, 4, 23, 3), out_channels=256, pre
     return sd
 
 
-def make_state_dict(seed=0, blocks=(3, 4, 23, 3), **head_kw):
+def make_swin_state_dict(seed=1, embed_dim=128, depths=(2, 2, 18, 2), heads=(4, 8, 16, 32), window=7, out_channels=256,
+                         prefix="backbone."):
+    """Swin-Transformer + FPN parameters under the reference's names (swintransformer.py modules wrapped by
+    detectron2's FPN as `backbone.bottom_up.*`).  Values are O(1)-preserving random (not the std-0.02 default)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    bu = prefix + "bottom_up."
+
+    def lin(name, o, i, bias=True):
+        sd[name + ".weight"] = torch.randn(o, i, generator=g) / math.sqrt(i)
+        if bias:
+            sd[name + ".bias"] = (torch.rand(o, generator=g) * 2 - 1) * 0.2
+
+    sd[bu + "patch_embed.proj.weight"] = torch.randn(embed_dim, 3, 4, 4, generator=g) / math.sqrt(48)
+    sd[bu + "patch_embed.proj.bias"] = (torch.rand(embed_dim, generator=g) * 2 - 1) * 0.2
+    _ln(g, sd, bu + "patch_embed.norm", embed_dim)
+    for i, depth in enumerate(depths):
+        C = embed_dim << i
+        for j in range(depth):
+            p = f"{bu}layers.{i}.blocks.{j}"
+            _ln(g, sd, p + ".norm1", C)
+            _ln(g, sd, p + ".norm2", C)
+            lin(p + ".attn.qkv", 3 * C, C)
+            lin(p + ".attn.proj", C, C)
+            sd[p + ".attn.proj.weight"] *= 0.5            # keep the residual stream from exploding over 24 blocks
+            sd[p + ".attn.relative_position_bias_table"] = torch.randn((2 * window - 1) ** 2, heads[i], generator=g) * 0.5
+            lin(p + ".mlp.fc1", 4 * C, C)
+            lin(p + ".mlp.fc2", C, 4 * C)
+            sd[p + ".mlp.fc2.weight"] *= 0.5
+        if i < len(depths) - 1:
+            _ln(g, sd, f"{bu}layers.{i}.downsample.norm", 4 * C)
+            lin(f"{bu}layers.{i}.downsample.reduction", 2 * C, 4 * C, bias=False)
+        if i >= 1:
+            _ln(g, sd, f"{bu}norm{i}", C)
+    for lvl, i in zip((3, 4, 5), (1, 2, 3)):
+        c = embed_dim << i
+        sd[f"{prefix}fpn_lateral{lvl}.weight"] = (torch.rand(out_channels, c, 1, 1, generator=g) * 2 - 1) * math.sqrt(3.0 / c)
+        sd[f"{prefix}fpn_lateral{lvl}.bias"] = (torch.rand(out_channels, generator=g) * 2 - 1) * 0.05
+        fan = out_channels * 9
+        sd[f"{prefix}fpn_output{lvl}.weight"] = (torch.rand(out_channels, out_channels, 3, 3, generator=g) * 2 - 1) * math.sqrt(3.0 / fan)
+        sd[f"{prefix}fpn_output{lvl}.bias"] = (torch.rand(out_channels, generator=g) * 2 - 1) * 0.05
+    return sd
+
+
+def make_state_dict(seed=0, blocks=(3, 4, 23, 3), swin=None, **head_kw):
     sd = make_head_state_dict(seed, **head_kw)
-    sd.update(make_backbone_state_dict(seed + 1, blocks))
+    if swin is not None:
+        sd.update(make_swin_state_dict(seed + 1, **swin))
+    else:
+        sd.update(make_backbone_state_dict(seed + 1, blocks))
     return sd
 
 

@@ -10,6 +10,7 @@
  * Reference interfaces replaced (paths relative to the reference repo root):
  *   dvid_backbone_resnet_fpn   detectron2 build_resnet_fpn_backbone called at
  *                              mega_core/modeling/detector/diffusion_det.py:219,:427 (+ normalizer :301-303,:422)
+ *   dvid_backbone_swin_fpn     build_swintransformer_fpn_backbone, mega_core/modeling/backbone/swintransformer.py:464-751
  *   dvid_rcnn_head             RCNNHead.forward / RCNNHead_cond.forward, DynamicConv.forward, apply_deltas
  *                              mega_core/modeling/roi_heads/box_head/box_head.py:495-548, :605-664, :687-711, :550-590
  *   dvid_roialign_v2_multilevel detectron2 ROIPooler(ROIAlignV2) built at box_head.py:250-271, called :507,:617
@@ -59,6 +60,11 @@ typedef struct dvid_config {
     int res_blocks[4];     /* bottleneck blocks per stage, {3,4,23,3} for R-101; all 0 = no backbone */
     float pixel_mean[3];   /* MODEL.PIXEL_MEAN (0..255 scale) */
     float pixel_std[3];
+    int backbone_type;     /* 0: ResNet-FPN (res_blocks), 1: Swin-FPN (swin_*), MODEL.BACKBONE.NAME */
+    int swin_embed_dim;    /* size2config[MODEL.SWIN.SIZE]: 128 for B */
+    int swin_depths[4];    /* {2,2,18,2} */
+    int swin_heads[4];     /* {4,8,16,32}; head dim must be 32 */
+    int swin_window;       /* 7 */
 } dvid_config;
 
 const char* dvid_last_error(void);
@@ -82,6 +88,11 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
  * p3 [n,h/8,w/8,256], p4 [n,h/16,w/16,256], p5 [n,h/32,w/32,256]. */
 int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
                              void* stream);
+
+/* Swin-Transformer + FPN (mega_core/modeling/backbone/swintransformer.py:464-751, out_indices (1,2,3)); same
+ * inputs/outputs as dvid_backbone_resnet_fpn. */
+int dvid_backbone_swin_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
+                           void* stream);
 
 /* One RCNNHead (cond == NULL) or RCNNHead_cond pass.  head_index indexes head_series, or
  * head_series_cond when is_cond.  t: host int64 [n_frames] diffusion timesteps.

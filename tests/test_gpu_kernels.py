@@ -348,3 +348,25 @@ def test_backbone_small(dv):
         # fp16 activations + fp16 folded-BN weights through ~20 conv layers
         check(f"backbone_small.{name}", dv.nchw_from_nhwc(got), ref[name], 3e-2, 3e-2)
     model.close()
+
+
+def test_backbone_swin_small(dv):
+    """Swin-Transformer + FPN (same kernels/graph as Swin-B, reduced widths/depths) vs the CPU oracle:
+    patch embed, (shifted-)window MFMA attention with padding + relative-position bias + shift mask,
+    GELU MLP, fp32 residual stream, odd-size PatchMerging, per-output LayerNorm, FPN."""
+    from diffusionvid_amd.utils import synthetic
+    from oracle import swin as oswin
+    sw = dict(embed_dim=64, depths=(2, 2, 2, 1), heads=(2, 4, 8, 16), window=7)
+    sd = synthetic.make_state_dict(0, swin=sw)
+    g = torch.Generator().manual_seed(15)
+    imgs = torch.rand(2, 3, 160, 224, generator=g)        # tokens 40x56 -> 20x28 -> 10x14 -> 5x7 (pads to 42x56, 21x28, 14x14, 7x7)
+    mean, std = (123.675, 116.280, 103.530), (58.395, 57.120, 57.375)
+    ref = oswin.backbone_swin_fpn(backbone_r101.normalizer(imgs, mean, std), sd, "backbone.", embed_dim=64, depths=sw["depths"],
+                                  num_heads=sw["heads"])
+    model = dv.Model(sd, res_blocks=(0, 0, 0, 0), backbone="swin", swin_embed_dim=64, swin_depths=sw["depths"],
+                     swin_heads=sw["heads"])
+    model.reserve(2, 160, 224, 300)
+    p3, p4, p5 = model.backbone(imgs.cuda())
+    for name, got in (("p3", p3), ("p4", p4), ("p5", p5)):
+        check(f"backbone_swin_small.{name}", dv.nchw_from_nhwc(got), ref[name], 3e-2, 3e-2)
+    model.close()
