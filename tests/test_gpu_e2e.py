@@ -188,3 +188,43 @@ def test_non_batch_calls_return_empty_and_errors():
     assert [len(o) for o in outs] == [8, 0, 0, 0, 0, 0, 0, 0, 4, 0, 0, 0]     # tail batch: end_id - frame_id + 1 = 4
     with pytest.raises(ValueError):
         model(ds[0][0], targets=[None])
+
+
+def test_video_e2e_swin():
+    """Swin-FPN DiffusionVID x1 (configs/vid_Swin_B_DiffusionVID.yaml: INFER_BATCH 4, ALL_FRAME_INTERVAL 4) at reduced
+    Swin widths/depths: extraction pass, memory and detections vs the CPU oracle, same staging/tolerances as above."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    from oracle import swin as oswin
+    sw = dict(embed_dim=64, depths=(2, 2, 2, 1), heads=(2, 4, 8, 16), window=7)
+    cfg = get_cfg("configs/vid_Swin_B_DiffusionVID.yaml", None, "configs/BASE_RCNN_1gpu.yaml")
+    cfg.MODEL.SWIN.CONFIG_OVERRIDE = sw
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+    model = model.to("cuda").eval()
+    L, H0, W0 = 4, 250, 380
+    ds = SyntheticVIDDataset([L], cfg, height=H0, width=W0, device="cuda", smooth=True)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ocfg = odet.DetCfg(infer_batch=4, all_frame_interval=4)
+    oracle = odet.OracleDiffusionDet(sd, ocfg, synthetic.noise_fn,
+                                     backbone_fn=lambda x: oswin.backbone_swin_fpn(x, sd, "backbone.", embed_dim=64,
+                                                                                   depths=sw["depths"], num_heads=sw["heads"]))
+    model.noise_fn = synthetic.noise_fn
+    model.debug_taps = {}
+    images, oitem, ids = _oracle_items(ds, 0)
+    with torch.no_grad():
+        ref_out = oracle.forward(oitem)
+        got_out = model(images)
+    assert len(got_out) == len(ref_out) == L and ids == [0, 1, 2, 3]
+    ocl, obx, opf = oracle.taps["extract"]
+    gcl = torch.cat([e[0] for e in model.debug_taps["extract"]]).cpu()
+    gbx = torch.cat([e[1] for e in model.debug_taps["extract"]]).cpu()
+    gpf = torch.cat([e[2] for e in model.debug_taps["extract"]]).cpu().view(-1, 300, 256)
+    assert gcl.shape[0] == 28                                   # 4 local + 24 global frames in 7 splits of 4
+    _stage_check("[swin x1] extraction", gpf, opf, gcl, ocl, gbx, obx)
+    rates = [_match_rate(r, g) for r, g in zip(ref_out, got_out)]
+    print(f"[swin x1] detections kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]}; match {rates}")
+    assert min(rates) >= 0.9
