@@ -46,14 +46,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 // NSTAGE 3: ring of three stages, two DMA tiles in flight across a raw `s_barrier`; each wave waits with a
 //           COUNTED `s_waitcnt vmcnt(P)` (P = its DMA pieces per tile) so only the tile about to be read has
 //           landed, and re-fills the stage freed by the previous step right after the barrier.
-template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC>
-__global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
+// WN: waves along N (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads); always 2 waves along M.
+template <int BM, int BN, int BKT, int NSTAGE, int WN, bool SMALLC>
+__global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
+    constexpr int NW = 2 * WN;                      // waves per workgroup
+    constexpr int NT = 64 * NW;                     // threads
     constexpr int ROW_BYTES = BKT * 2;
     constexpr int CHUNKS = BKT / 8;                 // 16-byte chunks per row
     constexpr int RPP = 1024 / ROW_BYTES;           // tile rows per 1-KiB DMA piece
     constexpr int KEY_SHIFT = (BKT == 64) ? 1 : 2;  // swizzle key = (row >> KEY_SHIFT) & (CHUNKS - 1)
-    constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves 2x2)
-    constexpr int A_IT = BM / RPP / 4, B_IT = BN / RPP / 4;   // DMA pieces per wave per K tile
+    constexpr int TM = BM / 64, TN = BN / (32 * WN);   // 32x32 MFMA tiles per wave (waves 2 x WN)
+    constexpr int A_IT = BM / RPP / NW, B_IT = BN / RPP / NW;   // DMA pieces per wave per K tile
+    static_assert(A_IT >= 1 && B_IT >= 1 && A_IT * RPP * NW == BM && B_IT * RPP * NW == BN, "tile / wave-count mismatch");
     constexpr int A_BYTES = BM * ROW_BYTES;
     constexpr int STAGE = Smem2<BM, BN, BKT, NSTAGE>::kStage;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int split = p.splitk > 1 ? (int)blockIdx.x / ntiles : 0;       // wave-uniform
     const int lid = igemm_xcd_remap((int)blockIdx.x - split * ntiles, ntiles);
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
     int a_iy[A_IT], a_ix[A_IT], a_lch[A_IT];       // only used by the SMALLC (stem) path
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int row = RPP * (wave + 4 * i) + lrow;
+        const int row = RPP * (wave + NW * i) + lrow;
         a_lch[i] = pch ^ ((row >> KEY_SHIFT) & (CHUNKS - 1));   // logical chunk stored at this position
         const int m = m0 + row;
         a_mask[i] = 0u;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
     int b_step[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int row = RPP * (wave + 4 * i) + lrow;
+        const int row = RPP * (wave + NW * i) + lrow;
         const int n = n0 + row;
         const bool ok = n < p.Cout;
         b_ptr[i] = ok ? reinterpret_cast<const char*>(p.w + (long)n * p.Kpad + (pch ^ ((row >> KEY_SHIFT) & (CHUNKS - 1))) * 8) : zero;
@@ -119,7 +123,11 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
     // K range of this workgroup (split-K) and the filter-tap walk of the K loop (wave-uniform): k0 = tap*Cin + c0
     const int nk_all = p.Kpad / BKT;
     const int nk = p.splitk > 1 ? nk_all / p.splitk : nk_all;
-    const int kt0 = split * nk;
+    // K rotation (p.krot): every tile starts its K walk at a different K tile and wraps, so that the workgroups of
+    // a launch do not all pull the same weight lines from L2 at the same moment (the sum is order-independent).
+    const int rot = (p.krot && !SMALLC && p.splitk <= 1) ? (tile_m * 5 + tile_n * 3) % nk : 0;
+    const int kt0 = split * nk + rot;
+    int kpos = rot;
     int ky = 0, kx = 0, c0 = 0, tap = 0;
     if (!SMALLC && kt0) {
         tap = (kt0 * BKT) / p.Cin;
@@ -141,19 +149,19 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
                 const int iy = a_iy[i] + tky, ix = a_ix[i] + tkx;
                 const bool ok = tp < p.ntaps && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const char* src = ok ? a_ptr[i] + (long)((tky * p.W + tkx) * p.Cin) * 2 : zero;
-                glds16(src, sa + (wave + 4 * i) * 1024);
+                glds16(src, sa + (wave + NW * i) * 1024);
             }
         } else {
             const long koff = (long)((ky * p.W + kx) * p.Cin + c0) * 2;          // wave-uniform byte offset of this K tile
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const char* src = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + koff : zero;
-                glds16(src, sa + (wave + 4 * i) * 1024);
+                glds16(src, sa + (wave + NW * i) * 1024);
             }
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            glds16(b_ptr[i], sb + (wave + 4 * i) * 1024);
+            glds16(b_ptr[i], sb + (wave + NW * i) * 1024);
             b_ptr[i] += b_step[i];
         }
         if (!SMALLC) {
@@ -165,6 +173,12 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
                     kx = 0;
                     ++ky;
                 }
+            }
+            if (rot && ++kpos == nk) {                           // wrap to the first K tile
+                kpos = 0;
+                c0 = tap = ky = kx = 0;
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i) b_ptr[i] -= (long)nk * b_step[i];
             }
         }
     };
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
 
     // ---- residual prefetch: issued before the K loop so its HBM latency hides under it -------------
     constexpr int VPR = BN / 8;
-    constexpr int ERPP = 256 / VPR;
+    constexpr int ERPP = NT / VPR;
     constexpr int EROWS = (BM / 2) / ERPP;
     const int c8 = (tid % VPR) * 8;
     const int n = n0 + c8;
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
     const int frow = lane & 31;
     const int sw = (frow >> KEY_SHIFT) & (CHUNKS - 1);
     const int fa_off = (wm * (BM / 2) + frow) * ROW_BYTES;
-    const int fb_off = A_BYTES + (wn * (BN / 2) + frow) * ROW_BYTES;
+    const int fb_off = A_BYTES + (wn * (BN / WN) + frow) * ROW_BYTES;
     int choff[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) choff[ks] = ((2 * ks + (lane >> 5)) ^ sw) * 16;
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        const int col = wn * (BN / 2) + j * 32 + (lane & 31);
+                        const int col = wn * (BN / WN) + j * 32 + (lane & 31);
                         Cs[row * CP + col] = acc[i][j][r];
                     }
         }
@@ -280,22 +294,24 @@ __global__ __launch_bounds__(256) void igemm2_kernel(IgemmParams p) {
     }
 }
 
-template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC>
+template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC, int WN = 2>
 int launch2(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
+    static const int rot_env = getenv("DVID_IGEMM_ROT") ? atoi(getenv("DVID_IGEMM_ROT")) : 0;
+    p.krot = rot_env;
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.Cout, BN);
     constexpr int smem = Smem2<BM, BN, BKT, NSTAGE>::kBytes;
     if (smem > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, SMALLC>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
     }
     const int nsplit = p.splitk > 1 ? p.splitk : 1;
-    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, SMALLC>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(256), smem, s, p);
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(128 * WN), smem, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
 }
@@ -326,6 +342,12 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
     // layers (<= 4 K steps) are bound by HBM traffic and the epilogue: the smaller LDS footprint of BKT 32
     // (4 resident workgroups per CU instead of 2) wins (measured per layer, tools/bench_igemm.py).
     static const int nst_env = getenv("DVID_IGEMM_STAGES") ? atoi(getenv("DVID_IGEMM_STAGES")) : 0;
+    // Long-K layers with N a multiple of 256 and enough rows: 128x256x64 tile, 8 waves, 3-stage DMA ring with counted
+    // vmcnt -- 85 FLOP per staged byte instead of 43 (128x64), one workgroup per CU, latency hidden by the ring.
+    static const int big_env = getenv("DVID_IGEMM_BIG") ? atoi(getenv("DVID_IGEMM_BIG")) : 0;
+    if (big_env && !smallc && p.splitk <= 1 && p.Kpad >= 512 && (p.Cout % 256) == 0 &&
+        (long)ceil_div(p.M, 128) * (p.Cout / 256) >= 128)
+        return launch2<128, 256, 64, 3, false, 4>(p, s);
     const int bkt = bkt_env ? bkt_env : (p.Kpad >= 512 ? 64 : 32);
     const int nst = nst_env ? nst_env : 2;
     if (bkt == 32) return nst == 3 ? dispatch2<32, 3>(p, s, smallc) : dispatch2<32, 2>(p, s, smallc);
