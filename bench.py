@@ -164,11 +164,16 @@ def main():
     if os.environ.get("DVID_PROFILE_DUMP") and rank == 0:
         lib.dvid_profile_dump(os.environ["DVID_PROFILE_DUMP"].encode())
     lib.dvid_profile_reset()
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_igemm_traffic.json")
+    if os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected in-process)
+        traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
     if ms.value > 0:
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, fp16 MFMA)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01_pmc_igemm_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch)",
                     "launches_per_step": int(nl.value), "avg_launch_us": round(ms.value * 1e3 / max(1, nl.value), 2),
                     "kernel_ms_per_step": round(ms.value, 2), "alg_gflop_per_launch": round(fl.value / max(1, nl.value) / 1e9, 3)}
 
