@@ -2,6 +2,7 @@
 // See include/dvid_hip.h for the contract of every exported symbol.
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -174,6 +175,22 @@ struct dvid_model {
     DevBuf sw_x, sw_x2, sw_ln16, sw_qkv16, sw_attn16, sw_h16;   // Swin token buffers
     DevBuf roi, params, dyn, qkv, attn16, f32a, f32b, f32c, f32d, h16a, h16b, hid16, ss, deltas, kvproj, mem16, splitk, vt;
     std::map<int, std::vector<int64_t>> ss_keys;  // per head slot: t vector of the uploaded scale/shift table
+
+    // sub-batch chains (see dvid_backbone_resnet_fpn)
+    int nchain = 2;
+    hipStream_t cs[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool streams_ready = false;
+    int ensure_streams() {
+        if (streams_ready) return DVID_OK;
+        for (int c = 0; c < 4; ++c) {
+            HIP_TRY(hipStreamCreateWithFlags(&cs[c], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev_join[c], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        streams_ready = true;
+        return DVID_OK;
+    }
 
     int upload(const void* host, size_t bytes, void** dev) {
         HIP_TRY(hipMalloc(dev, bytes));
@@ -389,6 +406,109 @@ int run_fpn(dvid_model* m, int n, const int* sh, const int* sw, void* p3, void* 
     return DVID_OK;
 }
 
+// One RCNNHead / RCNNHead_cond pass over frames [f0, f0 + nf) on stream `s`; `wrow` = first workspace row of this
+// chain's slice of the [rows, *] buffers, `vt_off` = its offset (halves) in the V^T scratch.
+int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3, const void* p4, const void* p5, int f0, int nf,
+                    int height, int width, int M, const float* boxes_all, const float* pro_all, const float* cond_all,
+                    float* logits_all, float* boxes_out_all, float* obj_all, int* bad_box_flag, const float* ss_all, size_t wrow,
+                    size_t vt_off, hipStream_t s) {
+    const int d = m->cfg.hidden_dim, R = nf * M;
+    const size_t r0 = (size_t)f0 * M;
+    const float* boxes = boxes_all + r0 * 4;
+    const float* pro_features = pro_all ? pro_all + r0 * d : nullptr;
+    const float* cond = cond_all ? cond_all + r0 * d : nullptr;
+    float* logits = logits_all + r0 * m->cfg.num_classes;
+    float* boxes_out = boxes_out_all + r0 * 4;
+    float* obj_features = obj_all + r0 * d;
+    const int ss_ld = is_cond ? d : 2 * d;
+    const float* ss_dev = ss_all + (size_t)f0 * ss_ld;
+    // workspace slices
+    half_t* roi16 = m->roi.as<half_t>() + wrow * 49 * d;
+    half_t* dyn16 = m->dyn.as<half_t>() + wrow * 49 * d;
+    half_t* params16 = m->params.as<half_t>() + wrow * 2 * d * m->cfg.dim_dynamic;
+    half_t* qkv16 = m->qkv.as<half_t>() + wrow * 3 * d * 2;        // buffer is sized in fp32 units; fp16 use needs half of it
+    half_t* attn16 = m->attn16.as<half_t>() + wrow * d;
+    float* f32a = m->f32a.as<float>() + wrow * d;
+    float* f32b = m->f32b.as<float>() + wrow * d;
+    float* f32c = m->f32c.as<float>() + wrow * d;
+    float* f32d = m->f32d.as<float>() + wrow * d;
+    half_t* h16a = m->h16a.as<half_t>() + wrow * d;
+    half_t* h16b = m->h16b.as<half_t>() + wrow * d;
+    half_t* hid16 = m->hid16.as<half_t>() + wrow * m->cfg.dim_feedforward;
+    float* deltas = m->deltas.as<float>() + wrow * 4;
+    float* splitk = m->splitk.as<float>() + wrow * d * 8;
+    half_t* vt = m->vt.as<half_t>() + vt_off;
+
+    // --- RoIAlign ---
+    RoiLevels lv;
+    const void* pl[3] = {p3, p4, p5};
+    for (int l = 0; l < 3; ++l) {
+        lv.h[l] = height >> (3 + l);
+        lv.w[l] = width >> (3 + l);
+        lv.feat[l] = reinterpret_cast<const half_t*>(pl[l]) + (size_t)f0 * lv.h[l] * lv.w[l] * d;
+        lv.scale[l] = 1.f / (float)(8 << l);
+    }
+    float* pro32 = f32a;
+    TRY(dvid_roialign_launch(lv, d, boxes, nf, M, roi16, pro_features ? nullptr : pro32, s));
+    const float* pro = pro_features ? pro_features : pro32;
+    // --- self attention + norm1 ---
+    TRY(dvid_f32_to_f16_launch(pro, h16a, (long)R * d, s));
+    TRY(linear_run(hw.in_proj, h16a, R, qkv16, 0, 0, s));          // fp16 q|k|v, MFMA operands
+    TRY(dvid_mha_mfma_launch(qkv16, qkv16 + d, qkv16 + 2 * d, attn16, vt, nf, M, M, m->cfg.nheads, 3 * d, 3 * d, d, (long)M * 3 * d,
+                             (long)M * 3 * d, (long)M * d, s));
+    TRY(linear_run(hw.out_proj, attn16, R, f32b, 0, 1, s));
+    float* x1 = f32c;
+    TRY(dvid_add_layernorm_launch(pro, f32b, hw.norm1.g, hw.norm1.b, x1, h16a, R, d, 0, s));
+    // --- DynamicConv ---
+    TRY(linear_run(hw.dynamic_layer, h16a, R, params16, 0, 0, s));
+    TRY(dvid_dynconv_launch(roi16, params16, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn16, R, s));
+    // out_layer: K = 49*d = 12544 on only R x d outputs -> split K over 7 workgroups per tile; the partial slabs
+    // and the bias are summed inside the norm3 kernel that consumes them.
+    const int osplit = ((hw.out_layer.kpad / 64) % 7 == 0) ? 7 : 1;
+    if (osplit > 1) {
+        TRY(conv_run(hw.out_layer, dyn16, R, 1, 1, splitk, 0, 1, nullptr, 0, 0, s, nullptr, nullptr, 0, osplit));
+        TRY(dvid_add_layernorm_launch(splitk, nullptr, hw.dc_norm3.g, hw.dc_norm3.b, f32b, nullptr, R, d, 1, s, osplit, (long)R * d,
+                                      hw.out_layer.bias));
+    } else {
+        TRY(linear_run(hw.out_layer, dyn16, R, f32b, 0, 1, s));
+        TRY(dvid_add_layernorm_launch(f32b, nullptr, hw.dc_norm3.g, hw.dc_norm3.b, f32b, nullptr, R, d, 1, s));
+    }
+    float* obj = f32d;
+    TRY(dvid_add_layernorm_launch(x1, f32b, hw.norm2.g, hw.norm2.b, obj, h16a, R, d, 0, s));
+    // --- FFN + norm3 ---
+    TRY(linear_run(hw.linear1, h16a, R, hid16, 1, 0, s));
+    TRY(linear_run(hw.linear2, hid16, R, f32b, 0, 1, s));
+    TRY(dvid_add_layernorm_launch(obj, f32b, hw.norm3.g, hw.norm3.b, obj_features, nullptr, R, d, 0, s));
+    // --- time / cond modulation ---
+    half_t* fc16 = h16a;
+    if (!is_cond) {
+        TRY(dvid_modulate_launch(obj_features, ss_dev, 2 * d, ss_dev + d, 0, 2 * d, fc16, R, M, d, s));
+    } else {
+        TRY(dvid_silu_f16_launch(cond, h16b, (long)R * d, s));
+        TRY(linear_run(hw.c_mlp, h16b, R, f32b, 0, 1, s));
+        TRY(dvid_modulate_launch(obj_features, ss_dev, d, f32b, 1, d, fc16, R, M, d, s));
+    }
+    // --- cls tower ---
+    const half_t* cur = fc16;
+    for (size_t i = 0; i < hw.cls.size(); ++i) {
+        TRY(linear_run(hw.cls[i], cur, R, f32b, 0, 1, s));
+        TRY(dvid_add_layernorm_launch(f32b, nullptr, hw.cls_ln[i].g, hw.cls_ln[i].b, nullptr, h16b, R, d, 1, s));
+        cur = h16b;
+    }
+    TRY(conv_run(hw.class_logits, cur, R, 1, 1, logits, 0, 1, nullptr, 0, 0, s, nullptr, nullptr, m->cfg.num_classes));
+    // --- reg tower ---
+    cur = fc16;
+    half_t* regbuf[2] = {h16b, attn16};
+    for (size_t i = 0; i < hw.reg.size(); ++i) {
+        TRY(linear_run(hw.reg[i], cur, R, f32b, 0, 1, s));
+        TRY(dvid_add_layernorm_launch(f32b, nullptr, hw.reg_ln[i].g, hw.reg_ln[i].b, nullptr, regbuf[i & 1], R, d, 1, s));
+        cur = regbuf[i & 1];
+    }
+    TRY(conv_run(hw.bboxes_delta, cur, R, 1, 1, deltas, 0, 1, nullptr, 0, 0, s, nullptr, nullptr, 4));
+    TRY(dvid_apply_deltas_launch(deltas, 4, boxes, boxes_out, R, 2.f, 2.f, 1.f, 1.f, logf(100000.f / 16.f), bad_box_flag, s));
+    return DVID_OK;
+}
+
 float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // box_head.py:218-223 + :734-741 on the host (a handful of distinct t values per config)
@@ -437,6 +557,7 @@ int dvid_model_create(const dvid_config* cfg, dvid_model** out) {
     if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count == 0) FAIL(DVID_ERR_HIP, "no HIP device available");
     dvid_model* m = new dvid_model();
     m->cfg = *cfg;
+    if (const char* e = getenv("DVID_CHAINS")) m->nchain = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
     *out = m;
     return DVID_OK;
 }
@@ -575,11 +696,18 @@ int dvid_model_finalize(dvid_model* m) {
     return DVID_OK;
 }
 
+int dvid_set_chains(dvid_model* m, int nchain) {
+    g_err[0] = 0;
+    if (!m || nchain < 1 || nchain > 4) FAIL(DVID_ERR_ARG, "nchain must be 1..4");
+    m->nchain = nchain;
+    return DVID_OK;
+}
+
 int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width, int boxes_per_frame) {
     g_err[0] = 0;
     if (!m || max_frames <= 0 || boxes_per_frame <= 0) FAIL(DVID_ERR_ARG, "bad argument");
     if (height % 32 || width % 32) FAIL(DVID_ERR_ARG, "height/width must be multiples of 32 (got %dx%d)", height, width);
-    const size_t n = max_frames;
+    const size_t n = ((size_t)max_frames + 3) / 4 * 4;      // room for up to 4 equal sub-batch chains
     const size_t px4 = (size_t)(height / 4) * (width / 4);
     if (m->has_backbone && m->cfg.backbone_type == 1) {
         const size_t C0 = m->cfg.swin_embed_dim, M0 = n * px4;      // stage-0 tokens; M*C halves per stage
@@ -647,40 +775,81 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
         mean[i] = m->cfg.pixel_mean[i] / 255.f;
         inv_std[i] = 1.f / (m->cfg.pixel_std[i] / 255.f);
     }
-    TRY(dvid_prep_images_launch(images, m->img8.as<half_t>(), n, height, width, mean, inv_std, s));
-    int h = height, w = width;
-    TRY(conv_run(m->stem, m->img8.as<half_t>(), n, h, w, m->bufT1.p, 1, 0, nullptr, 0, 0, s, &h, &w));
-    TRY(dvid_maxpool3x3s2_launch(m->bufT1.as<half_t>(), m->bufX.as<half_t>(), n, h, w, 64, s));
-    h = (h + 2 - 3) / 2 + 1;
-    w = (w + 2 - 3) / 2 + 1;
-    half_t* const bx = m->bufX.as<half_t>();
-    half_t* const by = m->bufY.as<half_t>();
-    half_t* cur = bx;  // block input
-    half_t* stage_out[4] = {nullptr, m->c3.as<half_t>(), m->c4.as<half_t>(), m->c5.as<half_t>()};
-    int sh[4], sw[4];
-    for (int st = 0; st < 4; ++st) {
-        const int nb = (int)m->blocks[st].size();
-        for (int b = 0; b < nb; ++b) {
-            const Block& blk = m->blocks[st][b];
-            int h2 = h, w2 = w;
-            TRY(conv_run(blk.c1, cur, n, h, w, m->bufT1.p, 1, 0, nullptr, 0, 0, s));
-            TRY(conv_run(blk.c2, m->bufT1.as<half_t>(), n, h, w, m->bufT2.p, 1, 0, nullptr, 0, 0, s, &h2, &w2));
-            const half_t* res = cur;
-            if (blk.has_sc) {
-                TRY(conv_run(blk.sc, cur, n, h, w, m->bufSC.p, 0, 0, nullptr, 0, 0, s));
-                res = m->bufSC.as<half_t>();
-            }
-            // res3..res5 outputs persist for the FPN; everything else ping-pongs between bufX/bufY
-            half_t* dst = (b == nb - 1 && stage_out[st]) ? stage_out[st] : (cur == bx ? by : bx);
-            TRY(conv_run(blk.c3, m->bufT2.as<half_t>(), n, h2, w2, dst, 1, 0, res, 1, 0, s));
-            h = h2;
-            w = w2;
-            cur = dst;
-        }
-        sh[st] = h;
-        sw[st] = w;
+    // Frames are independent through the backbone.  They are processed as `nchain` sub-batches on separate HIP
+    // streams: a layer of one sub-batch rarely fills 256 CUs evenly (e.g. res4: 304-608 tiles), and with two chains
+    // in flight the blocks of one chain's next kernel start on the CUs the other chain's tail leaves idle.
+    const int nchain = (m->nchain > 1 && n >= 2 * m->nchain) ? m->nchain : 1;
+    if (nchain > 1) TRY(m->ensure_streams());
+    const int per = (n + nchain - 1) / nchain;
+    const size_t cap_frames = (size_t)(m->ws_frames + nchain - 1) / nchain;      // workspace slice of one chain
+    const size_t px = (size_t)height * width, px4 = px / 16;
+    if (nchain > 1) {
+        HIP_TRY(hipEventRecord(m->ev_fork, s));
+        for (int c = 0; c < nchain; ++c) HIP_TRY(hipStreamWaitEvent(m->cs[c], m->ev_fork, 0));
     }
-    return run_fpn(m, n, sh + 1, sw + 1, p3, p4, p5, s);
+    for (int c = 0; c < nchain; ++c) {
+        const int f0 = c * per, nf = (f0 + per <= n) ? per : n - f0;
+        if (nf <= 0) continue;
+        hipStream_t cs = nchain > 1 ? m->cs[c] : s;
+        // this chain's slice of every workspace buffer (sized for cap_frames frames)
+        half_t* img8 = m->img8.as<half_t>() + c * cap_frames * px * 8;
+        const size_t big = cap_frames * px4 * 256;
+        half_t* bx = m->bufX.as<half_t>() + c * big;
+        half_t* by = m->bufY.as<half_t>() + c * big;
+        half_t* t1 = m->bufT1.as<half_t>() + c * big;
+        half_t* t2 = m->bufT2.as<half_t>() + c * big;
+        half_t* sc = m->bufSC.as<half_t>() + c * big;
+        half_t* stage_out[4] = {nullptr, m->c3.as<half_t>() + c * cap_frames * (px4 / 4) * 512,
+                                m->c4.as<half_t>() + c * cap_frames * (px4 / 16) * 1024,
+                                m->c5.as<half_t>() + c * cap_frames * (px4 / 64) * 2048};
+        half_t* lat[3];
+        for (int l = 0; l < 3; ++l) lat[l] = m->lat[l].as<half_t>() + c * cap_frames * (px4 / (4 << (2 * l))) * 256;
+
+        TRY(dvid_prep_images_launch(images + (size_t)f0 * 3 * px, img8, nf, height, width, mean, inv_std, cs));
+        int h = height, w = width;
+        TRY(conv_run(m->stem, img8, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs, &h, &w));
+        TRY(dvid_maxpool3x3s2_launch(t1, bx, nf, h, w, 64, cs));
+        h = (h + 2 - 3) / 2 + 1;
+        w = (w + 2 - 3) / 2 + 1;
+        half_t* cur = bx;  // block input
+        int sh[4], sw[4];
+        for (int st = 0; st < 4; ++st) {
+            const int nb = (int)m->blocks[st].size();
+            for (int b = 0; b < nb; ++b) {
+                const Block& blk = m->blocks[st][b];
+                int h2 = h, w2 = w;
+                TRY(conv_run(blk.c1, cur, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs));
+                TRY(conv_run(blk.c2, t1, nf, h, w, t2, 1, 0, nullptr, 0, 0, cs, &h2, &w2));
+                const half_t* res = cur;
+                if (blk.has_sc) {
+                    TRY(conv_run(blk.sc, cur, nf, h, w, sc, 0, 0, nullptr, 0, 0, cs));
+                    res = sc;
+                }
+                // res3..res5 outputs persist for the FPN; everything else ping-pongs between bufX/bufY
+                half_t* dst = (b == nb - 1 && stage_out[st]) ? stage_out[st] : (cur == bx ? by : bx);
+                TRY(conv_run(blk.c3, t2, nf, h2, w2, dst, 1, 0, res, 1, 0, cs));
+                h = h2;
+                w = w2;
+                cur = dst;
+            }
+            sh[st] = h;
+            sw[st] = w;
+        }
+        // FPN: outputs go to the caller's [n, ...] tensors at this chain's frame offset
+        void* pout[3] = {reinterpret_cast<half_t*>(p3) + (size_t)f0 * sh[1] * sw[1] * 256,
+                         reinterpret_cast<half_t*>(p4) + (size_t)f0 * sh[2] * sw[2] * 256,
+                         reinterpret_cast<half_t*>(p5) + (size_t)f0 * sh[3] * sw[3] * 256};
+        for (int l = 2; l >= 0; --l) {
+            const void* res = (l < 2) ? lat[l + 1] : nullptr;
+            TRY(conv_run(m->lateral[l], stage_out[l + 1], nf, sh[l + 1], sw[l + 1], lat[l], 0, 0, res, res ? 2 : 0, 0, cs));
+            TRY(conv_run(m->output[l], lat[l], nf, sh[l + 1], sw[l + 1], pout[l], 0, 0, nullptr, 0, 0, cs));
+        }
+        if (nchain > 1) {
+            HIP_TRY(hipEventRecord(m->ev_join[c], cs));
+            HIP_TRY(hipStreamWaitEvent(s, m->ev_join[c], 0));
+        }
+    }
+    return DVID_OK;
 }
 
 int dvid_backbone_swin_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
@@ -752,7 +921,7 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
     if (height % 32 || width % 32) FAIL(DVID_ERR_ARG, "height/width must be multiples of 32");
     const HeadW& hw = hv[head_index];
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int d = m->cfg.hidden_dim, R = n_frames * boxes_per_frame, M = boxes_per_frame;
+    const int d = m->cfg.hidden_dim, M = boxes_per_frame;
 
     // --- time conditioning (box_head.py:533-536 / :645): host-side, cached on the t vector ---
     const int slot = (is_cond ? m->cfg.num_heads : 0) + head_index;
@@ -780,76 +949,31 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
         }
     }
 
-    // --- RoIAlign ---
-    RoiLevels lv;
-    const void* pl[3] = {p3, p4, p5};
-    for (int l = 0; l < 3; ++l) {
-        lv.feat[l] = reinterpret_cast<const half_t*>(pl[l]);
-        lv.h[l] = height >> (3 + l);
-        lv.w[l] = width >> (3 + l);
-        lv.scale[l] = 1.f / (float)(8 << l);
+    // Frames are independent inside a head (self-attention is per frame): run them as sub-batch chains on separate
+    // streams so that the many small GEMM / row kernels of the two chains fill each other's idle CUs.
+    // (measured: 0.49 ms per pass sequential vs 0.53 ms with two chains -- the head is launch-latency bound, so the
+    //  chains stay off here unless DVID_HEAD_CHAINS=1; tools/bench_head.py)
+    static const bool head_chains = getenv("DVID_HEAD_CHAINS") != nullptr;
+    const int nchain = (head_chains && m->nchain > 1 && n_frames >= 2 * m->nchain) ? 2 : 1;
+    if (nchain > 1) {
+        TRY(m->ensure_streams());
+        HIP_TRY(hipEventRecord(m->ev_fork, s));
+        for (int c = 0; c < nchain; ++c) HIP_TRY(hipStreamWaitEvent(m->cs[c], m->ev_fork, 0));
     }
-    float* pro32 = m->f32a.as<float>();
-    TRY(dvid_roialign_launch(lv, d, boxes, n_frames, M, m->roi.as<half_t>(), pro_features ? nullptr : pro32, s));
-    const float* pro = pro_features ? pro_features : pro32;
-    // --- self attention + norm1 ---
-    TRY(dvid_f32_to_f16_launch(pro, m->h16a.as<half_t>(), (long)R * d, s));
-    TRY(linear_run(hw.in_proj, m->h16a.as<half_t>(), R, m->qkv.p, 0, 0, s));          // fp16 q|k|v, MFMA operands
-    const half_t* qkv = m->qkv.as<half_t>();
-    TRY(dvid_mha_mfma_launch(qkv, qkv + d, qkv + 2 * d, m->attn16.as<half_t>(), m->vt.as<half_t>(), n_frames, M, M, m->cfg.nheads,
-                             3 * d, 3 * d, d, (long)M * 3 * d, (long)M * 3 * d, (long)M * d, s));
-    TRY(linear_run(hw.out_proj, m->attn16.as<half_t>(), R, m->f32b.p, 0, 1, s));
-    float* x1 = m->f32c.as<float>();
-    TRY(dvid_add_layernorm_launch(pro, m->f32b.as<float>(), hw.norm1.g, hw.norm1.b, x1, m->h16a.as<half_t>(), R, d, 0, s));
-    // --- DynamicConv ---
-    TRY(linear_run(hw.dynamic_layer, m->h16a.as<half_t>(), R, m->params.p, 0, 0, s));
-    TRY(dvid_dynconv_launch(m->roi.as<half_t>(), m->params.as<half_t>(), hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b,
-                            m->dyn.as<half_t>(), R, s));
-    // out_layer: K = 49*d = 12544 on only R x d outputs -> split K over 7 workgroups per tile; the partial slabs
-    // and the bias are summed inside the norm3 kernel that consumes them.
-    const int osplit = ((hw.out_layer.kpad / 64) % 7 == 0) ? 7 : 1;
-    if (osplit > 1) {
-        TRY(conv_run(hw.out_layer, m->dyn.as<half_t>(), R, 1, 1, m->splitk.p, 0, 1, nullptr, 0, 0, s, nullptr, nullptr, 0, osplit));
-        TRY(dvid_add_layernorm_launch(m->splitk.as<float>(), nullptr, hw.dc_norm3.g, hw.dc_norm3.b, m->f32b.as<float>(), nullptr, R, d, 1,
-                                      s, osplit, (long)R * d, hw.out_layer.bias));
-    } else {
-        TRY(linear_run(hw.out_layer, m->dyn.as<half_t>(), R, m->f32b.p, 0, 1, s));
-        TRY(dvid_add_layernorm_launch(m->f32b.as<float>(), nullptr, hw.dc_norm3.g, hw.dc_norm3.b, m->f32b.as<float>(), nullptr, R, d, 1, s));
+    const int per = (n_frames + nchain - 1) / nchain;
+    const size_t cap_rows = (size_t)((m->ws_frames + nchain - 1) / nchain) * m->ws_boxes;    // workspace slice of one chain
+    const size_t lk_pad = ((size_t)M + 31) / 32 * 32 + 32;
+    for (int c = 0; c < nchain; ++c) {
+        const int f0 = c * per, nf = (f0 + per <= n_frames) ? per : n_frames - f0;
+        if (nf <= 0) continue;
+        TRY(rcnn_head_chain(m, hw, is_cond, p3, p4, p5, f0, nf, height, width, M, boxes, pro_features, cond, logits, boxes_out,
+                            obj_features, bad_box_flag, ss_dev, c * cap_rows, c * (size_t)((m->ws_frames + nchain - 1) / nchain) * m->cfg.nheads * 32 * lk_pad,
+                            nchain > 1 ? m->cs[c] : s));
+        if (nchain > 1) {
+            HIP_TRY(hipEventRecord(m->ev_join[c], m->cs[c]));
+            HIP_TRY(hipStreamWaitEvent(s, m->ev_join[c], 0));
+        }
     }
-    float* obj = m->f32d.as<float>();
-    TRY(dvid_add_layernorm_launch(x1, m->f32b.as<float>(), hw.norm2.g, hw.norm2.b, obj, m->h16a.as<half_t>(), R, d, 0, s));
-    // --- FFN + norm3 ---
-    TRY(linear_run(hw.linear1, m->h16a.as<half_t>(), R, m->hid16.p, 1, 0, s));
-    TRY(linear_run(hw.linear2, m->hid16.as<half_t>(), R, m->f32b.p, 0, 1, s));
-    TRY(dvid_add_layernorm_launch(obj, m->f32b.as<float>(), hw.norm3.g, hw.norm3.b, obj_features, nullptr, R, d, 0, s));
-    // --- time / cond modulation ---
-    half_t* fc16 = m->h16a.as<half_t>();
-    if (!is_cond) {
-        TRY(dvid_modulate_launch(obj_features, ss_dev, 2 * d, ss_dev + d, 0, 2 * d, fc16, R, M, d, s));
-    } else {
-        TRY(dvid_silu_f16_launch(cond, m->h16b.as<half_t>(), (long)R * d, s));
-        TRY(linear_run(hw.c_mlp, m->h16b.as<half_t>(), R, m->f32b.p, 0, 1, s));
-        TRY(dvid_modulate_launch(obj_features, ss_dev, d, m->f32b.as<float>(), 1, d, fc16, R, M, d, s));
-    }
-    // --- cls tower ---
-    const half_t* cur = fc16;
-    for (size_t i = 0; i < hw.cls.size(); ++i) {
-        TRY(linear_run(hw.cls[i], cur, R, m->f32b.p, 0, 1, s));
-        TRY(dvid_add_layernorm_launch(m->f32b.as<float>(), nullptr, hw.cls_ln[i].g, hw.cls_ln[i].b, nullptr, m->h16b.as<half_t>(), R, d,
-                                      1, s));
-        cur = m->h16b.as<half_t>();
-    }
-    TRY(conv_run(hw.class_logits, cur, R, 1, 1, logits, 0, 1, nullptr, 0, 0, s, nullptr, nullptr, m->cfg.num_classes));
-    // --- reg tower ---
-    cur = fc16;
-    half_t* regbuf[2] = {m->h16b.as<half_t>(), m->attn16.as<half_t>()};
-    for (size_t i = 0; i < hw.reg.size(); ++i) {
-        TRY(linear_run(hw.reg[i], cur, R, m->f32b.p, 0, 1, s));
-        TRY(dvid_add_layernorm_launch(m->f32b.as<float>(), nullptr, hw.reg_ln[i].g, hw.reg_ln[i].b, nullptr, regbuf[i & 1], R, d, 1, s));
-        cur = regbuf[i & 1];
-    }
-    TRY(conv_run(hw.bboxes_delta, cur, R, 1, 1, m->deltas.p, 0, 1, nullptr, 0, 0, s, nullptr, nullptr, 4));
-    TRY(dvid_apply_deltas_launch(m->deltas.as<float>(), 4, boxes, boxes_out, R, 2.f, 2.f, 1.f, 1.f, logf(100000.f / 16.f), bad_box_flag, s));
     return DVID_OK;
 }
 

@@ -137,6 +137,9 @@ class DiffusionDet(nn.Module):
         for name, t in sd.items():
             _register_nested(self, name, t, buffer=name.endswith(("running_mean", "running_var")))
         self._engine = None
+        self._ac_host = alphas_cumprod.clone()      # host copies: schedule lookups must not sync the device
+        self._sr_host = torch.sqrt(1.0 / alphas_cumprod)
+        self._srm1_host = torch.sqrt(1.0 / alphas_cumprod - 1)
         self.noise_fn = None
         self.debug_taps = None      # dict -> receives intermediates (parity tests)
         # True: a batch's detections come back with ONE device->host copy and the BoxLists hold CPU tensors
@@ -225,10 +228,14 @@ class DiffusionDet(nn.Module):
             eng.reserve(self.infer_batch, total.shape[-2], total.shape[-1], M)
             len_l = len(ref_l)
             splits, k1_all, k2_all = [], [], []
-            for bi, chunk in enumerate(total.split(self.infer_batch)):
+            chunks = total.split(self.infer_batch)
+            # every random draw of this call is uploaded BEFORE any kernel is queued: a host->device copy from pageable
+            # memory blocks the host until the stream has drained, which would cut the launch queue once per split
+            box_inits = [self._noise("box_init", frame_id, bi, 0, (c.shape[0], M, 4)) for bi, c in enumerate(chunks)]
+            for bi, chunk in enumerate(chunks):
                 feats = eng.backbone(chunk.contiguous())
                 B = chunk.shape[0]
-                box_init = self._noise("box_init", frame_id, bi, 0, (B, M, 4))
+                box_init = box_inits[bi]
                 t = torch.full((B,), 999, dtype=torch.long)
                 (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init, t, box_extract=bi + 1)
                 splits.append({"feats": feats, "logits": cl, "boxes": bx, "obj": pf[0].view(B, M, self.hidden_dim)})
@@ -306,6 +313,12 @@ class DiffusionDet(nn.Module):
         NMS ensemble."""
         M = self.num_proposals
         img = self._noise("img", frame_id, 0, 0, (batch, M, 4))
+        draws = {}                     # all DDIM / renewal noise up front (see the note on uploads in _forward_test)
+        for step, (time, time_next) in enumerate(pairs):
+            if time_next >= 0:
+                draws[step] = (torch.stack([self._noise("ddim", frame_id, step, i, (M, 4)) for i in range(batch)]),
+                               torch.stack([self._noise("renew", frame_id, step, i, (M, 4)) for i in range(batch)]))
+        coef = {t: (float(self._sr_host[t]), float(self._srm1_host[t])) for t, _ in pairs}
         ens_logits, ens_boxes = [], []
         for step, (time, time_next) in enumerate(pairs):
             t = torch.full((batch,), time, dtype=torch.long)
@@ -314,15 +327,13 @@ class DiffusionDet(nn.Module):
                 self.debug_taps[f"final_{step}"] = (outputs_class[-1], outputs_coord[-1])
             if time_next < 0:
                 continue            # the last step never reaches the ensemble (diffusion_det.py:573-575)
-            a = self.alphas_cumprod[time].double().cpu()
-            an = self.alphas_cumprod[time_next].double().cpu()
+            a = self._ac_host[time].double()
+            an = self._ac_host[time_next].double()
             sigma = self.ddim_sampling_eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
             c = (1 - an - sigma ** 2).sqrt()
-            noise = torch.stack([self._noise("ddim", frame_id, step, i, (M, 4)) for i in range(batch)])
-            fresh = torch.stack([self._noise("renew", frame_id, step, i, (M, 4)) for i in range(batch)])
+            noise, fresh = draws[step]
             img = ops.ddim_renew_step(outputs_class[-1], outputs_coord[-1], img, noise, fresh, whwh, self.scale,
-                                      float(self.sqrt_recip_alphas_cumprod[time]), float(self.sqrt_recipm1_alphas_cumprod[time]),
-                                      float(self.alphas_cumprod[time_next].sqrt()), float(c), float(sigma), 0.5)
+                                      coef[time][0], coef[time][1], float(self._ac_host[time_next].sqrt()), float(c), float(sigma), 0.5)
             ens_logits.append(outputs_class[-1])
             ens_boxes.append(outputs_coord[-1])
         return ops.postproc_topk_nms(torch.stack(ens_logits), torch.stack(ens_boxes), w, h, 0.5, self.use_nms)

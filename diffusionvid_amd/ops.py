@@ -252,6 +252,10 @@ class Model:
         _lib.check(lib.dvid_model_finalize(h), "dvid_model_finalize")
         self._ws = None
 
+    def set_chains(self, n):
+        """concurrent sub-batch chains inside the library (1 = sequential kernels, for per-kernel profiling)"""
+        call("dvid_set_chains", self.handle, int(n))
+
     def reserve(self, max_frames, height, width, boxes_per_frame):
         key = (max_frames, height, width, boxes_per_frame)
         if self._ws != key:

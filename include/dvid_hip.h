@@ -83,6 +83,10 @@ int dvid_model_finalize(dvid_model* m);
  * (multiples of 32) and boxes_per_frame boxes. */
 int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width, int boxes_per_frame);
 
+/* Number of concurrent sub-batch chains (separate HIP streams inside the library, joined back to the caller's
+ * stream before returning) used by the backbone and the heads; 1 = strictly sequential kernels (profiling). */
+int dvid_set_chains(dvid_model* m, int nchain);
+
 /* ---- stages -------------------------------------------------------------------------------- */
 /* images: fp32 NCHW [n,3,height,width] in [0,1] (zero padded, un-normalised).  Outputs fp16 NHWC
  * p3 [n,h/8,w/8,256], p4 [n,h/16,w/16,256], p5 [n,h/32,w/32,256]. */
