@@ -104,3 +104,23 @@ def predictions_list(merged):
     """dict -> list indexed by dataset image id, as torch.save'd to predictions.pth (inference.py:101-115)."""
     ids = sorted(merged.keys())
     return [merged[i] for i in ids]
+
+
+def inference(model, dataset, indices, device, output_folder=None, gt_boxlists=None, max_det=300):
+    """Reference `inference` (mega_core/engine/inference.py:118-181) for the in-scope path: run this rank's
+    contiguous share, gather on rank 0, write `predictions.pth`, and -- when ground truth is supplied -- the
+    VID AP50 of data/evaluation/vid_eval.py.  Returns (predictions list | None off rank 0, eval dict | None)."""
+    import os
+
+    from ..data.evaluation import vid_eval
+    from ..utils import comm
+    results = compute_on_dataset(model, dataset, indices, device)
+    merged = gather_predictions(results, max_det, device=device)
+    if not comm.is_main_process():
+        return None, None
+    preds = predictions_list(merged)
+    if output_folder:
+        os.makedirs(output_folder, exist_ok=True)
+        vid_eval.save_predictions(preds, os.path.join(output_folder, "predictions.pth"))
+    ev = vid_eval.eval_detection_vid(preds, gt_boxlists) if gt_boxlists is not None else None
+    return preds, ev

@@ -236,6 +236,41 @@ def g8_swin():
     save("g8_swin", x=x, swin1=out["swin1"], swin2=out["swin2"], swin3=out["swin3"], **sd)
 
 
+def g11_vid_eval():
+    """eval_detection_vid (vid_eval.py:130-354) on a toy 3-class set with near-duplicate detections, misses,
+    false positives, frames without ground truth and a class that only appears in predictions."""
+    from mega_core.data.datasets.evaluation.vid.vid_eval import eval_detection_vid
+    g = torch.Generator().manual_seed(110)
+    preds, gts, flat = [], [], {}
+    for f in range(12):
+        ng = int(torch.randint(0, 4, (1,), generator=g))
+        gb = torch.rand(ng, 2, generator=g) * 300
+        gwh = torch.rand(ng, 2, generator=g) * 120 + 20
+        gt = BoxList(torch.cat([gb, gb + gwh], 1).round(), (500, 400))
+        gt.add_field("labels", torch.randint(1, 4, (ng,), generator=g))
+        npred = int(torch.randint(0, 7, (1,), generator=g))
+        rows, labs = [], []
+        for k in range(npred):
+            if ng and torch.rand(1, generator=g) < 0.7:
+                j = int(torch.randint(0, ng, (1,), generator=g))
+                rows.append(gt.bbox[j] + torch.randn(4, generator=g) * 12)
+                labs.append(int(gt.get_field("labels")[j]) if torch.rand(1, generator=g) < 0.85 else 4)
+            else:
+                b = torch.rand(2, generator=g) * 300
+                rows.append(torch.cat([b, b + torch.rand(2, generator=g) * 100 + 10]))
+                labs.append(int(torch.randint(1, 5, (1,), generator=g)))
+        pb = torch.stack(rows) if rows else torch.zeros(0, 4)
+        pr = BoxList(pb, (500, 400))
+        pr.add_field("labels", torch.tensor(labs, dtype=torch.int64))
+        pr.add_field("scores", torch.rand(len(labs), generator=g))
+        preds.append(pr)
+        gts.append(gt)
+        flat[f"gt_box_{f}"], flat[f"gt_lab_{f}"] = gt.bbox, gt.get_field("labels")
+        flat[f"pr_box_{f}"], flat[f"pr_lab_{f}"], flat[f"pr_sc_{f}"] = pr.bbox, pr.get_field("labels"), pr.get_field("scores")
+    res = eval_detection_vid(preds, gts, iou_thresh=0.5, motion_ranges=[[0.0, 1.0]], motion_specific=False)
+    save("g11_vid_eval", nframes=np.array(12), ap=res[0]["ap"], map=np.array(res[0]["map"]), **flat)
+
+
 if __name__ == "__main__":
     # The reference targets torch 1.8 (INSTALL.md:3-13) where nn.MultiheadAttention.forward IS
     # F.multi_head_attention_forward; keep torch 2.x's fused inference fast path out of the goldens.
@@ -250,4 +285,5 @@ if __name__ == "__main__":
     g7_greedy_perm()
     g8_swin()
     g9_structures()
+    g11_vid_eval()
     g10_sampler()

@@ -94,6 +94,21 @@ def _match_rate(ref, got):
     return hit / max(1, len(ref["scores"]))
 
 
+def _ap50_vs_oracle(ref_out, got_out, size):
+    """the reference's VID AP50 protocol (diffusionvid_amd/data/evaluation/vid_eval.py, pinned by
+    golden g11) with the oracle's kept detections playing ground truth -- 1.0 means every oracle detection is found
+    at IoU >= 0.5 with the same label before any extra GPU detection of that class."""
+    from diffusionvid_amd.data.evaluation import vid_eval
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    gts, preds = [], []
+    for r, g in zip(ref_out, got_out):
+        gt = BoxList(torch.as_tensor(r["boxes"], dtype=torch.float32).reshape(-1, 4), size)
+        gt.add_field("labels", torch.as_tensor(r["labels"], dtype=torch.int64).reshape(-1))
+        gts.append(gt)
+        preds.append(g.to(torch.device("cpu")))
+    return vid_eval.eval_detection_vid(preds, gts)["map"]
+
+
 @pytest.mark.parametrize("sample_step", [1, 4])
 def test_video_e2e(sample_step):
     from diffusionvid_amd import ops
@@ -169,6 +184,11 @@ def test_video_e2e(sample_step):
     print(f"[x{sample_step}] detections: kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]}; "
           f"match rates {['%.2f' % r for r in rates]}")
     assert min(rates) >= 0.9
+    ap = _ap50_vs_oracle(ref_out, got_out, (W0, H0))
+    print(f"[x{sample_step}] VID AP50 of the GPU detections with the oracle's detections as ground truth: {ap:.4f}")
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write(f"[x{sample_step}] AP50(GPU | oracle detections as ground truth) = {ap:.4f}\n")
+    assert ap >= 0.95
     for g in got_out:
         assert g.mode == "xyxy" and g.size == (W0, H0)
         assert g.get_field("labels").dtype == torch.int64 and g.get_field("labels").min() >= 1

@@ -183,3 +183,35 @@ def test_detector_builds_with_reference_state_dict_names():
     with pytest.raises(NotImplementedError):
         m.train()
         m({"cur": torch.zeros(1, 3, 32, 32), "ref_l": [], "ref_g": []})
+
+
+def test_vid_evaluator_matches_reference_golden(tmp_path):
+    """diffusionvid_amd/data/evaluation/vid_eval.py vs the reference's eval_detection_vid (golden g11)."""
+    from diffusionvid_amd.data.evaluation import vid_eval
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    z = golden("g11_vid_eval")
+    preds, gts = [], []
+    for f in range(int(z["nframes"])):
+        gt = BoxList(torch.from_numpy(z[f"gt_box_{f}"]), (500, 400))
+        gt.add_field("labels", torch.from_numpy(z[f"gt_lab_{f}"]))
+        pr = BoxList(torch.from_numpy(z[f"pr_box_{f}"]), (500, 400))
+        pr.add_field("labels", torch.from_numpy(z[f"pr_lab_{f}"]))
+        pr.add_field("scores", torch.from_numpy(z[f"pr_sc_{f}"]))
+        preds.append(pr)
+        gts.append(gt)
+    res = vid_eval.eval_detection_vid(preds, gts)
+    np.testing.assert_allclose(res["ap"], z["ap"], rtol=0, atol=1e-12, equal_nan=True)
+    assert abs(res["map"] - float(z["map"])) < 1e-12 and 0.0 < res["map"] < 1.0
+    # perfect predictions -> AP50 = 1 for every class present
+    perfect = []
+    for gt in gts:
+        p = BoxList(gt.bbox.clone(), gt.size)
+        p.add_field("labels", gt.get_field("labels"))
+        p.add_field("scores", torch.ones(len(gt)))
+        perfect.append(p)
+    assert vid_eval.eval_detection_vid(perfect, gts)["map"] == 1.0
+    # predictions.pth round trip
+    path = str(tmp_path / "predictions.pth")
+    vid_eval.save_predictions(preds, path)
+    back = vid_eval.load_predictions(path)
+    assert len(back) == len(preds) and torch.equal(back[3].bbox, preds[3].bbox)
