@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=304, help="frames per synthetic video")
+    ap.add_argument("--lookahead", type=int, default=4,
+                    help="INPUT.LOOKAHEAD_BATCHES: 8-frame batches whose backbone + extraction heads share one launch (1 = reference schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -113,7 +115,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         comm.init_dist("nccl")
 
-    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16"],
+    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", args.lookahead],
                   os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
     cfg.freeze()
     model = build_detection_model(cfg).to(device).eval()
@@ -153,11 +155,17 @@ def main():
     # ---- roofline of the dominant kernel: instrumented repeat of one step -------------------------
     roofline = None
     lib = _lib.load()
+    # per-launch HIP events on the library's stream; sub-batch chains are switched off for this pass so that launches
+    # do not overlap and each event pair times one kernel alone (the same condition rocprofv3 summaries in profiles/
+    # are taken under: DVID_CHAINS=1)
+    engine_model = model._get_engine()
+    engine_model.set_chains(1)
     lib.dvid_profile_reset()
     lib.dvid_profile_enable(1)
     with torch.no_grad():
         run_video(model, ds, device)
     torch.cuda.synchronize()
+    engine_model.set_chains(int(os.environ.get("DVID_CHAINS", "2")))
     ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     _lib.check(lib.dvid_profile_read(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), "dvid_profile_read")
     lib.dvid_profile_enable(0)
@@ -186,7 +194,8 @@ def main():
             "config": {"workload": "ResNet-101 DiffusionVID x1 fp16, 300 boxes, 1 DDIM step; one step = one synthetic "
                                    "%d-frame 1000x600 video per GPU (24 global + %d local frames, %d batches of 8)"
                                    % (L, L, (L + 7) // 8),
-                       "frames_per_step_per_gpu": L, "infer_batch": 8, "parallelism": "videos sharded across ranks"},
+                       "frames_per_step_per_gpu": L, "infer_batch": 8, "lookahead_batches": args.lookahead,
+                       "parallelism": "videos sharded across ranks"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

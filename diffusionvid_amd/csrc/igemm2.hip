@@ -47,7 +47,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 //           COUNTED `s_waitcnt vmcnt(P)` (P = its DMA pieces per tile) so only the tile about to be read has
 //           landed, and re-fills the stage freed by the previous step right after the barrier.
 // WN: waves along N (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads); always 2 waves along M.
-template <int BM, int BN, int BKT, int NSTAGE, int WN, bool SMALLC>
+// ILV (NSTAGE 2 only): the DMA pieces of the next K tile are issued between the MFMA groups of the current one
+//           instead of in front of them -- one piece costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md,
+//           "LDS-DMA piece issue cost"), which is hidden only while that wave's earlier MFMAs are still executing.
+template <int BM, int BN, int BKT, int NSTAGE, int WN, bool SMALLC, bool ILV = false>
 __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     constexpr int NW = 2 * WN;                      // waves per workgroup
     constexpr int NT = 64 * NW;                     // threads
@@ -138,32 +141,31 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) b_ptr[i] += (long)kt0 * b_step[i];
 
-    auto issue = [&](int kt, int stage) {
+    // one DMA piece of K tile `kt` into `stage`: pieces [0, A_IT) are A rows, [A_IT, A_IT + B_IT) are B rows
+    auto issue_piece = [&](int kt, int stage, int i) {
         char* sa = smem + stage * STAGE;
         char* sb = sa + A_BYTES;
-        if (SMALLC) {                                            // Cin == 8: one tap per 16-byte chunk
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
+        if (i < A_IT) {
+            if (SMALLC) {                                        // Cin == 8: one tap per 16-byte chunk
                 const int tp = kt * CHUNKS + a_lch[i];
                 const int tky = tp / p.KW, tkx = tp - tky * p.KW;
                 const int iy = a_iy[i] + tky, ix = a_ix[i] + tkx;
                 const bool ok = tp < p.ntaps && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const char* src = ok ? a_ptr[i] + (long)((tky * p.W + tkx) * p.Cin) * 2 : zero;
                 glds16(src, sa + (wave + NW * i) * 1024);
-            }
-        } else {
-            const long koff = (long)((ky * p.W + kx) * p.Cin + c0) * 2;          // wave-uniform byte offset of this K tile
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
+            } else {
+                const long koff = (long)((ky * p.W + kx) * p.Cin + c0) * 2;      // wave-uniform byte offset of this K tile
                 const char* src = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + koff : zero;
                 glds16(src, sa + (wave + NW * i) * 1024);
             }
+        } else {
+            const int j = i - A_IT;
+            glds16(b_ptr[j], sb + (wave + NW * j) * 1024);
+            b_ptr[j] += b_step[j];
         }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            glds16(b_ptr[i], sb + (wave + NW * i) * 1024);
-            b_ptr[i] += b_step[i];
-        }
+    };
+    // advance the filter-tap walk to the next K tile (after the last piece of a tile has been issued)
+    auto advance = [&]() {
         if (!SMALLC) {
             c0 += BKT;
             if (c0 >= p.Cin) {
@@ -182,6 +184,11 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
             }
         }
     };
+    auto issue = [&](int kt, int stage) {
+#pragma unroll
+        for (int i = 0; i < A_IT + B_IT; ++i) issue_piece(kt, stage, i);
+        advance();
+    };
 
     float16v acc[TM][TN];
 #pragma unroll
@@ -197,8 +204,9 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     constexpr int EROWS = (BM / 2) / ERPP;
     const int c8 = (tid % VPR) * 8;
     const int n = n0 + c8;
-    const bool pre_ok = p.res_mode == 1 && !p.res_f32 && (p.Cout & 7) == 0;
-    half8 rpre[2][EROWS];
+    constexpr bool PRE = BM * BN <= 128 * 128;      // larger tiles need the registers for accumulators
+    const bool pre_ok = PRE && p.res_mode == 1 && !p.res_f32 && (p.Cout & 7) == 0;
+    half8 rpre[2][PRE ? EROWS : 1];
     if (pre_ok) {
 #pragma unroll
         for (int half = 0; half < 2; ++half)
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
             for (int e = 0; e < EROWS; ++e) {
                 const int m = m0 + half * (BM / 2) + tid / VPR + e * ERPP;
                 const bool ok = m < p.M && n < p.Cout;
-                rpre[half][e] = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.res) + (ok ? (long)m * p.Cout + n : 0));
+                rpre[half][PRE ? e : 0] = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.res) + (ok ? (long)m * p.Cout + n : 0));
             }
     }
 
@@ -237,7 +245,73 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         }
     };
 
-    if (NSTAGE == 2) {
+    if (NSTAGE == 2 && ILV) {
+        constexpr int P = A_IT + B_IT;
+        issue(kt0, 0);
+        __syncthreads();
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int cur = kt & 1;
+            const char* st = smem + cur * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                half8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * ROW_BYTES + choff[ks]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * ROW_BYTES + choff[ks]);
+                constexpr int NM = TM * TN;                      // MFMAs of this K sub-step; pieces go after MFMA number q
+#pragma unroll
+                for (int q = 0; q < NM; ++q) {
+                    acc[q / TN][q % TN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[q / TN], fb[q % TN], acc[q / TN][q % TN], 0, 0, 0);
+                    // pieces [ (ks*NM+q) * P / (KS*NM), (ks*NM+q+1) * P / (KS*NM) ) -- evenly spread over the tile's MFMAs
+                    const int lo = (ks * NM + q) * P / (KS * NM), hi = (ks * NM + q + 1) * P / (KS * NM);
+#pragma unroll
+                    for (int i = lo; i < hi; ++i) issue_piece(kt0 + kt + 1, cur ^ 1, i);
+                }
+            }
+            advance();
+            __syncthreads();
+        }
+        compute((nk - 1) & 1);
+        __syncthreads();
+    } else if (NSTAGE == 2 && p.ablate) {
+        // diagnostics: the same loop with one ingredient removed (results are garbage)
+        const bool no_mfma = p.ablate & 1, no_read = p.ablate & 2, no_dma = p.ablate & 4;
+        issue(kt0, 0);
+        __syncthreads();
+        half8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const half8*>(smem + fa_off + i * 32 * ROW_BYTES);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const half8*>(smem + fb_off + j * 32 * ROW_BYTES);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk && !no_dma) issue(kt0 + kt + 1, cur ^ 1);
+            const char* st = smem + cur * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (!no_read) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * ROW_BYTES + choff[ks]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * ROW_BYTES + choff[ks]);
+                }
+                if (!no_mfma) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[j]));
+                }
+            }
+            __syncthreads();
+        }
+    } else if (NSTAGE == 2) {
         issue(kt0, 0);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
@@ -289,43 +363,55 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         for (int e = 0; e < EROWS; ++e) {
             const int r = tid / VPR + e * ERPP;
             const int m = m0 + half * (BM / 2) + r;
-            if (m < p.M && n < p.Cout) igemm_store_row8(p, Cs + r * CP + c8, m, n, bias8, pre_ok, rpre[half][e]);
+            if (m < p.M && n < p.Cout && !(p.ablate & 8)) igemm_store_row8(p, Cs + r * CP + c8, m, n, bias8, pre_ok, rpre[half][PRE ? e : 0]);
         }
     }
 }
 
-template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC, int WN = 2>
+template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC, int WN = 2, bool ILV = false>
 int launch2(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     static const int rot_env = getenv("DVID_IGEMM_ROT") ? atoi(getenv("DVID_IGEMM_ROT")) : 0;
     p.krot = rot_env;
+    static const int abl_env = getenv("DVID_IGEMM_ABLATE") ? atoi(getenv("DVID_IGEMM_ABLATE")) : 0;
+    p.ablate = abl_env;
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.Cout, BN);
     constexpr int smem = Smem2<BM, BN, BKT, NSTAGE>::kBytes;
     if (smem > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC, ILV>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
     }
     const int nsplit = p.splitk > 1 ? p.splitk : 1;
-    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(128 * WN), smem, s, p);
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC, ILV>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(128 * WN), smem, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
 }
 
-template <int BKT, int NSTAGE>
+template <int BKT, int NSTAGE, bool ILV = false>
 int dispatch2(const IgemmParams& p, hipStream_t s, bool smallc) {
-    if (smallc) return launch2<128, 64, BKT, NSTAGE, true>(p, s);
+    if (smallc) return launch2<128, 64, BKT, NSTAGE, true, 2, ILV>(p, s);
+    static const int tile_env = getenv("DVID_IGEMM_TILE") ? atoi(getenv("DVID_IGEMM_TILE")) : 0;   // experiments only
+    if (tile_env == 1) return launch2<128, 128, BKT, NSTAGE, false, 2, ILV>(p, s);
+    if (tile_env == 2) return launch2<128, 64, BKT, NSTAGE, false, 2, ILV>(p, s);
+    if (tile_env == 3) return launch2<64, 64, BKT, NSTAGE, false, 2, ILV>(p, s);
+    if constexpr (BKT == 64 && NSTAGE == 2 && !ILV) {
+        if (tile_env == 4) return launch2<256, 256, 64, 2, false, 4>(p, s);
+        if (tile_env == 5) return launch2<256, 128, 64, 2, false, 2>(p, s);
+        if (tile_env == 6) return launch2<128, 256, 64, 2, false, 4>(p, s);
+        if (tile_env == 7) return launch2<256, 128, 64, 2, false, 4>(p, s);
+    }
     // prefer the big tile while it still gives every CU ~2 workgroups
     const int ns = p.splitk > 1 ? p.splitk : 1;
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.Cout, 128) * ns;
-    if (t128 >= 512 && p.Cout >= 128) return launch2<128, 128, BKT, NSTAGE, false>(p, s);
+    if (t128 >= 512 && p.Cout >= 128) return launch2<128, 128, BKT, NSTAGE, false, 2, ILV>(p, s);
     const long t12864 = (long)ceil_div(p.M, 128) * ceil_div(p.Cout, 64) * ns;
-    if (t12864 >= 512) return launch2<128, 64, BKT, NSTAGE, false>(p, s);
-    return launch2<64, 64, BKT, NSTAGE, false>(p, s);
+    if (t12864 >= 512) return launch2<128, 64, BKT, NSTAGE, false, 2, ILV>(p, s);
+    return launch2<64, 64, BKT, NSTAGE, false, 2, ILV>(p, s);
 }
 
 }  // namespace
@@ -350,6 +436,8 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
         return launch2<128, 256, 64, 3, false, 4>(p, s);
     const int bkt = bkt_env ? bkt_env : (p.Kpad >= 512 ? 64 : 32);
     const int nst = nst_env ? nst_env : 2;
+    static const int ilv_env = getenv("DVID_IGEMM_ILV") ? atoi(getenv("DVID_IGEMM_ILV")) : 0;
+    if (ilv_env && nst == 2) return bkt == 32 ? dispatch2<32, 2, true>(p, s, smallc) : dispatch2<64, 2, true>(p, s, smallc);
     if (bkt == 32) return nst == 3 ? dispatch2<32, 3>(p, s, smallc) : dispatch2<32, 2>(p, s, smallc);
     return nst == 3 ? dispatch2<64, 3>(p, s, smallc) : dispatch2<64, 2>(p, s, smallc);
 }

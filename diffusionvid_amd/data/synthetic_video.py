@@ -25,6 +25,7 @@ class SyntheticVIDDataset:
         self.global_size = mega.GLOBAL.SIZE
         self.stop_update_after_init_g_test = mega.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST
         self.infer_batch = cfg.INPUT.INFER_BATCH
+        self.lookahead = max(1, int(getattr(cfg.INPUT, "LOOKAHEAD_BATCHES", 1)))
         self.size_divisible = cfg.DATALOADER.SIZE_DIVISIBILITY
         self.height, self.width, self.device = height, width, torch.device(device)
         self.video_base = video_base
@@ -98,4 +99,10 @@ class SyntheticVIDDataset:
             "seg_len": seg_len,
             "last_queue_id": ref_id_final,
         }
+        if self.lookahead > 1 and frame_id % (self.infer_batch * self.lookahead) == 0:
+            # INPUT.LOOKAHEAD_BATCHES extension: the 8 frame slots each of the next batches will be built from, i.e.
+            # exactly what calls fb-7 .. fb will deliver through `ref_l` (last frame repeated past the end of the video)
+            images["ref_ahead"] = {
+                fb: [self.frame(v, min(fb - self.infer_batch + 1 + i + self.max_offset, seg_len - 1)) for i in range(self.infer_batch)]
+                for fb in range(frame_id + self.infer_batch, min(frame_id + self.infer_batch * self.lookahead, seg_len), self.infer_batch)}
         return images, None, [idx + i for i in range(self.infer_batch)]

@@ -75,6 +75,7 @@ class DiffusionDet(nn.Module):
         self.hidden_dim = d.HIDDEN_DIM
         self.num_heads = d.NUM_HEADS
         self.infer_batch = cfg.INPUT.INFER_BATCH
+        self.lookahead = max(1, int(getattr(cfg.INPUT, "LOOKAHEAD_BATCHES", 1)))
         self.size_divisibility = 32
         if list(self.in_features) != ["p3", "p4", "p5"]:
             raise NotImplementedError("ROI_HEADS.IN_FEATURES must be [p3, p4, p5] (configs/vid_*_DiffusionVID.yaml)")
@@ -189,6 +190,7 @@ class DiffusionDet(nn.Module):
         return self._forward_test(images["cur"], infos, targets)
 
     def _reset_video(self):
+        self._ahead = {}
         n = self.all_frame_interval
         self.local_img_queue = []
         self.head.proposal_feats_global = [None, None]
@@ -222,34 +224,86 @@ class DiffusionDet(nn.Module):
         eng = self._get_engine()
         M = self.num_proposals
 
-        # 1. features + extraction pass over [local frames | global frames] in splits of INFER_BATCH
-        if ref_l or ref_g:
-            total = torch.cat([im.tensors for im in ref_l] + [im.tensors for im in ref_g]).to(self.device, torch.float32)
-            eng.reserve(self.infer_batch, total.shape[-2], total.shape[-1], M)
-            len_l = len(ref_l)
-            splits, k1_all, k2_all = [], [], []
-            chunks = total.split(self.infer_batch)
-            # every random draw of this call is uploaded BEFORE any kernel is queued: a host->device copy from pageable
-            # memory blocks the host until the stream has drained, which would cut the launch queue once per split
-            box_inits = [self._noise("box_init", frame_id, bi, 0, (c.shape[0], M, 4)) for bi, c in enumerate(chunks)]
-            for bi, chunk in enumerate(chunks):
-                feats = eng.backbone(chunk.contiguous())
+        # 1. features + extraction pass over [local frames | global frames] in splits of INFER_BATCH.  Every stage here
+        # (backbone, the 3 RCNNHeads, top-k feature selection) is per-frame independent, so the splits -- and with
+        # INPUT.LOOKAHEAD_BATCHES > 1 the frames of the next batches (`ref_ahead`) -- run as launches of up to
+        # INFER_BATCH * LOOKAHEAD_BATCHES frames; a batch extracted early waits in `_ahead` for its own call.
+        ahead = infos.get("ref_ahead") or {}
+        local_split = self._ahead.pop(frame_id, None) if not ref_g else None
+        if local_split is not None:
+            ref_l_run = []
+        else:
+            ref_l_run = ref_l
+        len_l = len(ref_l_run)
+        splits, k1_all, k2_all = [], [], []
+        if ref_l_run or ref_g or ahead:
+            frames = [im.tensors for im in ref_l_run] + [im.tensors for im in ref_g]
+            n_own = len(frames)
+            # random draws: one (B, M, 4) tensor per reference split `bi` of this call, then one per look-ahead batch
+            # (drawn as that batch's own call would: split 0 of call `fb`).  All uploads happen BEFORE any kernel is
+            # queued: a host->device copy from pageable memory blocks the host until the stream has drained.
+            sizes = [min(self.infer_batch, n_own - a) for a in range(0, n_own, self.infer_batch)]
+            noise = [self._noise("box_init", frame_id, bi, 0, (b, M, 4)) for bi, b in enumerate(sizes)]
+            ahead_keys = sorted(k for k in ahead if k not in self._ahead)
+            for fb in ahead_keys:
+                group = [to_image_list(im).tensors for im in ahead[fb]]
+                frames += group
+                noise.append(self._noise("box_init", fb, 0, 0, (len(group), M, 4)))
+            total = torch.cat(frames).to(self.device, torch.float32)
+            box_init_all = torch.cat(noise)
+            cap = self.infer_batch * self.lookahead
+            eng.reserve(min(cap, total.shape[0]), total.shape[-2], total.shape[-1], M)
+            per_frame = []          # (chunk result dict, index inside the chunk) for every frame slot of `total`
+            for ci, a in enumerate(range(0, total.shape[0], cap)):
+                chunk = total[a:a + cap].contiguous()
+                feats = eng.backbone(chunk)
                 B = chunk.shape[0]
-                box_init = box_inits[bi]
                 t = torch.full((B,), 999, dtype=torch.long)
-                (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init, t, box_extract=bi + 1)
-                splits.append({"feats": feats, "logits": cl, "boxes": bx, "obj": pf[0].view(B, M, self.hidden_dim)})
-                k1_all.append(k1)
-                k2_all.append(k2)
+                (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init_all[a:a + B], t, box_extract=ci + 1)
+                res = {"feats": feats, "logits": cl, "boxes": bx, "obj": pf[0].view(B, M, self.hidden_dim),
+                       "k1": k1.view(B, self.top_k[0], self.hidden_dim), "k2": k2.view(B, self.top_k[1], self.hidden_dim)}
+                per_frame += [(res, i) for i in range(B)]
                 if self.debug_taps is not None:
                     self.debug_taps.setdefault("extract", []).append((cl, bx, pf[0], feats))
+
+            def take(a, b):
+                """result slots [a, b) as one split: views when they sit in one launch, else a concatenation"""
+                runs = []
+                for j in range(a, b):
+                    src, i = per_frame[j]
+                    if runs and runs[-1][0] is src:
+                        runs[-1][2] = i + 1
+                    else:
+                        runs.append([src, i, i + 1])
+                keys = ("logits", "boxes", "obj", "k1", "k2")
+                if len(runs) == 1:
+                    src, i0, i1 = runs[0]
+                    out = {k: src[k][i0:i1] for k in keys}
+                    out["feats"] = [f[i0:i1] for f in src["feats"]]
+                    return out
+                out = {k: torch.cat([src[k][i0:i1] for src, i0, i1 in runs]) for k in keys}
+                out["feats"] = [torch.cat([src["feats"][l][i0:i1] for src, i0, i1 in runs]) for l in range(3)]
+                return out
+
             if len_l > self.infer_batch:
                 raise NotImplementedError("more local frames than INFER_BATCH in one call")
+            if len_l:
+                local_split = take(0, len_l)
+            if ref_g:
+                gsplit = take(len_l, n_own)
+                k1_all = [gsplit["k1"].reshape(-1, self.hidden_dim)]
+                k2_all = [gsplit["k2"].reshape(-1, self.hidden_dim)]
+            pos = n_own
+            for fb in ahead_keys:
+                nb = len(ahead[fb])
+                self._ahead[fb] = take(pos, pos + nb)
+                pos += nb
+        splits = [local_split]
 
         # 2. global memory, once per video with the shipped config (diffusion_det.py:479-488)
         if ref_g:
-            g1 = torch.cat(k1_all, dim=0).view(-1, self.top_k[0], self.hidden_dim)[len_l:].reshape(-1, self.hidden_dim)
-            g2 = torch.cat(k2_all, dim=0).view(-1, self.top_k[1], self.hidden_dim)[len_l:].reshape(-1, self.hidden_dim)
+            g1 = torch.cat(k1_all, dim=0)
+            g2 = torch.cat(k2_all, dim=0)
             m0, _ = ops.update_erase_memory(g1, self.head.proposal_feats_global[0], self.mem_management_size_test)
             m1, _ = ops.update_erase_memory(g2, self.head.proposal_feats_global[1], 150)
             self.head.proposal_feats_global = [m0, m1]

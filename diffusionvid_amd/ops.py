@@ -257,9 +257,12 @@ class Model:
         call("dvid_set_chains", self.handle, int(n))
 
     def reserve(self, max_frames, height, width, boxes_per_frame):
+        """Workspace for up to max_frames frames of height x width with boxes_per_frame boxes; only ever grows."""
         key = (max_frames, height, width, boxes_per_frame)
+        if self._ws is not None:
+            key = tuple(max(a, b) for a, b in zip(key, self._ws))
         if self._ws != key:
-            call("dvid_workspace_reserve", self.handle, max_frames, height, width, boxes_per_frame)
+            call("dvid_workspace_reserve", self.handle, *key)
             self._ws = key
 
     def backbone(self, images):

@@ -215,3 +215,29 @@ def test_vid_evaluator_matches_reference_golden(tmp_path):
     vid_eval.save_predictions(preds, path)
     back = vid_eval.load_predictions(path)
     assert len(back) == len(preds) and torch.equal(back[3].bbox, preds[3].bbox)
+
+
+def test_dataset_lookahead_slots_match_later_calls():
+    """`ref_ahead[fb]` (INPUT.LOOKAHEAD_BATCHES extension) must hold exactly the frames that calls fb-7 .. fb deliver
+    through `ref_l` in the reference protocol (vid_mega.py:178-221), including the repeated last frame at the tail."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["INPUT.LOOKAHEAD_BATCHES", 4], "configs/BASE_RCNN_1gpu.yaml")
+    ds = SyntheticVIDDataset([53], cfg, height=32, width=48)
+    delivered = {}            # batch call fb -> frames accumulated from ref_l of calls fb-7 .. fb
+    queue = []
+    ahead = {}
+    for idx in range(len(ds)):
+        item = ds[idx][0]
+        f = item["frame_id"]
+        ahead.update(item.get("ref_ahead", {}))
+        assert ("ref_ahead" in item) == (f % 32 == 0)
+        queue += item["ref_l"]
+        if f % 8 == 0:
+            delivered[f] = queue
+            queue = []
+    assert sorted(ahead) == [8, 16, 24, 40, 48]
+    for fb, frames in ahead.items():
+        assert len(frames) == len(delivered[fb]) == 8
+        for a, b in zip(frames, delivered[fb]):
+            assert a is b                  # the same cached ImageList object -> the same frame
