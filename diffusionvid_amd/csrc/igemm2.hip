@@ -10,7 +10,11 @@
 // physical 16-byte chunk = logical chunk ^ ((row >> 2) & 3), conflict-free for ds_read_b128.
 // Two LDS stages of (BM+BN)*64 B and a half-tile fp32 epilogue buffer keep a workgroup at <= 33 KB,
 // so 4 workgroups (16 waves) share a CU and hide the DMA latency of each other's K steps.
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 #include "igemm_epilogue.h"
@@ -47,10 +51,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 //           COUNTED `s_waitcnt vmcnt(P)` (P = its DMA pieces per tile) so only the tile about to be read has
 //           landed, and re-fills the stage freed by the previous step right after the barrier.
 // WN: waves along N (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads); always 2 waves along M.
-// ILV (NSTAGE 2 only): the DMA pieces of the next K tile are issued between the MFMA groups of the current one
-//           instead of in front of them -- one piece costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md,
-//           "LDS-DMA piece issue cost"), which is hidden only while that wave's earlier MFMAs are still executing.
-template <int BM, int BN, int BKT, int NSTAGE, int WN, bool SMALLC, bool ILV = false>
+template <int BM, int BN, int BKT, int NSTAGE, int WN, bool SMALLC>
 __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     constexpr int NW = 2 * WN;                      // waves per workgroup
     constexpr int NT = 64 * NW;                     // threads
@@ -228,90 +229,38 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) choff[ks] = ((2 * ks + (lane >> 5)) ^ sw) * 16;
 
+    // Fragment reads run one K sub-step ahead of the MFMAs that consume them (two register sets), so that the LDS
+    // latency of sub-step ks+1 is covered by the MFMAs of sub-step ks (one wave per SIMD has nobody else to hide it).
+    auto load_frags = [&](const char* st, int ks, half8 (&fa)[TM], half8 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * ROW_BYTES + choff[ks]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * ROW_BYTES + choff[ks]);
+    };
     auto compute = [&](int stage) {
         const char* st = smem + stage * STAGE;
+        half8 fa[2][TM], fb[2][TN];
+        load_frags(st, 0, fa[0], fb[0]);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            half8 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * ROW_BYTES + choff[ks]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * ROW_BYTES + choff[ks]);
+            if (ks + 1 < KS) load_frags(st, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+        }
+        // pin the issue order the source spells out (hipcc otherwise folds the two register sets into one and waits
+        // for every read right before its MFMAs): reads(0), then per sub-step reads(ks+1) ahead of MFMAs(ks)
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
     };
 
-    if (NSTAGE == 2 && ILV) {
-        constexpr int P = A_IT + B_IT;
-        issue(kt0, 0);
-        __syncthreads();
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            const int cur = kt & 1;
-            const char* st = smem + cur * STAGE;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                half8 fa[TM], fb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * ROW_BYTES + choff[ks]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * ROW_BYTES + choff[ks]);
-                constexpr int NM = TM * TN;                      // MFMAs of this K sub-step; pieces go after MFMA number q
-#pragma unroll
-                for (int q = 0; q < NM; ++q) {
-                    acc[q / TN][q % TN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[q / TN], fb[q % TN], acc[q / TN][q % TN], 0, 0, 0);
-                    // pieces [ (ks*NM+q) * P / (KS*NM), (ks*NM+q+1) * P / (KS*NM) ) -- evenly spread over the tile's MFMAs
-                    const int lo = (ks * NM + q) * P / (KS * NM), hi = (ks * NM + q + 1) * P / (KS * NM);
-#pragma unroll
-                    for (int i = lo; i < hi; ++i) issue_piece(kt0 + kt + 1, cur ^ 1, i);
-                }
-            }
-            advance();
-            __syncthreads();
-        }
-        compute((nk - 1) & 1);
-        __syncthreads();
-    } else if (NSTAGE == 2 && p.ablate) {
-        // diagnostics: the same loop with one ingredient removed (results are garbage)
-        const bool no_mfma = p.ablate & 1, no_read = p.ablate & 2, no_dma = p.ablate & 4;
-        issue(kt0, 0);
-        __syncthreads();
-        half8 fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const half8*>(smem + fa_off + i * 32 * ROW_BYTES);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const half8*>(smem + fb_off + j * 32 * ROW_BYTES);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk && !no_dma) issue(kt0 + kt + 1, cur ^ 1);
-            const char* st = smem + cur * STAGE;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (!no_read) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * ROW_BYTES + choff[ks]);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * ROW_BYTES + choff[ks]);
-                }
-                if (!no_mfma) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i]));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[j]));
-                }
-            }
-            __syncthreads();
-        }
-    } else if (NSTAGE == 2) {
+    if (NSTAGE == 2) {
         issue(kt0, 0);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
@@ -363,81 +312,170 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         for (int e = 0; e < EROWS; ++e) {
             const int r = tid / VPR + e * ERPP;
             const int m = m0 + half * (BM / 2) + r;
-            if (m < p.M && n < p.Cout && !(p.ablate & 8)) igemm_store_row8(p, Cs + r * CP + c8, m, n, bias8, pre_ok, rpre[half][PRE ? e : 0]);
+            if (m < p.M && n < p.Cout) igemm_store_row8(p, Cs + r * CP + c8, m, n, bias8, pre_ok, rpre[half][PRE ? e : 0]);
         }
     }
 }
 
-template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC, int WN = 2, bool ILV = false>
+template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC, int WN = 2>
 int launch2(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     static const int rot_env = getenv("DVID_IGEMM_ROT") ? atoi(getenv("DVID_IGEMM_ROT")) : 0;
     p.krot = rot_env;
-    static const int abl_env = getenv("DVID_IGEMM_ABLATE") ? atoi(getenv("DVID_IGEMM_ABLATE")) : 0;
-    p.ablate = abl_env;
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.Cout, BN);
     constexpr int smem = Smem2<BM, BN, BKT, NSTAGE>::kBytes;
     if (smem > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC, ILV>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
     }
     const int nsplit = p.splitk > 1 ? p.splitk : 1;
-    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC, ILV>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(128 * WN), smem, s, p);
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(128 * WN), smem, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
 }
 
-template <int BKT, int NSTAGE, bool ILV = false>
-int dispatch2(const IgemmParams& p, hipStream_t s, bool smallc) {
-    if (smallc) return launch2<128, 64, BKT, NSTAGE, true, 2, ILV>(p, s);
-    static const int tile_env = getenv("DVID_IGEMM_TILE") ? atoi(getenv("DVID_IGEMM_TILE")) : 0;   // experiments only
-    if (tile_env == 1) return launch2<128, 128, BKT, NSTAGE, false, 2, ILV>(p, s);
-    if (tile_env == 2) return launch2<128, 64, BKT, NSTAGE, false, 2, ILV>(p, s);
-    if (tile_env == 3) return launch2<64, 64, BKT, NSTAGE, false, 2, ILV>(p, s);
-    if constexpr (BKT == 64 && NSTAGE == 2 && !ILV) {
-        if (tile_env == 4) return launch2<256, 256, 64, 2, false, 4>(p, s);
-        if (tile_env == 5) return launch2<256, 128, 64, 2, false, 2>(p, s);
-        if (tile_env == 6) return launch2<128, 256, 64, 2, false, 4>(p, s);
-        if (tile_env == 7) return launch2<256, 128, 64, 2, false, 4>(p, s);
-    }
-    // prefer the big tile while it still gives every CU ~2 workgroups
+// ---- tile configurations ----------------------------------------------------------------------------------------
+// Every configuration computes the same sums in the same order (K ascending, 16 at a time inside the MFMA), so the
+// choice changes the time of a layer and never its result.
+struct TileCfg {
+    int bm, bn, bkt, nstage;
+    int (*launch)(const IgemmParams&, hipStream_t);
+};
+const TileCfg kCfgs[] = {
+    {64, 64, 32, 2, &launch2<64, 64, 32, 2, false>},        {128, 64, 32, 2, &launch2<128, 64, 32, 2, false>},
+    {128, 128, 32, 2, &launch2<128, 128, 32, 2, false>},    {64, 64, 64, 2, &launch2<64, 64, 64, 2, false>},
+    {128, 64, 64, 2, &launch2<128, 64, 64, 2, false>},      {128, 128, 64, 2, &launch2<128, 128, 64, 2, false>},
+    {128, 256, 64, 2, &launch2<128, 256, 64, 2, false, 4>}, {256, 256, 64, 2, &launch2<256, 256, 64, 2, false, 4>},
+    {128, 128, 64, 3, &launch2<128, 128, 64, 3, false>},    {128, 64, 64, 3, &launch2<128, 64, 64, 3, false>},
+    {128, 128, 32, 3, &launch2<128, 128, 32, 3, false>},
+};
+constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
+const TileCfg kStemCfgs[] = {   // Cin == 8 stem (one filter tap per 16-byte chunk)
+    {128, 64, 32, 2, &launch2<128, 64, 32, 2, true>},
+    {128, 64, 64, 2, &launch2<128, 64, 64, 2, true>},
+};
+
+bool cfg_valid(const TileCfg& c, const IgemmParams& p) {
+    if (p.splitk > 1 && (p.Kpad / c.bkt) % p.splitk) return false;
+    if (c.bm > 128 && p.M < 2 * c.bm) return false;
+    if (c.bn > 64 && p.Cout <= c.bn / 2) return false;          // more than half of the tile would be padding
+    return true;
+}
+
+// the hand rule used without the tuner (DVID_IGEMM_TUNE=0) and as the tuner's starting point
+int heuristic_cfg(const IgemmParams& p) {
+    // Long-K layers are bound by the global->LDS staging rate: full 128-byte lines (BKT 64) win.  Short-K layers
+    // (<= 4 K steps) are bound by HBM traffic and the epilogue: the smaller LDS footprint of BKT 32 (4 resident
+    // workgroups per CU instead of 2) wins (measured per layer, tools/bench_igemm.py).
+    const int base = p.Kpad >= 512 ? 3 : 0;
     const int ns = p.splitk > 1 ? p.splitk : 1;
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.Cout, 128) * ns;
-    if (t128 >= 512 && p.Cout >= 128) return launch2<128, 128, BKT, NSTAGE, false, 2, ILV>(p, s);
+    if (t128 >= 512 && p.Cout >= 128) return base + 2;
     const long t12864 = (long)ceil_div(p.M, 128) * ceil_div(p.Cout, 64) * ns;
-    if (t12864 >= 512) return launch2<128, 64, BKT, NSTAGE, false, 2, ILV>(p, s);
-    return launch2<64, 64, BKT, NSTAGE, false, 2, ILV>(p, s);
+    return t12864 >= 512 ? base + 1 : base;
+}
+
+// ---- per-shape autotuning ---------------------------------------------------------------------------------------
+// The best tile depends on how M x N lands on 256 CUs (a 128x128 grid of 304 tiles runs two rounds, the second 19 %
+// full) and on whether the layer is staging-, MFMA- or epilogue-bound; rules of thumb lose 10-40 % on individual
+// layers (profiles/r01_igemm_tile_sweep.txt).  The first launch of every distinct problem shape therefore times each
+// valid configuration on the real operands (output redirected to a scratch buffer) and the winner is cached.
+struct ShapeKey {
+    int M, Cout, Kpad, Cin, ntaps, stride, res_mode, flags;
+    bool operator==(const ShapeKey& o) const {
+        return M == o.M && Cout == o.Cout && Kpad == o.Kpad && Cin == o.Cin && ntaps == o.ntaps && stride == o.stride &&
+               res_mode == o.res_mode && flags == o.flags;
+    }
+};
+struct ShapeHash {
+    size_t operator()(const ShapeKey& k) const {
+        size_t h = 1469598103934665603ull;
+        for (int v : {k.M, k.Cout, k.Kpad, k.Cin, k.ntaps, k.stride, k.res_mode, k.flags}) h = (h ^ (size_t)(unsigned)v) * 1099511628211ull;
+        return h;
+    }
+};
+std::mutex g_tune_mu;
+std::unordered_map<ShapeKey, int, ShapeHash> g_tuned;
+
+int tune_shape(const IgemmParams& p, hipStream_t s, const TileCfg* cfgs, int ncfg, int fallback, int* best_out) {
+    const size_t out_bytes = (size_t)p.M * p.ldc * (p.out_f32 ? 4 : 2) * (p.splitk > 1 ? p.splitk : 1);
+    void* scratch = nullptr;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMalloc(&scratch, out_bytes));
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    IgemmParams q = p;
+    q.out = scratch;
+    static const bool log = getenv("DVID_IGEMM_TUNE_LOG") != nullptr;
+    int best = fallback;
+    float best_ms = 1e30f;
+    for (int c = 0; c < ncfg; ++c) {
+        if (!cfg_valid(cfgs[c], p)) continue;
+        int rc = cfgs[c].launch(q, s);           // warm-up: code object load, L2 / MALL state
+        if (rc != DVID_OK) continue;
+        constexpr int kReps = 3;
+        HIP_TRY(hipEventRecord(a, s));
+        for (int r = 0; r < kReps; ++r) (void)cfgs[c].launch(q, s);
+        HIP_TRY(hipEventRecord(b, s));
+        HIP_TRY(hipEventSynchronize(b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, a, b));
+        ms /= kReps;
+        if (log)
+            fprintf(stderr, "[igemm tune] M %d N %d K %d taps %d res %d split %d : %dx%dx%d/%d  %.2f us\n", p.M, p.Cout, p.Kpad, p.ntaps,
+                    p.res_mode, p.splitk, cfgs[c].bm, cfgs[c].bn, cfgs[c].bkt, cfgs[c].nstage, ms * 1e3f);
+        if (ms < best_ms) {
+            best_ms = ms;
+            best = c;
+        }
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIP_TRY(hipFree(scratch));
+    if (log)
+        fprintf(stderr, "[igemm tune] M %d N %d K %d -> %dx%dx%d/%d (%.2f us, %.0f TFLOP/s)\n", p.M, p.Cout, p.Kpad, cfgs[best].bm,
+                cfgs[best].bn, cfgs[best].bkt, cfgs[best].nstage, best_ms * 1e3f, 2.0 * p.M * p.Cout * (double)p.alg_k / best_ms / 1e9);
+    *best_out = best;
+    return DVID_OK;
 }
 
 }  // namespace
 
 int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
-    static const int bkt_env = getenv("DVID_IGEMM_BK") ? atoi(getenv("DVID_IGEMM_BK")) : 0;
     if (p.Kpad % 64 != 0 || p.Kpad < 64) return DVID_ERR_ARG;
     const bool smallc = (p.Cin == 8 && p.KH * p.KW > 1);
     if (!smallc && (p.Cin % 64 != 0)) return DVID_ERR_UNSUPPORTED;
     if (p.res_mode == 2 && ((p.Ho | p.Wo) & 1)) return DVID_ERR_ARG;
     if (p.splitk > 1 && (!p.out_f32 || p.bias || p.relu || p.res_mode || smallc || (p.Kpad / 64) % p.splitk)) return DVID_ERR_ARG;
-    // Long-K layers are bound by the global->LDS staging rate: full 128-byte lines (BKT 64) win.  Short-K
-    // layers (<= 4 K steps) are bound by HBM traffic and the epilogue: the smaller LDS footprint of BKT 32
-    // (4 resident workgroups per CU instead of 2) wins (measured per layer, tools/bench_igemm.py).
-    static const int nst_env = getenv("DVID_IGEMM_STAGES") ? atoi(getenv("DVID_IGEMM_STAGES")) : 0;
-    // Long-K layers with N a multiple of 256 and enough rows: 128x256x64 tile, 8 waves, 3-stage DMA ring with counted
-    // vmcnt -- 85 FLOP per staged byte instead of 43 (128x64), one workgroup per CU, latency hidden by the ring.
-    static const int big_env = getenv("DVID_IGEMM_BIG") ? atoi(getenv("DVID_IGEMM_BIG")) : 0;
-    if (big_env && !smallc && p.splitk <= 1 && p.Kpad >= 512 && (p.Cout % 256) == 0 &&
-        (long)ceil_div(p.M, 128) * (p.Cout / 256) >= 128)
-        return launch2<128, 256, 64, 3, false, 4>(p, s);
-    const int bkt = bkt_env ? bkt_env : (p.Kpad >= 512 ? 64 : 32);
-    const int nst = nst_env ? nst_env : 2;
-    static const int ilv_env = getenv("DVID_IGEMM_ILV") ? atoi(getenv("DVID_IGEMM_ILV")) : 0;
-    if (ilv_env && nst == 2) return bkt == 32 ? dispatch2<32, 2, true>(p, s, smallc) : dispatch2<64, 2, true>(p, s, smallc);
-    if (bkt == 32) return nst == 3 ? dispatch2<32, 3>(p, s, smallc) : dispatch2<32, 2>(p, s, smallc);
-    return nst == 3 ? dispatch2<64, 3>(p, s, smallc) : dispatch2<64, 2>(p, s, smallc);
+    const TileCfg* cfgs = smallc ? kStemCfgs : kCfgs;
+    const int ncfg = smallc ? 2 : kNumCfg;
+    // experiment knobs: DVID_IGEMM_CFG=<index into the table> forces one configuration for every layer it is valid for
+    static const int cfg_env = getenv("DVID_IGEMM_CFG") ? atoi(getenv("DVID_IGEMM_CFG")) : -1;
+    static const bool tune = !(getenv("DVID_IGEMM_TUNE") && atoi(getenv("DVID_IGEMM_TUNE")) == 0);
+    int fallback = smallc ? (p.Kpad >= 512 ? 1 : 0) : heuristic_cfg(p);
+    if (!cfg_valid(cfgs[fallback], p)) fallback = smallc ? 0 : (p.Kpad >= 512 ? 3 : 0);
+    if (cfg_env >= 0 && cfg_env < ncfg && cfg_valid(cfgs[cfg_env], p)) return cfgs[cfg_env].launch(p, s);
+    if (!tune) return cfgs[fallback].launch(p, s);
+    const ShapeKey key{p.M, p.Cout, p.Kpad, p.Cin, p.ntaps, p.stride, p.res_mode,
+                       (p.out_f32 ? 1 : 0) | (p.res_f32 ? 2 : 0) | (smallc ? 4 : 0) | (p.splitk << 4) | (p.relu << 12)};
+    int cfg = -1;
+    {
+        std::lock_guard<std::mutex> lock(g_tune_mu);
+        auto it = g_tuned.find(key);
+        if (it != g_tuned.end()) {
+            cfg = it->second;
+        } else {
+            const int rc = tune_shape(p, s, cfgs, ncfg, fallback, &cfg);
+            if (rc != DVID_OK) return rc;
+            g_tuned.emplace(key, cfg);
+        }
+    }
+    return cfgs[cfg].launch(p, s);
 }
