@@ -47,9 +47,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 }
 
 // NSTAGE 2: one DMA tile in flight, `__syncthreads()` per K step (the compiler drains vmcnt there).
-// NSTAGE 3: ring of three stages, two DMA tiles in flight across a raw `s_barrier`; each wave waits with a
-//           COUNTED `s_waitcnt vmcnt(P)` (P = its DMA pieces per tile) so only the tile about to be read has
-//           landed, and re-fills the stage freed by the previous step right after the barrier.
+// NSTAGE 3, 4: ring of stages, NSTAGE - 1 DMA tiles in flight across a raw `s_barrier`; each wave waits with a
+//           COUNTED `s_waitcnt vmcnt((NSTAGE - 2) * P)` (P = its DMA pieces per tile) so only the tile about to be
+//           read has landed, and re-fills the stage freed by the previous step right after the barrier.
 // WN: waves along N (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads); always 2 waves along M.
 template <int BM, int BN, int BKT, int NSTAGE, int WN, bool SMALLC>
 __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     constexpr int KEY_SHIFT = (BKT == 64) ? 1 : 2;  // swizzle key = (row >> KEY_SHIFT) & (CHUNKS - 1)
     constexpr int TM = BM / 64, TN = BN / (32 * WN);   // 32x32 MFMA tiles per wave (waves 2 x WN)
     constexpr int A_IT = BM / RPP / NW, B_IT = BN / RPP / NW;   // DMA pieces per wave per K tile
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
     static_assert(A_IT >= 1 && B_IT >= 1 && A_IT * RPP * NW == BM && B_IT * RPP * NW == BN, "tile / wave-count mismatch");
     constexpr int A_BYTES = BM * ROW_BYTES;
     constexpr int STAGE = Smem2<BM, BN, BKT, NSTAGE>::kStage;
@@ -271,13 +272,19 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         }
     } else {
         constexpr int P = A_IT + B_IT;          // DMA instructions per wave per K tile
-        issue(kt0, 0);
-        if (nk > 1) issue(kt0 + 1, 1);
-        int cs = 0, is = 2;                     // stage being computed / stage to refill
+        constexpr int AHEAD = NSTAGE - 1;       // K tiles issued before the first one is consumed
+#pragma unroll
+        for (int d = 0; d < AHEAD; ++d)
+            if (d < nk) issue(kt0 + d, d);
+        int cs = 0, is = AHEAD;                 // stage being computed / stage to refill
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) wait_vmcnt<P>(); else wait_vmcnt<0>();
+            // tiles still allowed in flight while tile kt is read: the AHEAD - 1 issued after it (fewer at the tail)
+            const int later = nk - 1 - kt;
+            if (later >= AHEAD - 1) wait_vmcnt<(AHEAD - 1) * P>();
+            else if (AHEAD > 2 && later == 1) wait_vmcnt<P>();
+            else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();       // tile kt visible to all waves; stage `is` no longer read
-            if (kt + 2 < nk) issue(kt0 + kt + 2, is);
+            if (kt + AHEAD < nk) issue(kt0 + kt + AHEAD, is);
             compute(cs);
             cs = (cs == NSTAGE - 1) ? 0 : cs + 1;
             is = (is == NSTAGE - 1) ? 0 : is + 1;
@@ -352,7 +359,10 @@ const TileCfg kCfgs[] = {
     {128, 64, 64, 2, &launch2<128, 64, 64, 2, false>},      {128, 128, 64, 2, &launch2<128, 128, 64, 2, false>},
     {128, 256, 64, 2, &launch2<128, 256, 64, 2, false, 4>}, {256, 256, 64, 2, &launch2<256, 256, 64, 2, false, 4>},
     {128, 128, 64, 3, &launch2<128, 128, 64, 3, false>},    {128, 64, 64, 3, &launch2<128, 64, 64, 3, false>},
-    {128, 128, 32, 3, &launch2<128, 128, 32, 3, false>},
+    {128, 128, 32, 3, &launch2<128, 128, 32, 3, false>},    {128, 256, 32, 3, &launch2<128, 256, 32, 3, false, 4>},
+    {256, 256, 32, 3, &launch2<256, 256, 32, 3, false, 4>}, {256, 256, 32, 2, &launch2<256, 256, 32, 2, false, 4>},
+    {128, 64, 32, 3, &launch2<128, 64, 32, 3, false>},      {128, 128, 32, 4, &launch2<128, 128, 32, 4, false>},
+    {128, 256, 32, 4, &launch2<128, 256, 32, 4, false, 4>}, {128, 64, 32, 4, &launch2<128, 64, 32, 4, false>},
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 const TileCfg kStemCfgs[] = {   // Cin == 8 stem (one filter tap per 16-byte chunk)
