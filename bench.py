@@ -13,13 +13,22 @@ value = frames emitted by all ranks / max-over-ranks wall time (barrier + device
 N > 1: one process per GPU, each rank owns whole videos (weak scaling, no data-path collective); the
 single RCCL gather of the predictions to rank 0 is inside the timed region.
 
+Schedule: INPUT.LOOKAHEAD_BATCHES (--lookahead, default 3) 8-frame batches share one launch sequence of the
+per-frame-independent stages (backbone + 3 extraction heads); --lookahead 1 is the reference's schedule and gives
+identical detections (tests/test_gpu_e2e.py::test_lookahead_batches_do_not_change_results).
+
 Extra objects on the JSON line:
-  roofline     the dominant kernel is the implicit-GEMM MFMA conv/linear kernel (igemm_kernel<...>);
-               achieved = algorithmic FLOP of all its launches / summed launch durations, measured with
-               HIP events on the launch stream in an instrumented repeat of one step right after the
-               timed region; peak = 2500 TFLOP/s dense fp16 MFMA (MI355X_MICROARCH.md).
+  roofline     the dominant kernel is the implicit-GEMM MFMA conv/linear kernel (igemm2_kernel<...>, ~78 % of the
+               GPU time, profiles/r01c_kernel_stats.txt).  An instrumented repeat of one step right after the timed
+               region brackets every launch with HIP events on its launch stream (sub-batch chains off, so launches
+               do not overlap) and sums durations, algorithmic FLOP (2*M*N*K) and algorithmic HBM bytes (input +
+               weights + output + residual, each once).  The bound is the lower roof at the measured intensity
+               (ridge = 2500 TFLOP/s / 8 TB/s = 312 FLOP/B, MI355X_MICROARCH.md): below the ridge
+               achieved/peak are GB/s against 8000, above it TFLOP/s against 2500; both fractions are always
+               printed (hbm_frac, mfma_frac).  traffic = measured HBM bytes per launch from the committed
+               rocprofv3 --pmc passes (tools/profile_round.sh).
   cpu_baseline the CPU oracle (oracle/, PyTorch CPU fp32, a port of the reference path) timed on the host
-               cores of this box on ONE steady-state batch of 8 frames at the same size.
+               cores of this box on ONE steady-state call of 4 frames at the same size.
 """
 import argparse
 import ctypes
@@ -41,7 +50,9 @@ from diffusionvid_amd.engine import inference as engine  # noqa: E402
 from diffusionvid_amd.modeling.detector import build_detection_model  # noqa: E402
 from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
+TRAFFIC_FILE = "r01c_pmc_igemm_traffic.json"
 PEAK_FP16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
 
 
 def run_video(model, ds, device):
@@ -171,22 +182,36 @@ def main():
     engine_model.set_chains(int(os.environ.get("DVID_CHAINS", "2")))
     ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     _lib.check(lib.dvid_profile_read(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), "dvid_profile_read")
+    ab = ctypes.c_double()
+    _lib.check(lib.dvid_profile_read_bytes(ctypes.byref(ab)), "dvid_profile_read_bytes")
     lib.dvid_profile_enable(0)
     if os.environ.get("DVID_PROFILE_DUMP") and rank == 0:
         lib.dvid_profile_dump(os.environ["DVID_PROFILE_DUMP"].encode())
     lib.dvid_profile_reset()
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_igemm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected in-process)
         traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
     if ms.value > 0:
-        achieved = fl.value / (ms.value * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, fp16 MFMA)",
-                    "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01_pmc_igemm_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, bytes per launch)",
+        sec = ms.value * 1e-3
+        tflops = fl.value / sec / 1e12
+        gbs = ab.value / sec / 1e9
+        intensity = fl.value / max(ab.value, 1.0)                    # algorithmic FLOP per HBM byte over all igemm launches
+        ridge = PEAK_FP16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)       # 312 FLOP/B: below it the HBM roof is the lower one
+        hbm_bound = intensity < ridge
+        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": "igemm2_kernel (implicit-GEMM conv/linear, fp16 MFMA)",
+                    "achieved": round(gbs if hbm_bound else tflops, 2), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_FP16_TFLOPS,
+                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                    "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of tools/profile_round.sh on a 64-frame "
+                                      "video, bytes per launch; its own algorithmic figure is in the file)" % TRAFFIC_FILE,
+                    "alg_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+                    "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_FP16_TFLOPS, 4),
+                    "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "alg_mbytes_per_launch": round(ab.value / max(1, nl.value) / 1e6, 2),
+                    "alg_gflop_per_launch": round(fl.value / max(1, nl.value) / 1e9, 3),
                     "launches_per_step": int(nl.value), "avg_launch_us": round(ms.value * 1e3 / max(1, nl.value), 2),
-                    "kernel_ms_per_step": round(ms.value, 2), "alg_gflop_per_launch": round(fl.value / max(1, nl.value) / 1e9, 3)}
+                    "kernel_ms_per_step": round(ms.value, 2)}
 
     if rank == 0:
         line = {

@@ -63,6 +63,7 @@ SIGNATURES = {
     "dvid_profile_reset": (c_int, []),
     "dvid_profile_dump": (c_int, [C.c_char_p]),
     "dvid_profile_read": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int64)]),
+    "dvid_profile_read_bytes": (c_int, [C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -412,6 +412,29 @@ struct ShapeHash {
 std::mutex g_tune_mu;
 std::unordered_map<ShapeKey, int, ShapeHash> g_tuned;
 
+// DVID_IGEMM_TUNE_CACHE=<file>: winners are appended as they are found and read back at the first launch of the next
+// process, so a deployment (or a profiling run) starts without the timing launches.  One line per shape:
+// M Cout Kpad Cin ntaps stride res_mode flags cfg table_size
+void tune_cache_load() {
+    const char* path = getenv("DVID_IGEMM_TUNE_CACHE");
+    if (!path) return;
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    ShapeKey k;
+    int cfg, n;
+    while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d", &k.M, &k.Cout, &k.Kpad, &k.Cin, &k.ntaps, &k.stride, &k.res_mode, &k.flags, &cfg, &n) == 10)
+        if (cfg >= 0 && ((k.flags & 4) ? (n == 2 && cfg < 2) : (n == kNumCfg && cfg < kNumCfg))) g_tuned[k] = cfg;
+    fclose(f);
+}
+void tune_cache_append(const ShapeKey& k, int cfg, int n) {
+    const char* path = getenv("DVID_IGEMM_TUNE_CACHE");
+    if (!path) return;
+    if (FILE* f = fopen(path, "a")) {
+        fprintf(f, "%d %d %d %d %d %d %d %d %d %d\n", k.M, k.Cout, k.Kpad, k.Cin, k.ntaps, k.stride, k.res_mode, k.flags, cfg, n);
+        fclose(f);
+    }
+}
+
 int tune_shape(const IgemmParams& p, hipStream_t s, const TileCfg* cfgs, int ncfg, int fallback, int* best_out) {
     const size_t out_bytes = (size_t)p.M * p.ldc * (p.out_f32 ? 4 : 2) * (p.splitk > 1 ? p.splitk : 1);
     void* scratch = nullptr;
@@ -478,6 +501,11 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
     int cfg = -1;
     {
         std::lock_guard<std::mutex> lock(g_tune_mu);
+        static bool loaded = false;
+        if (!loaded) {
+            loaded = true;
+            tune_cache_load();
+        }
         auto it = g_tuned.find(key);
         if (it != g_tuned.end()) {
             cfg = it->second;
@@ -485,6 +513,7 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
             const int rc = tune_shape(p, s, cfgs, ncfg, fallback, &cfg);
             if (rc != DVID_OK) return rc;
             g_tuned.emplace(key, cfg);
+            tune_cache_append(key, cfg, ncfg);
         }
     }
     return cfgs[cfg].launch(p, s);

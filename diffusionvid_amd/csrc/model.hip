@@ -41,7 +41,7 @@ void set_err(const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 struct ProfRec {
     hipEvent_t a, b;
-    double flop;
+    double flop, bytes;
     int M, N, K, taps, stride, res_mode;
 };
 bool g_prof_on = false;
@@ -59,6 +59,11 @@ int igemm(const IgemmParams& p, hipStream_t s) {
         HIP_TRY(hipEventCreate(&r.b));
     }
     r.flop = 2.0 * p.M * (double)p.Cout * (double)p.alg_k;
+    // algorithmic HBM bytes: every operand touched once (input pixels, packed weights, output, residual)
+    const double in_px = (double)p.M * (p.ntaps > 1 ? p.stride * p.stride : 1);
+    r.bytes = in_px * p.Cin * 2.0 + (double)p.Cout * p.Kpad * 2.0 +
+              (double)p.M * p.Cout * (p.out_f32 ? 4.0 : 2.0) * (p.splitk > 1 ? p.splitk : 1) +
+              (p.res_mode == 1 ? (double)p.M * p.Cout * (p.res_f32 ? 4.0 : 2.0) : p.res_mode == 2 ? (double)p.M * p.Cout * 0.5 : 0.0);
     r.M = p.M;
     r.N = p.Cout;
     r.K = p.Kpad;
@@ -1148,6 +1153,14 @@ int dvid_profile_reset(void) {
     g_prof.clear();
     return DVID_OK;
 }
+int dvid_profile_read_bytes(double* igemm_alg_bytes) {
+    g_err[0] = 0;
+    double b = 0;
+    for (auto& r : g_prof) b += r.bytes;
+    if (igemm_alg_bytes) *igemm_alg_bytes = b;
+    return DVID_OK;
+}
+
 int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches) {
     g_err[0] = 0;
     double ms = 0, fl = 0;

@@ -160,6 +160,8 @@ int dvid_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
 int dvid_profile_enable(int on);
 int dvid_profile_reset(void);
 int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches);
+/* sum over the recorded launches of the algorithmic HBM bytes (input + weights + output + residual, each touched once) */
+int dvid_profile_read_bytes(double* igemm_alg_bytes);
 /* CSV (M,N,K,taps,stride,res_mode,ms,tflops), one line per recorded igemm launch */
 int dvid_profile_dump(const char* path);
 

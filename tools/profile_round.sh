@@ -1,0 +1,59 @@
+#!/bin/bash
+# Round profile on the GPU box: per-kernel time (rocprofv3 --kernel-trace --stats) and HBM traffic of the igemm kernel
+# (separate --pmc passes, MI355X_MICROARCH.md HBM section) for the bench.py workload.  Writes gpurun_out/<tag>_*.
+#   gpurun -- 'bash tools/profile_round.sh r01c'
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+export DVID_CHAINS=1            # sequential launches: per-kernel durations are not inflated by overlap
+CMD="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+# tile-tuner timing launches would pollute the statistics: fill the tuning cache in an unprofiled run first
+export DVID_IGEMM_TUNE_CACHE=/tmp/dvid_tune_cache.txt
+rm -f $DVID_IGEMM_TUNE_CACHE
+$CMD > /tmp/prof_pre.log 2>&1
+$CMD --frames 64 > /tmp/prof_pre64.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- $CMD > /tmp/prof_stats.log 2>&1
+grep '^{"metric"' /tmp/prof_stats.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -o pmc -- $CMD --frames 64 > /tmp/prof_$C.log 2>&1
+done
+python - "$TAG" "$OUT" <<'PY'
+import csv, glob, json, sys
+tag, out = sys.argv[1], sys.argv[2]
+f = glob.glob("/tmp/prof_stats/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+with open(f"{out}/{tag}_kernel_stats.txt", "w") as o:
+    o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline  (DVID_CHAINS=1; 4 videos of 304 frames:\n")
+    o.write("# warm-up, timed step, tuner warm-up and instrumented pass)\n")
+    o.write("total kernel time %.1f ms\n" % (tot / 1e6))
+    ig = [r for r in rows if "igemm2_kernel" in r["Name"]]
+    igt = sum(float(r["TotalDurationNs"]) for r in ig); igc = sum(int(r["Calls"]) for r in ig)
+    o.write("igemm2_kernel (all instantiations): calls %d total %.2f ms avg %.2f us  %.1f%%\n" % (igc, igt / 1e6, igt / igc / 1e3, 100 * igt / tot))
+    for r in rows[:40]:
+        o.write("%-100s calls %7s total %9.2f ms avg %9.1f us %5.1f%%\n" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = glob.glob(f"/tmp/prof_{c}/**/*counter_collection.csv", recursive=True)
+    s = n = 0.0
+    for fn in fs:
+        for r in csv.DictReader(open(fn)):
+            if "igemm2_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                s += float(r["Counter_Value"]); n += 1
+    res[c] = (s, n)
+if res["FETCH_SIZE"][1] and res["WRITE_SIZE"][1]:
+    fetch = res["FETCH_SIZE"][0] / res["FETCH_SIZE"][1] * 1024 * 2       # KiB units; gfx950 counts 128-B requests at 64 B
+    write = res["WRITE_SIZE"][0] / res["WRITE_SIZE"][1] * 1024
+    same = json.loads([l for l in open("/tmp/prof_FETCH_SIZE.log") if l.startswith('{"metric"')][-1])["roofline"]
+    json.dump({"kernel": "igemm2_kernel (all instantiations)", "launches": int(res["FETCH_SIZE"][1]),
+               "alg_bytes_per_launch_same_run": same["alg_mbytes_per_launch"] * 1e6,
+               "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
+               "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 "
+                         "--warmup 1 --frames 64 --no-cpu-baseline, DVID_CHAINS=1; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                         "(gfx950 counts 128-B requests at 64 B); WRITE_SIZE uncorrected", "round": 1},
+              open(f"{out}/{tag}_pmc_igemm_traffic.json", "w"), indent=1)
+else:
+    open(f"{out}/{tag}_pmc_error.txt", "w").write(repr(res) + "\n" + open("/tmp/prof_FETCH_SIZE.log").read()[-3000:])
+PY
