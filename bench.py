@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--frames", type=int, default=304, help="frames per synthetic video")
     ap.add_argument("--lookahead", type=int, default=3,
                     help="INPUT.LOOKAHEAD_BATCHES: 8-frame batches whose backbone + extraction heads share one launch (1 = reference schedule)")
+    ap.add_argument("--arch", choices=("r101", "swinb"), default="r101",
+                    help="r101 = the BASELINE.json headline configuration; swinb = configs/vid_Swin_B_DiffusionVID.yaml (INFER_BATCH 4)")
+    ap.add_argument("--sample-step", type=int, default=1, help="MODEL.DiffusionDet.SAMPLE_STEP (4 = the x4 configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,7 +129,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         comm.init_dist("nccl")
 
-    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", args.lookahead],
+    headline = args.arch == "r101" and args.sample_step == 1
+    yaml = "configs/vid_R_101_DiffusionVID.yaml" if args.arch == "r101" else "configs/vid_Swin_B_DiffusionVID.yaml"
+    cfg = get_cfg(os.path.join(ROOT, yaml), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", args.lookahead,
+                                             "MODEL.DiffusionDet.SAMPLE_STEP", args.sample_step],
                   os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
     cfg.freeze()
     model = build_detection_model(cfg).to(device).eval()
@@ -215,18 +221,19 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "frames/sec (1000x600) DiffusionVID-R101 x1",
+            "metric": "frames/sec (1000x600) DiffusionVID-%s x%d" % ("R101" if args.arch == "r101" else "SwinB", args.sample_step),
             "value": round(total_frames / dt, 2), "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "ResNet-101 DiffusionVID x1 fp16, 300 boxes, 1 DDIM step; one step = one synthetic "
-                                   "%d-frame 1000x600 video per GPU (24 global + %d local frames, %d batches of 8)"
-                                   % (L, L, (L + 7) // 8),
-                       "frames_per_step_per_gpu": L, "infer_batch": 8, "lookahead_batches": args.lookahead,
+            "config": {"workload": "%s DiffusionVID x%d fp16, 300 boxes, %d DDIM step(s); one step = one synthetic "
+                                   "%d-frame 1000x600 video per GPU (24 global + %d local frames, %d batches of %d)"
+                                   % ("ResNet-101" if args.arch == "r101" else "Swin-Base", args.sample_step, args.sample_step, L, L,
+                                      -(-L // cfg.INPUT.INFER_BATCH), cfg.INPUT.INFER_BATCH),
+                       "frames_per_step_per_gpu": L, "infer_batch": cfg.INPUT.INFER_BATCH, "lookahead_batches": args.lookahead,
                        "parallelism": "videos sharded across ranks"},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and headline and not args.no_cpu_baseline:
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             frames8 = [ds.frame(0, i).tensors.cpu() for i in range(8, 12)]
             line["cpu_baseline"] = cpu_baseline(cfg, sd, frames8, H, W)

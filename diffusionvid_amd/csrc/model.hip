@@ -179,7 +179,8 @@ struct dvid_model {
     DevBuf img8, bufX, bufY, bufT1, bufT2, bufSC, c3, c4, c5, lat[3];
     DevBuf sw_x, sw_x2, sw_ln16, sw_qkv16, sw_attn16, sw_h16;   // Swin token buffers
     DevBuf roi, params, dyn, qkv, attn16, f32a, f32b, f32c, f32d, h16a, h16b, hid16, ss, deltas, kvproj, mem16, splitk, vt;
-    std::map<int, std::vector<int64_t>> ss_keys;  // per head slot: t vector of the uploaded scale/shift table
+    std::map<std::pair<int, std::vector<int64_t>>, DevBuf> ss_tables;   // (head slot, t vector) -> device scale/shift table
+    std::map<std::pair<int, int64_t>, std::vector<float>> ss_rows;     // (head slot, t) -> host row [bt_out]
 
     // sub-batch chains (see dvid_backbone_resnet_fpn)
     int nchain = 2;
@@ -574,6 +575,7 @@ int dvid_model_destroy(dvid_model* m) {
                       &m->lat[1], &m->lat[2], &m->roi, &m->params, &m->dyn, &m->qkv, &m->attn16, &m->f32a, &m->f32b, &m->f32c,
                       &m->f32d, &m->h16a, &m->h16b, &m->hid16, &m->ss, &m->deltas, &m->kvproj, &m->mem16, &m->splitk, &m->vt};
     for (DevBuf* b : bufs) b->release();
+    for (auto& kv : m->ss_tables) kv.second.release();
     delete m;
     return DVID_OK;
 }
@@ -928,30 +930,43 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int d = m->cfg.hidden_dim, M = boxes_per_frame;
 
-    // --- time conditioning (box_head.py:533-536 / :645): host-side, cached on the t vector ---
+    // --- time conditioning (box_head.py:533-536 / :645): scale/shift rows are a function of (head, t) only; they are
+    // computed once on the host and every distinct (head, t vector) keeps its device table, so the steady state --
+    // including the 4 alternating time steps of the x4 sampler -- does no host math, no upload and no stream sync.
     const int slot = (is_cond ? m->cfg.num_heads : 0) + head_index;
-    float* ss_dev = m->ss.as<float>() + (size_t)slot * m->ws_frames * 2 * d;
+    const float* ss_dev = nullptr;
     {
-        std::vector<int64_t> key(t, t + n_frames);
-        // one cache entry per slot: re-upload only when this slot's t vector changes
-        auto& prev = m->ss_keys[slot];
-        if (prev != key) {
+        std::pair<int, std::vector<int64_t>> key(slot, std::vector<int64_t>(t, t + n_frames));
+        auto it = m->ss_tables.find(key);
+        if (it == m->ss_tables.end()) {
+            if (m->ss_tables.size() >= 512) {          // unbounded t streams: start over rather than grow for ever
+                HIP_TRY(hipDeviceSynchronize());
+                for (auto& kv : m->ss_tables) kv.second.release();
+                m->ss_tables.clear();
+            }
             std::vector<float> tab((size_t)n_frames * hw.bt_out);
             const int td = 4 * d;
             for (int f = 0; f < n_frames; ++f) {
-                const std::vector<float>& te = time_embedding(m, t[f]);
-                std::vector<float> sl(td);
-                for (int i = 0; i < td; ++i) sl[i] = te[i] / (1.f + expf(-te[i]));  // SiLU
-                for (int o = 0; o < hw.bt_out; ++o) {
-                    double acc = hw.bt_b[o];
-                    for (int i = 0; i < td; ++i) acc += (double)hw.bt_w[(size_t)o * td + i] * sl[i];
-                    tab[(size_t)f * hw.bt_out + o] = (float)acc;
+                auto& row = m->ss_rows[std::make_pair(slot, t[f])];
+                if (row.empty()) {
+                    const std::vector<float>& te = time_embedding(m, t[f]);
+                    std::vector<float> sl(td);
+                    for (int i = 0; i < td; ++i) sl[i] = te[i] / (1.f + expf(-te[i]));  // SiLU
+                    row.resize(hw.bt_out);
+                    for (int o = 0; o < hw.bt_out; ++o) {
+                        double acc = hw.bt_b[o];
+                        for (int i = 0; i < td; ++i) acc += (double)hw.bt_w[(size_t)o * td + i] * sl[i];
+                        row[o] = (float)acc;
+                    }
                 }
+                memcpy(&tab[(size_t)f * hw.bt_out], row.data(), (size_t)hw.bt_out * sizeof(float));
             }
-            HIP_TRY(hipMemcpyAsync(ss_dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));  // `tab` is a stack temporary; happens once per distinct t vector
-            prev = key;
+            DevBuf buf;
+            TRY(buf.ensure(tab.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(buf.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));   // once per distinct key
+            it = m->ss_tables.emplace(std::move(key), buf).first;
         }
+        ss_dev = it->second.as<float>();
     }
 
     // Frames are independent inside a head (self-attention is per frame): run them as sub-batch chains on separate

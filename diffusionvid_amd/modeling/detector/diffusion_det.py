@@ -177,6 +177,24 @@ class DiffusionDet(nn.Module):
             return self.noise_fn(kind, frame_id, step, image, shape).to(self.device, torch.float32)
         return torch.randn(shape, device=self.device)
 
+    def _noise_images(self, kind, frame_id, step, batch, shape):
+        """[batch, *shape]: one draw per image of the batch, uploaded as ONE tensor (an injected noise_fn draws on the host)"""
+        if self.noise_fn is not None:
+            host = torch.stack([self.noise_fn(kind, frame_id, step, i, shape) for i in range(batch)])
+            return host.to(self.device, torch.float32)
+        return torch.randn((batch,) + tuple(shape), device=self.device)
+
+    def _ddim_draws(self, batch, frame_id, pairs):
+        """every random draw of the DDIM loop of one call (diffusion_det.py:542,:587,:595), made before any kernel of the
+        call is queued -- see the note on uploads in _forward_test"""
+        M = self.num_proposals
+        draws = {"img": self._noise("img", frame_id, 0, 0, (batch, M, 4))}
+        for step, (time, time_next) in enumerate(pairs):
+            if time_next >= 0:
+                draws[step] = (self._noise_images("ddim", frame_id, step, batch, (M, 4)),
+                               self._noise_images("renew", frame_id, step, batch, (M, 4)))
+        return draws
+
     # ---- forward (diffusion_det.py:306-336) ---------------------------------------------------
     def forward(self, images, targets=None):
         if self.training:
@@ -223,6 +241,9 @@ class DiffusionDet(nn.Module):
         whwh = (float(w), float(h))
         eng = self._get_engine()
         M = self.num_proposals
+        batch = min(self.infer_batch, end_id - frame_id + 1)
+        pairs = self._time_pairs()
+        ddim_draws = self._ddim_draws(batch, frame_id, pairs) if self.sampling_timesteps > 1 else None
 
         # 1. features + extraction pass over [local frames | global frames] in splits of INFER_BATCH.  Every stage here
         # (backbone, the 3 RCNNHeads, top-k feature selection) is per-frame independent, so the splits -- and with
@@ -321,11 +342,9 @@ class DiffusionDet(nn.Module):
             self.queue.append((splits[0], i))
 
         # current batch (diffusion_det.py:515-523)
-        batch = min(self.infer_batch, end_id - frame_id + 1)
         entries = [self.queue[i] for i in range(self.key_frame_location, self.key_frame_location + batch)]
         feats_cur, cached = self._gather_entries(entries)
 
-        pairs = self._time_pairs()
         if self.sampling_timesteps == 1:
             # x1: the randn `img` of diffusion_det.py:542 never reaches the output (the head pops the cached
             # stages, box_head.py:300-302) and the DDIM update after the single step is dead code (:573-575)
@@ -337,7 +356,7 @@ class DiffusionDet(nn.Module):
             if self.debug_taps is not None:
                 self.debug_taps["final_0"] = (outputs_class[-1], outputs_coord[-1])
         else:
-            ob, osc, ol, oc = self._ddim_ensemble(feats_cur, whwh, batch, frame_id, pairs, w, h)
+            ob, osc, ol, oc = self._ddim_ensemble(feats_cur, whwh, batch, frame_id, pairs, w, h, ddim_draws)
         return self._to_boxlists(ob, osc, ol, oc, (int(w), int(h)))
 
     # ---- helpers --------------------------------------------------------------------------------
@@ -361,17 +380,13 @@ class DiffusionDet(nn.Module):
         return ([f.index_select(0, sel) for f in src["feats"]],
                 tuple(src[k].index_select(0, sel) for k in ("logits", "boxes", "obj")))
 
-    def _ddim_ensemble(self, feats_cur, whwh, batch, frame_id, pairs, w, h):
+    def _ddim_ensemble(self, feats_cur, whwh, batch, frame_id, pairs, w, h, draws=None):
         """SAMPLE_STEP > 1 (diffusion_det.py:551-627): every step re-runs the 3 heads + global attention +
         cond head on the current noisy boxes, renews low-score boxes, and all but the last step feed the
         NMS ensemble."""
-        M = self.num_proposals
-        img = self._noise("img", frame_id, 0, 0, (batch, M, 4))
-        draws = {}                     # all DDIM / renewal noise up front (see the note on uploads in _forward_test)
-        for step, (time, time_next) in enumerate(pairs):
-            if time_next >= 0:
-                draws[step] = (torch.stack([self._noise("ddim", frame_id, step, i, (M, 4)) for i in range(batch)]),
-                               torch.stack([self._noise("renew", frame_id, step, i, (M, 4)) for i in range(batch)]))
+        if draws is None:
+            draws = self._ddim_draws(batch, frame_id, pairs)
+        img = draws["img"]
         coef = {t: (float(self._sr_host[t]), float(self._srm1_host[t])) for t, _ in pairs}
         ens_logits, ens_boxes = [], []
         for step, (time, time_next) in enumerate(pairs):

@@ -16,8 +16,8 @@ $CMD > /tmp/prof_pre.log 2>&1
 $CMD --frames 64 > /tmp/prof_pre64.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- $CMD > /tmp/prof_stats.log 2>&1
 grep '^{"metric"' /tmp/prof_stats.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -o pmc -- $CMD --frames 64 > /tmp/prof_$C.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -o pmc -- $CMD --frames 64 > /tmp/prof_$C.log 2>&1
 done
 python - "$TAG" "$OUT" <<'PY'
 import csv, glob, json, sys
@@ -43,12 +43,27 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if "igemm2_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
                 s += float(r["Counter_Value"]); n += 1
     res[c] = (s, n)
+def per_kernel(c):
+    s = n = 0.0
+    for fn in glob.glob(f"/tmp/prof_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if "igemm2_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                s += float(r["Counter_Value"]); n += 1
+    return s, n
+mb, _ = per_kernel("SQ_VALU_MFMA_BUSY_CYCLES")
+ga, _ = per_kernel("GRBM_GUI_ACTIVE")
+mfma_busy = None
+if mb and ga:
+    # MFMA_BUSY_CYCLES sums over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (MI355X_MICROARCH.md counter notes)
+    mfma_busy = mb / 1024.0 / (ga / 8.0)
 if res["FETCH_SIZE"][1] and res["WRITE_SIZE"][1]:
     fetch = res["FETCH_SIZE"][0] / res["FETCH_SIZE"][1] * 1024 * 2       # KiB units; gfx950 counts 128-B requests at 64 B
     write = res["WRITE_SIZE"][0] / res["WRITE_SIZE"][1] * 1024
     same = json.loads([l for l in open("/tmp/prof_FETCH_SIZE.log") if l.startswith('{"metric"')][-1])["roofline"]
     json.dump({"kernel": "igemm2_kernel (all instantiations)", "launches": int(res["FETCH_SIZE"][1]),
                "alg_bytes_per_launch_same_run": same["alg_mbytes_per_launch"] * 1e6,
+               "mfma_busy_fraction": mfma_busy,
+               "mfma_busy_method": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs over sum(GRBM_GUI_ACTIVE) / 8 XCDs, igemm2 launches only",
                "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 "
                          "--warmup 1 --frames 64 --no-cpu-baseline, DVID_CHAINS=1; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md "
