@@ -59,6 +59,8 @@ SIGNATURES = {
     "dvid_nhwc_from_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dvid_nchw_from_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dvid_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "dvid_igemm_num_configs": (c_int, []),
+    "dvid_igemm_set_config": (c_int, [c_int]),
     "dvid_profile_enable": (c_int, [c_int]),
     "dvid_profile_reset": (c_int, []),
     "dvid_profile_dump": (c_int, [C.c_char_p]),

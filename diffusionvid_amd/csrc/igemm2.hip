@@ -16,6 +16,7 @@
 #include <mutex>
 #include <unordered_map>
 
+#include "../../include/dvid_hip.h"
 #include "common.h"
 #include "igemm_epilogue.h"
 #include "kernels.h"
@@ -410,6 +411,7 @@ struct ShapeHash {
     }
 };
 std::mutex g_tune_mu;
+int g_forced_cfg = -2;          // -2: follow DVID_IGEMM_CFG; -1: tuner; >= 0: forced table index
 std::unordered_map<ShapeKey, int, ShapeHash> g_tuned;
 
 // DVID_IGEMM_TUNE_CACHE=<file>: winners are appended as they are found and read back at the first launch of the next
@@ -480,6 +482,14 @@ int tune_shape(const IgemmParams& p, hipStream_t s, const TileCfg* cfgs, int ncf
 
 }  // namespace
 
+int dvid_igemm_num_configs(void) { return kNumCfg; }
+
+int dvid_igemm_set_config(int cfg) {
+    if (cfg < -1 || cfg >= kNumCfg) return DVID_ERR_ARG;
+    g_forced_cfg = cfg;
+    return DVID_OK;
+}
+
 int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
     if (p.Kpad % 64 != 0 || p.Kpad < 64) return DVID_ERR_ARG;
@@ -489,8 +499,10 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
     if (p.splitk > 1 && (!p.out_f32 || p.bias || p.relu || p.res_mode || smallc || (p.Kpad / 64) % p.splitk)) return DVID_ERR_ARG;
     const TileCfg* cfgs = smallc ? kStemCfgs : kCfgs;
     const int ncfg = smallc ? 2 : kNumCfg;
-    // experiment knobs: DVID_IGEMM_CFG=<index into the table> forces one configuration for every layer it is valid for
-    static const int cfg_env = getenv("DVID_IGEMM_CFG") ? atoi(getenv("DVID_IGEMM_CFG")) : -1;
+    // DVID_IGEMM_CFG=<index into the table> / dvid_igemm_set_config() force one configuration for every layer it is
+    // valid for (parity tests compare configurations bit for bit; experiments)
+    static const int cfg_env0 = getenv("DVID_IGEMM_CFG") ? atoi(getenv("DVID_IGEMM_CFG")) : -1;
+    const int cfg_env = g_forced_cfg >= -1 ? g_forced_cfg : cfg_env0;
     static const bool tune = !(getenv("DVID_IGEMM_TUNE") && atoi(getenv("DVID_IGEMM_TUNE")) == 0);
     int fallback = smallc ? (p.Kpad >= 512 ? 1 : 0) : heuristic_cfg(p);
     if (!cfg_valid(cfgs[fallback], p)) fallback = smallc ? 0 : (p.Kpad >= 512 ? 3 : 0);

@@ -155,6 +155,11 @@ int dvid_nchw_from_nhwc(const void* in_f16, float* out, int n, int h, int w, int
 int dvid_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
 
 /* ---- measurement -------------------------------------------------------------------------- */
+/* Tile configurations of the implicit-GEMM kernel (all bit-identical in their results): the per-shape tuner picks one;
+ * dvid_igemm_set_config(k) forces table entry k wherever it is valid (k = -1: back to the tuner). */
+int dvid_igemm_num_configs(void);
+int dvid_igemm_set_config(int cfg);
+
 /* When enabled, every igemm launch is bracketed by HIP events on its stream; dvid_profile_read
  * synchronises those events and returns totals since the last reset. */
 int dvid_profile_enable(int on);
