@@ -110,8 +110,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=304, help="frames per synthetic video")
-    ap.add_argument("--lookahead", type=int, default=3,
-                    help="INPUT.LOOKAHEAD_BATCHES: 8-frame batches whose backbone + extraction heads share one launch (1 = reference schedule)")
+    ap.add_argument("--lookahead", type=int, default=0,
+                    help="INPUT.LOOKAHEAD_BATCHES: INFER_BATCH groups whose backbone + extraction heads share one launch sequence "
+                         "(1 = the reference's schedule; default 0 = 24 frames' worth: 3 for R101, 6 for Swin-B)")
     ap.add_argument("--arch", choices=("r101", "swinb"), default="r101",
                     help="r101 = the BASELINE.json headline configuration; swinb = configs/vid_Swin_B_DiffusionVID.yaml (INFER_BATCH 4)")
     ap.add_argument("--sample-step", type=int, default=1, help="MODEL.DiffusionDet.SAMPLE_STEP (4 = the x4 configuration)")
@@ -131,6 +132,8 @@ def main():
 
     headline = args.arch == "r101" and args.sample_step == 1
     yaml = "configs/vid_R_101_DiffusionVID.yaml" if args.arch == "r101" else "configs/vid_Swin_B_DiffusionVID.yaml"
+    if args.lookahead <= 0:
+        args.lookahead = 3 if args.arch == "r101" else 6
     cfg = get_cfg(os.path.join(ROOT, yaml), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", args.lookahead,
                                              "MODEL.DiffusionDet.SAMPLE_STEP", args.sample_step],
                   os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))

@@ -149,9 +149,10 @@ __global__ void add_layernorm_kernel(const float* __restrict__ x, const float* _
 // Swin PatchMerging front half (swintransformer.py:296-319): gather the 2x2 neighbourhood
 // [x(2i,2j) | x(2i+1,2j) | x(2i,2j+1) | x(2i+1,2j+1)] (zeros beyond an odd H/W), LayerNorm over 4C, fp16 out.
 // One wave per output token; the bias-free reduction Linear(4C -> 2C) that follows is an igemm launch.
-template <int MAXV>
-__global__ void patch_merge_ln_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                      half_t* __restrict__ y16, int B, int H, int W, int C) {
+// C <= 512: every lane holds up to 2 float4 of each of the 4 source tokens (no per-element division, 32 live registers)
+__global__ __launch_bounds__(256) void patch_merge_ln_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ b, half_t* __restrict__ y16, int B, int H,
+                                                             int W, int C) {
     const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
     const long tok = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (tok >= (long)B * H2 * W2) return;
@@ -160,48 +161,52 @@ __global__ void patch_merge_ln_kernel(const float* __restrict__ x, const float* 
     const long t2 = tok / W2;
     const int oy = t2 % H2;
     const int img = t2 / H2;
-    const int nv = C;              // float4 vectors in the 4C-wide row
-    const int cv = C >> 2;         // float4 vectors per source token
-    float4v v[MAXV];
+    const int cv = C >> 2;         // float4 vectors per source token (<= 128)
+    float4v v[4][2];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int j = lane + i * 64;
-        v[i] = (float4v){0.f, 0.f, 0.f, 0.f};
-        if (j < nv) {
-            const int part = j / cv, c4 = j - part * cv;
-            const int y = 2 * oy + (part & 1), xx = 2 * ox + (part >> 1);
-            if (y < H && xx < W) v[i] = *reinterpret_cast<const float4v*>(x + (((long)img * H + y) * W + xx) * C + c4 * 4);
-            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    for (int part = 0; part < 4; ++part) {
+        const int y = 2 * oy + (part & 1), xx = 2 * ox + (part >> 1);
+        const bool inside = y < H && xx < W;
+        const float* src = x + (((long)img * H + (inside ? y : 0)) * W + (inside ? xx : 0)) * C;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c4 = lane + i * 64;
+            v[part][i] = (float4v){0.f, 0.f, 0.f, 0.f};
+            if (inside && c4 < cv) v[part][i] = *reinterpret_cast<const float4v*>(src + c4 * 4);
+            sum += v[part][i][0] + v[part][i][1] + v[part][i][2] + v[part][i][3];
         }
     }
     const int d = 4 * C;
     const float mean = wave_sum(sum) / d;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int j = lane + i * 64;
-        if (j < nv) {
+    for (int part = 0; part < 4; ++part)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = v[i][e] - mean;
-                sq += t * t;
+        for (int i = 0; i < 2; ++i)
+            if (lane + i * 64 < cv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = v[part][i][e] - mean;
+                    sq += t * t;
+                }
             }
-        }
-    }
     const float rstd = rsqrtf(wave_sum(sq) / d + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int j = lane + i * 64;
-        if (j < nv) {
-            const float4v gg = *reinterpret_cast<const float4v*>(g + j * 4);
-            const float4v bb = *reinterpret_cast<const float4v*>(b + j * 4);
-            half4 h;
+    for (int part = 0; part < 4; ++part)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = (half_t)((v[i][e] - mean) * rstd * gg[e] + bb[e]);
-            *reinterpret_cast<half4*>(y16 + tok * d + j * 4) = h;
+        for (int i = 0; i < 2; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < cv) {
+                const int j = part * cv + c4;
+                const float4v gg = *reinterpret_cast<const float4v*>(g + j * 4);
+                const float4v bb = *reinterpret_cast<const float4v*>(b + j * 4);
+                half4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (half_t)((v[part][i][e] - mean) * rstd * gg[e] + bb[e]);
+                *reinterpret_cast<half4*>(y16 + tok * d + j * 4) = h;
+            }
         }
-    }
 }
 
 __global__ void f32_to_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y, long n4) {
@@ -316,7 +321,7 @@ int dvid_patch_merge_ln_launch(const float* x, const float* g, const float* b, h
     if (C % 4 || C > 512) return DVID_ERR_UNSUPPORTED;
     const long ntok = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
     const int wpb = 4;
-    hipLaunchKernelGGL(patch_merge_ln_kernel<8>, dim3((unsigned)((ntok + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, x, g, b, y16, B, H, W, C);
+    hipLaunchKernelGGL(patch_merge_ln_kernel, dim3((unsigned)((ntok + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, x, g, b, y16, B, H, W, C);
     LAUNCH_CHECK();
     return DVID_OK;
 }
