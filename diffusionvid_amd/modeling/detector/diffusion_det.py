@@ -209,6 +209,7 @@ class DiffusionDet(nn.Module):
 
     def _reset_video(self):
         self._ahead = {}
+        self._results_ahead = {}
         n = self.all_frame_interval
         self.local_img_queue = []
         self.head.proposal_feats_global = [None, None]
@@ -234,6 +235,9 @@ class DiffusionDet(nn.Module):
         if frame_id % self.infer_batch != 0:
             self.local_img_queue += infos["ref_l"]
             return []
+        if frame_id in self._results_ahead:          # this batch was finished inside its look-ahead group's call
+            self.local_img_queue = []
+            return self._results_ahead.pop(frame_id)
         ref_l = self.local_img_queue + infos["ref_l"]
         self.local_img_queue = []
         ref_g = infos["ref_g"]
@@ -243,13 +247,17 @@ class DiffusionDet(nn.Module):
         M = self.num_proposals
         batch = min(self.infer_batch, end_id - frame_id + 1)
         pairs = self._time_pairs()
-        ddim_draws = self._ddim_draws(batch, frame_id, pairs) if self.sampling_timesteps > 1 else None
+        ahead = infos.get("ref_ahead") or {}
+        ahead_keys = sorted(k for k in ahead if k not in self._ahead)
+        nb_of = {frame_id: batch}
+        nb_of.update({fb: min(self.infer_batch, end_id - fb + 1) for fb in ahead_keys})
+        # DDIM draws of every batch finished in this call, keyed and shaped exactly as that batch's own call would draw them
+        ddim_draws = {fb: self._ddim_draws(nb, fb, pairs) for fb, nb in nb_of.items()} if self.sampling_timesteps > 1 else {}
 
         # 1. features + extraction pass over [local frames | global frames] in splits of INFER_BATCH.  Every stage here
         # (backbone, the 3 RCNNHeads, top-k feature selection) is per-frame independent, so the splits -- and with
         # INPUT.LOOKAHEAD_BATCHES > 1 the frames of the next batches (`ref_ahead`) -- run as launches of up to
         # INFER_BATCH * LOOKAHEAD_BATCHES frames; a batch extracted early waits in `_ahead` for its own call.
-        ahead = infos.get("ref_ahead") or {}
         local_split = self._ahead.pop(frame_id, None) if not ref_g else None
         if local_split is not None:
             ref_l_run = []
@@ -265,7 +273,6 @@ class DiffusionDet(nn.Module):
             # queued: a host->device copy from pageable memory blocks the host until the stream has drained.
             sizes = [min(self.infer_batch, n_own - a) for a in range(0, n_own, self.infer_batch)]
             noise = [self._noise("box_init", frame_id, bi, 0, (b, M, 4)) for bi, b in enumerate(sizes)]
-            ahead_keys = sorted(k for k in ahead if k not in self._ahead)
             for fb in ahead_keys:
                 group = [to_image_list(im).tensors for im in ahead[fb]]
                 frames += group
@@ -301,6 +308,7 @@ class DiffusionDet(nn.Module):
                     src, i0, i1 = runs[0]
                     out = {k: src[k][i0:i1] for k in keys}
                     out["feats"] = [f[i0:i1] for f in src["feats"]]
+                    out["_src"], out["_i0"], out["_i1"] = src, i0, i1          # lets neighbouring splits be re-joined as views
                     return out
                 out = {k: torch.cat([src[k][i0:i1] for src, i0, i1 in runs]) for k in keys}
                 out["feats"] = [torch.cat([src["feats"][l][i0:i1] for src, i0, i1 in runs]) for l in range(3)]
@@ -341,22 +349,67 @@ class DiffusionDet(nn.Module):
         for i in fill_idx:
             self.queue.append((splits[0], i))
 
-        # current batch (diffusion_det.py:515-523)
+        # 4. final stage.  Per frame it needs the frame's own extraction results and the video's global memory, nothing
+        # of its neighbours, so the batches extracted ahead in this call are finished here as well -- in one pass per
+        # run of adjacent frames -- and their detections wait on the host side for their own calls.
+        group = [(fb, nb_of[fb], self._ahead.pop(fb)) for fb in ahead_keys if fb in self._ahead]
+        if group and n_local == self.infer_batch and batch == self.infer_batch and splits[0].get("_src") is not None:
+            group = [(frame_id, batch, splits[0])] + group
+            runs = []
+            for fb, nb, sp in group:
+                if runs and runs[-1]["src"] is sp.get("_src") and runs[-1]["i1"] == sp.get("_i0"):
+                    runs[-1]["i1"] = sp["_i1"]
+                    runs[-1]["items"].append((fb, nb))
+                else:
+                    runs.append({"src": sp.get("_src"), "i0": sp.get("_i0"), "i1": sp.get("_i1"), "split": sp, "items": [(fb, nb)]})
+            mine = None
+            for run in runs:
+                if run["src"] is not None:
+                    src, i0, i1 = run["src"], run["i0"], run["i1"]
+                    feats_run = [f[i0:i1] for f in src["feats"]]
+                    cached = (src["logits"][i0:i1], src["boxes"][i0:i1], src["obj"][i0:i1])
+                else:
+                    sp = run["split"]
+                    feats_run, cached = sp["feats"], (sp["logits"], sp["boxes"], sp["obj"])
+                per_slot = self._final_stage(feats_run, cached, whwh, w, h, pairs, run["items"], ddim_draws)
+                for k, (fb, nb) in enumerate(run["items"]):
+                    out = per_slot[k * self.infer_batch: k * self.infer_batch + nb]
+                    if fb == frame_id:
+                        mine = out
+                    else:
+                        self._results_ahead[fb] = out
+            return mine
+
+        # current batch only (diffusion_det.py:515-523)
         entries = [self.queue[i] for i in range(self.key_frame_location, self.key_frame_location + batch)]
         feats_cur, cached = self._gather_entries(entries)
+        return self._final_stage(feats_cur, cached, whwh, w, h, pairs, [(frame_id, batch)], ddim_draws, slots=batch)
 
+    def _final_stage(self, feats, cached, whwh, w, h, pairs, items, ddim_draws, slots=None):
+        """Global attention + conditioned head (+ DDIM loop) + top-k/NMS over `R` frame slots holding the batches `items`
+        = [(call frame id, real frames)], INFER_BATCH slots each unless `slots` says otherwise; -> one BoxList per slot."""
+        M = self.num_proposals
+        R = cached[0].shape[0]
+        per = self.infer_batch if slots is None else slots
+        assert R == per * len(items)
         if self.sampling_timesteps == 1:
             # x1: the randn `img` of diffusion_det.py:542 never reaches the output (the head pops the cached
             # stages, box_head.py:300-302) and the DDIM update after the single step is dead code (:573-575)
-            self.head.proposals_feat_cur = [[cached[0], cached[1], cached[2].reshape(1, batch * M, self.hidden_dim)]]
-            t = torch.full((batch,), pairs[0][0], dtype=torch.long)
-            img = torch.zeros((batch, M, 4), device=self.device)
-            outputs_class, outputs_coord = self.model_predictions(feats_cur, whwh, img, t)
+            self.head.proposals_feat_cur = [[cached[0], cached[1], cached[2].reshape(1, R * M, self.hidden_dim)]]
+            t = torch.full((R,), pairs[0][0], dtype=torch.long)
+            img = torch.zeros((R, M, 4), device=self.device)
+            outputs_class, outputs_coord = self.model_predictions(feats, whwh, img, t)
             ob, osc, ol, oc = ops.postproc_topk_nms(outputs_class[-1], outputs_coord[-1], w, h, 0.5, self.use_nms)
             if self.debug_taps is not None:
                 self.debug_taps["final_0"] = (outputs_class[-1], outputs_coord[-1])
         else:
-            ob, osc, ol, oc = self._ddim_ensemble(feats_cur, whwh, batch, frame_id, pairs, w, h, ddim_draws)
+            def padded(x, nb):          # a batch's draws cover its real frames; the duplicate tail slots get zeros
+                return x if nb == per else torch.cat([x, torch.zeros((per - nb,) + tuple(x.shape[1:]), device=x.device)])
+            draws = {"img": torch.cat([padded(ddim_draws[fb]["img"], nb) for fb, nb in items])}
+            for step, (_, time_next) in enumerate(pairs):
+                if time_next >= 0:
+                    draws[step] = tuple(torch.cat([padded(ddim_draws[fb][step][i], nb) for fb, nb in items]) for i in (0, 1))
+            ob, osc, ol, oc = self._ddim_ensemble(feats, whwh, R, items[0][0], pairs, w, h, draws)
         return self._to_boxlists(ob, osc, ol, oc, (int(w), int(h)))
 
     # ---- helpers --------------------------------------------------------------------------------
