@@ -18,8 +18,8 @@ every stage is per-frame independent given the video's global memory, so the gro
 host sync; --lookahead 1 is the reference's schedule and gives the same detections (tests/test_gpu_e2e.py::test_lookahead_batches_do_not_change_results).
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel is the implicit-GEMM MFMA conv/linear kernel (igemm2_kernel<...>, ~78 % of the
-               GPU time, profiles/r01c_kernel_stats.txt).  An instrumented repeat of one step right after the timed
+  roofline     the dominant kernel is the implicit-GEMM MFMA conv/linear kernel (igemm2_kernel<...>, ~82 % of the
+               GPU time, profiles/r01d_kernel_stats.txt).  An instrumented repeat of one step right after the timed
                region brackets every launch with HIP events on its launch stream (sub-batch chains off, so launches
                do not overlap) and sums durations, algorithmic FLOP (2*M*N*K) and algorithmic HBM bytes (input +
                weights + output + residual, each once).  The bound is the lower roof at the measured intensity
@@ -50,7 +50,7 @@ from diffusionvid_amd.engine import inference as engine  # noqa: E402
 from diffusionvid_amd.modeling.detector import build_detection_model  # noqa: E402
 from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
-TRAFFIC_FILE = "r01c_pmc_igemm_traffic.json"
+TRAFFIC_FILE = "r01d_pmc_igemm_traffic.json"
 PEAK_FP16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
@@ -197,10 +197,12 @@ def main():
     if os.environ.get("DVID_PROFILE_DUMP") and rank == 0:
         lib.dvid_profile_dump(os.environ["DVID_PROFILE_DUMP"].encode())
     lib.dvid_profile_reset()
-    traffic = None
+    traffic = mfma_busy = None
     tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected in-process)
-        traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
+        pmc = json.load(open(tpath))
+        traffic = round(pmc["hbm_bytes_per_launch"])
+        mfma_busy = pmc.get("mfma_busy_fraction")
     if ms.value > 0:
         sec = ms.value * 1e-3
         tflops = fl.value / sec / 1e12
@@ -216,6 +218,7 @@ def main():
                                       "video, bytes per launch; its own algorithmic figure is in the file)" % TRAFFIC_FILE,
                     "alg_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
                     "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_FP16_TFLOPS, 4),
+                    "mfma_busy_pmc": None if mfma_busy is None else round(mfma_busy, 4),
                     "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
                     "alg_mbytes_per_launch": round(ab.value / max(1, nl.value) / 1e6, 2),
                     "alg_gflop_per_launch": round(fl.value / max(1, nl.value) / 1e9, 3),
