@@ -52,8 +52,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 //           COUNTED `s_waitcnt vmcnt((NSTAGE - 2) * P)` (P = its DMA pieces per tile) so only the tile about to be
 //           read has landed, and re-fills the stage freed by the previous step right after the barrier.
 // WN: waves along N (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads); always 2 waves along M.
-template <int BM, int BN, int BKT, int NSTAGE, int WN, bool SMALLC>
+// AK: how the A operand is addressed -- 0: filter-tap walk (KHxKW convolutions), 1: the Cin = 8 stem (one tap per
+//     16-byte chunk), 2: FLAT = 1x1 / linear with pad 0: a row of A is K contiguous halves, no taps, no masks (stride 1
+//     with Ho == H, Wo == W additionally needs no division: row m is pixel m).
+// SEPI: lean epilogue for the common case (fp16 out, vector-aligned N, residual none / same-shape fp16, ReLU or none);
+//     the general one (igemm_store_row8: fp32 out, GELU, upsampled / fp32 residual, ragged N) inlines to ~7000
+//     instructions per kernel.  Short-K layers are instruction-issue bound (23 scalar/vector instructions per MFMA,
+//     profiles/r01_pmc_conv3.txt), so both specialisations exist to cut executed instructions, not bytes.
+template <int BM, int BN, int BKT, int NSTAGE, int WN, int AK, bool SEPI>
 __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
+    constexpr bool SMALLC = AK == 1, FLAT = AK == 2;
     constexpr int NW = 2 * WN;                      // waves per workgroup
     constexpr int NT = 64 * NW;                     // threads
     constexpr int ROW_BYTES = BKT * 2;
@@ -98,7 +106,20 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         a_ptr[i] = zero;
         a_iy[i] = -(1 << 28);
         a_ix[i] = 0;
-        if (m < p.M) {
+        if (FLAT) {
+            if (m < p.M) {
+                long pix = m;
+                if (p.stride != 1) {
+                    const int ox = m % p.Wo;
+                    const int t = m / p.Wo;
+                    const int oy = t % p.Ho;
+                    const int img = t / p.Ho;
+                    pix = ((long)img * p.H + oy * p.stride) * p.W + ox * p.stride;
+                }
+                a_ptr[i] = reinterpret_cast<const char*>(p.in + pix * p.Cin + a_lch[i] * 8);
+                a_mask[i] = BKT * 2;              // FLAT: per-step pointer increment (0 keeps padded rows on the zero page)
+            }
+        } else if (m < p.M) {
             const int ox = m % p.Wo;
             const int t = m / p.Wo;
             const int oy = t % p.Ho;
@@ -129,17 +150,17 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     // K range of this workgroup (split-K) and the filter-tap walk of the K loop (wave-uniform): k0 = tap*Cin + c0
     const int nk_all = p.Kpad / BKT;
     const int nk = p.splitk > 1 ? nk_all / p.splitk : nk_all;
-    // K rotation (p.krot): every tile starts its K walk at a different K tile and wraps, so that the workgroups of
-    // a launch do not all pull the same weight lines from L2 at the same moment (the sum is order-independent).
-    const int rot = (p.krot && !SMALLC && p.splitk <= 1) ? (tile_m * 5 + tile_n * 3) % nk : 0;
-    const int kt0 = split * nk + rot;
-    int kpos = rot;
+    const int kt0 = split * nk;
     int ky = 0, kx = 0, c0 = 0, tap = 0;
-    if (!SMALLC && kt0) {
+    if (AK == 0 && kt0) {
         tap = (kt0 * BKT) / p.Cin;
         c0 = kt0 * BKT - tap * p.Cin;
         ky = tap / p.KW;
         kx = tap - ky * p.KW;
+    }
+    if (FLAT) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) a_ptr[i] += (long)kt0 * a_mask[i];
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) b_ptr[i] += (long)kt0 * b_step[i];
@@ -156,6 +177,9 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
                 const bool ok = tp < p.ntaps && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const char* src = ok ? a_ptr[i] + (long)((tky * p.W + tkx) * p.Cin) * 2 : zero;
                 glds16(src, sa + (wave + NW * i) * 1024);
+            } else if (FLAT) {
+                glds16(a_ptr[i], sa + (wave + NW * i) * 1024);
+                a_ptr[i] += a_mask[i];
             } else {
                 const long koff = (long)((ky * p.W + kx) * p.Cin + c0) * 2;      // wave-uniform byte offset of this K tile
                 const char* src = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + koff : zero;
@@ -169,7 +193,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     };
     // advance the filter-tap walk to the next K tile (after the last piece of a tile has been issued)
     auto advance = [&]() {
-        if (!SMALLC) {
+        if (AK == 0) {
             c0 += BKT;
             if (c0 >= p.Cin) {
                 c0 = 0;
@@ -178,12 +202,6 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
                     kx = 0;
                     ++ky;
                 }
-            }
-            if (rot && ++kpos == nk) {                           // wrap to the first K tile
-                kpos = 0;
-                c0 = tap = ky = kx = 0;
-#pragma unroll
-                for (int i = 0; i < B_IT; ++i) b_ptr[i] -= (long)nk * b_step[i];
             }
         }
     };
@@ -300,6 +318,10 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = (p.bias && n + e < p.Cout) ? p.bias[n + e] : 0.f;
+    // lean epilogue state: element offsets of this thread's first row of a half tile, advanced by constant strides
+    const bool has_res = p.res_mode == 1;
+    half_t* const outp = reinterpret_cast<half_t*>(p.out);
+    const half_t* const resp = reinterpret_cast<const half_t*>(p.res);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half) __syncthreads();
@@ -316,35 +338,95 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
                     }
         }
         __syncthreads();
+        if (SEPI) {
+            const int mrow = m0 + half * (BM / 2) + tid / VPR;
+            long oidx = (long)mrow * p.ldc + n;
+            long ridx = (long)mrow * p.Cout + n;
+            const float* csp = Cs + (tid / VPR) * CP + c8;
+            if (n < p.Cout) {
 #pragma unroll
-        for (int e = 0; e < EROWS; ++e) {
-            const int r = tid / VPR + e * ERPP;
-            const int m = m0 + half * (BM / 2) + r;
-            if (m < p.M && n < p.Cout) igemm_store_row8(p, Cs + r * CP + c8, m, n, bias8, pre_ok, rpre[half][PRE ? e : 0]);
+                for (int e = 0; e < EROWS; ++e) {
+                    if (mrow + e * ERPP < p.M) {
+                        const float4v lo = *reinterpret_cast<const float4v*>(csp + e * ERPP * CP);
+                        const float4v hi = *reinterpret_cast<const float4v*>(csp + e * ERPP * CP + 4);
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q] = lo[q] + bias8[q];
+                            v[q + 4] = hi[q] + bias8[q + 4];
+                        }
+                        if (has_res) {
+                            const half8 rv = pre_ok ? rpre[half][PRE ? e : 0] : *reinterpret_cast<const half8*>(resp + ridx);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] += (float)rv[q];
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                        }
+                        half8 hv;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) hv[q] = (half_t)v[q];
+                        *reinterpret_cast<half8*>(outp + oidx) = hv;
+                    }
+                    oidx += (long)ERPP * p.ldc;
+                    ridx += (long)ERPP * p.Cout;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EROWS; ++e) {
+                const int r = tid / VPR + e * ERPP;
+                const int m = m0 + half * (BM / 2) + r;
+                if (m < p.M && n < p.Cout) igemm_store_row8(p, Cs + r * CP + c8, m, n, bias8, pre_ok, rpre[half][PRE ? e : 0]);
+            }
         }
     }
 }
 
-template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC, int WN = 2>
-int launch2(const IgemmParams& p0, hipStream_t s) {
-    IgemmParams p = p0;
-    static const int rot_env = getenv("DVID_IGEMM_ROT") ? atoi(getenv("DVID_IGEMM_ROT")) : 0;
-    p.krot = rot_env;
-    p.tiles_m = ceil_div(p.M, BM);
-    p.tiles_n = ceil_div(p.Cout, BN);
+template <int BM, int BN, int BKT, int NSTAGE, int WN, int AK, bool SEPI>
+int launch2k(const IgemmParams& p, hipStream_t s) {
     constexpr int smem = Smem2<BM, BN, BKT, NSTAGE>::kBytes;
     if (smem > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, AK, SEPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
     }
     const int nsplit = p.splitk > 1 ? p.splitk : 1;
-    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, WN, SMALLC>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(128 * WN), smem, s, p);
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, WN, AK, SEPI>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(128 * WN), smem, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
+}
+
+// the lean epilogue covers: fp16 output and residual, N and ldc multiples of 8, residual none / same shape, ReLU / none
+bool lean_epilogue_ok(const IgemmParams& p) {
+    return !p.out_f32 && !p.res_f32 && (p.Cout & 7) == 0 && (p.ldc & 7) == 0 && p.res_mode <= 1 && p.relu <= 1 && p.splitk <= 1;
+}
+// FLAT addressing: 1x1 / linear, pad 0, K = Cin (stride 1 must cover the whole input: row m = pixel m)
+bool flat_ok(const IgemmParams& p) {
+    return p.ntaps == 1 && p.pad == 0 && p.Cin == p.Kpad && (p.stride != 1 || (p.Ho == p.H && p.Wo == p.W));
+}
+
+template <int BM, int BN, int BKT, int NSTAGE, bool SMALLC, int WN = 2>
+int launch2(const IgemmParams& p0, hipStream_t s) {
+    IgemmParams p = p0;
+    p.tiles_m = ceil_div(p.M, BM);
+    p.tiles_n = ceil_div(p.Cout, BN);
+    // DVID_IGEMM_GENERIC=1 (read per launch): always the general addressing + general epilogue -- the parity tests
+    // compare the specialised paths against it bit for bit
+    const char* g = getenv("DVID_IGEMM_GENERIC");
+    const bool generic = g && g[0] == '1';
+    const bool sepi = !generic && lean_epilogue_ok(p);
+    if constexpr (SMALLC) {
+        return sepi ? launch2k<BM, BN, BKT, NSTAGE, WN, 1, true>(p, s) : launch2k<BM, BN, BKT, NSTAGE, WN, 1, false>(p, s);
+    } else {
+        if (!generic && flat_ok(p))
+            return sepi ? launch2k<BM, BN, BKT, NSTAGE, WN, 2, true>(p, s) : launch2k<BM, BN, BKT, NSTAGE, WN, 2, false>(p, s);
+        return sepi ? launch2k<BM, BN, BKT, NSTAGE, WN, 0, true>(p, s) : launch2k<BM, BN, BKT, NSTAGE, WN, 0, false>(p, s);
+    }
 }
 
 // ---- tile configurations ----------------------------------------------------------------------------------------

@@ -12,7 +12,6 @@ struct IgemmParams {
     int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int M, Kpad, ntaps, ldc, alg_k;
     int relu, out_f32, res_mode, res_f32;   // relu: 0 none, 1 ReLU, 2 exact GELU; res_mode: 0 none, 1 same shape, 2 nearest-x2 upsample
-    int krot;                               // 1: rotate the K walk per tile (igemm2)
     int splitk;                             // > 1: K split over `splitk` workgroups per tile, fp32 partials (no bias/relu/residual)
     long split_stride;                      //       written to out + split * split_stride (elements)
     int tiles_m, tiles_n;                   // filled by the launcher

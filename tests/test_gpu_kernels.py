@@ -373,38 +373,53 @@ def test_backbone_swin_small(dv):
 
 
 @pytest.mark.parametrize("case", [
-    # (rows / image dims, Cin, Cout, stride, residual, relu, out_f32)
+    # (image dims, Cin, Cout, kernel, stride, residual, relu, out_f32)
     dict(n=1, h=1, w=777, cin=256, cout=1024, stride=1, res=True, relu=1),        # bottleneck conv3 + residual, ragged M
     dict(n=2, h=30, w=44, cin=64, cout=256, stride=1, res=True, relu=1),          # res2 conv3 (one K tile)
     dict(n=2, h=30, w=44, cin=128, cout=512, stride=2, res=False, relu=0),        # strided 1x1 shortcut
     dict(n=1, h=1, w=300, cin=256, cout=2048 + 64, stride=1, res=False, relu=0),  # wide N with a ragged last tile
     dict(n=1, h=1, w=500, cin=256, cout=1280, stride=1, res=False, relu=2, f32=True),   # GELU, fp32 out
+    dict(n=2, h=19, w=27, cin=64, cout=128, k=3, stride=1, res=False, relu=1),    # 3x3, pad 1 (tap walk + lean epilogue)
+    dict(n=2, h=19, w=27, cin=128, cout=128, k=3, stride=2, res=True, relu=1),    # 3x3 stride 2 with residual
+    dict(n=1, h=1, w=333, cin=1024, cout=250, stride=1, res=False, relu=0),       # N not a multiple of 8 -> general epilogue
 ])
 def test_igemm_configs_bit_identical(case):
     """Every tile configuration of the implicit-GEMM kernel must give bit-identical outputs (the per-shape tuner swaps
-    them freely); configuration 0 is also checked against fp32 math."""
+    them freely), and so must its specialised code paths (FLAT 1x1 addressing, lean epilogue) against the general ones
+    (DVID_IGEMM_GENERIC=1); configuration 0 is also checked against fp32 math."""
     from diffusionvid_amd import _lib, ops
     lib = _lib.load()
     g = torch.Generator().manual_seed(5)
     n, h, w, cin, cout, stride = (case[k] for k in ("n", "h", "w", "cin", "cout", "stride"))
+    k = case.get("k", 1)
+    pad = k // 2
     x = (torch.randn(n, h, w, cin, generator=g) * 0.5).half().cuda()
-    wt = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
     bias = torch.randn(cout, generator=g).cuda()
-    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     res = (torch.randn(n, ho, wo, cout, generator=g)).half().cuda() if case["res"] else None
+    wp, kpad = ops.pack_conv_weight(wt)
+    wp = wp.cuda()
+
+    def run():
+        return ops.conv2d_nhwc(x, wp, kpad, bias, cout, k, k, stride, pad, relu=case["relu"], residual=res,
+                               residual_mode=1 if res is not None else 0, out_f32=case.get("f32", False)).clone()
     outs = {}
     try:
         for cfg in range(lib.dvid_igemm_num_configs()):
             _lib.check(lib.dvid_igemm_set_config(cfg), "set_config")
-            wp, kpad = ops.pack_conv_weight(wt)
-            outs[cfg] = ops.conv2d_nhwc(x, wp.cuda(), kpad, bias, cout, 1, 1, stride, 0, relu=case["relu"], residual=res,
-                                        residual_mode=1 if res is not None else 0, out_f32=case.get("f32", False)).clone()
+            outs[cfg] = run()
+        os.environ["DVID_IGEMM_GENERIC"] = "1"
+        _lib.check(lib.dvid_igemm_set_config(0), "set_config")
+        generic = run()
     finally:
+        os.environ.pop("DVID_IGEMM_GENERIC", None)
         lib.dvid_igemm_set_config(-1)
     ref = outs[0]
     for cfg, o in outs.items():
         assert torch.equal(o, ref), f"configuration {cfg} differs from configuration 0 (max |d| = {(o.float() - ref.float()).abs().max().item():.3e})"
-    y = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), wt.half().float().cuda(), bias, stride=stride).permute(0, 2, 3, 1)
+    assert torch.equal(generic, ref), f"specialised paths differ from the general ones (max |d| = {(generic.float() - ref.float()).abs().max().item():.3e})"
+    y = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), wt.half().float().cuda(), bias, stride=stride, padding=pad).permute(0, 2, 3, 1)
     if res is not None:
         y = y + res.float()
     y = torch.relu(y) if case["relu"] == 1 else torch.nn.functional.gelu(y) if case["relu"] == 2 else y

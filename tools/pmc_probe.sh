@@ -6,9 +6,11 @@ cd /tmp && export TMPDIR=/tmp
 export DVID_IGEMM_CFG=$CFG
 i=0
 for SET in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
-           "SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" \
-           "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_sum" \
-           "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES"; do
+           "SQ_WAIT_ANY SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU" \
+           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_BUSY_avr TCC_EA0_WRREQ_STALL_sum" \
+           "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
   timeout 90 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmcp_$i -o p -- python $REPO/tools/bench_gemm_probe.py "$@" > /tmp/pmcp_$i.log 2>&1
   echo "pass $i ($SET): rc=$?"
