@@ -343,30 +343,23 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
             long oidx = (long)mrow * p.ldc + n;
             long ridx = (long)mrow * p.Cout + n;
             const float* csp = Cs + (tid / VPR) * CP + c8;
+            const float4v b_lo = {bias8[0], bias8[1], bias8[2], bias8[3]}, b_hi = {bias8[4], bias8[5], bias8[6], bias8[7]};
             if (n < p.Cout) {
 #pragma unroll
                 for (int e = 0; e < EROWS; ++e) {
                     if (mrow + e * ERPP < p.M) {
-                        const float4v lo = *reinterpret_cast<const float4v*>(csp + e * ERPP * CP);
-                        const float4v hi = *reinterpret_cast<const float4v*>(csp + e * ERPP * CP + 4);
-                        float v[8];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            v[q] = lo[q] + bias8[q];
-                            v[q + 4] = hi[q] + bias8[q + 4];
-                        }
+                        // vector forms: the compiler emits packed fp32 adds and packed fp16 max for these.  ReLU after the
+                        // rounding equals ReLU before it (rounding is monotonic and keeps 0), so it runs on the halves.
+                        float4v lo = *reinterpret_cast<const float4v*>(csp + e * ERPP * CP) + b_lo;
+                        float4v hi = *reinterpret_cast<const float4v*>(csp + e * ERPP * CP + 4) + b_hi;
                         if (has_res) {
                             const half8 rv = pre_ok ? rpre[half][PRE ? e : 0] : *reinterpret_cast<const half8*>(resp + ridx);
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] += (float)rv[q];
+                            lo += __builtin_convertvector(__builtin_shufflevector(rv, rv, 0, 1, 2, 3), float4v);
+                            hi += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
                         }
-                        if (p.relu) {
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-                        }
-                        half8 hv;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) hv[q] = (half_t)v[q];
+                        const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hi, half4);
+                        half8 hv = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        if (p.relu) hv = __builtin_elementwise_max(hv, half8{0, 0, 0, 0, 0, 0, 0, 0});
                         *reinterpret_cast<half8*>(outp + oidx) = hv;
                     }
                     oidx += (long)ERPP * p.ldc;
