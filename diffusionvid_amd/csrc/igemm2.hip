@@ -1,7 +1,8 @@
-// Implicit-GEMM convolution / linear layer, version 2: direct-to-LDS staging.
+// Implicit-GEMM convolution / linear layer: direct-to-LDS staging.
 //
-// Same contract as igemm.hip (out = act(A_im2col . Wt^T + bias + residual), fp16 in, fp32
-// accumulate on v_mfma_f32_32x32x16_f16) with the staging rebuilt around
+// out = act(A_im2col . Wt^T + bias + residual), fp16 in, fp32 accumulate on v_mfma_f32_32x32x16_f16 (IgemmParams,
+// kernels.h).  The first, register-staged version (global -> VGPR -> LDS, 214 TFLOP/s on this path) is in the history
+// of this file's predecessor igemm.hip; this one is built around
 // `global_load_lds_dwordx4`: every lane hands the DMA its own 16-byte source address -- the im2col
 // gather, filter-tap bounds and the M/N tails are all resolved in that address (out-of-range lanes
 // point at a 16-byte zero page) -- and the data lands in LDS without touching VGPRs.  The LDS image
@@ -565,7 +566,7 @@ int dvid_igemm_set_config(int cfg) {
     return DVID_OK;
 }
 
-int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
+int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
     if (p.Kpad % 64 != 0 || p.Kpad < 64) return DVID_ERR_ARG;
     const bool smallc = (p.Cin == 8 && p.KH * p.KW > 1);

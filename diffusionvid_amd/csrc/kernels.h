@@ -16,8 +16,7 @@ struct IgemmParams {
     long split_stride;                      //       written to out + split * split_stride (elements)
     int tiles_m, tiles_n;                   // filled by the launcher
 };
-int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);   // dispatches to v2 unless DVID_IGEMM_V1 is set
-int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s);
+int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);   // igemm2.hip: per-shape tuned tile configuration
 
 // elementwise.hip
 int dvid_prep_images_launch(const float* nchw, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
