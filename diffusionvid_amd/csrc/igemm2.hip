@@ -56,11 +56,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 // AK: how the A operand is addressed -- 0: filter-tap walk (KHxKW convolutions), 1: the Cin = 8 stem (one tap per
 //     16-byte chunk), 2: FLAT = 1x1 / linear with pad 0: a row of A is K contiguous halves, no taps, no masks (stride 1
 //     with Ho == H, Wo == W additionally needs no division: row m is pixel m).
-// SEPI: lean epilogue for the common case (fp16 out, vector-aligned N, residual none / same-shape fp16, ReLU or none);
-//     the general one (igemm_store_row8: fp32 out, GELU, upsampled / fp32 residual, ragged N) inlines to ~7000
-//     instructions per kernel.  Short-K layers are instruction-issue bound (23 scalar/vector instructions per MFMA,
+// EPI: epilogue specialisation -- 1: fp16 out, residual none / same-shape fp16, ReLU or none (the backbone); 2: fp32 out,
+//     residual none / same-shape fp32 (possibly in place), ReLU or none (Swin's residual stream, decoder linears);
+//     3: fp16 out, exact GELU (Swin fc1); all three need a vector-aligned N.  0: the general one (igemm_store_row8:
+//     upsampled residual, ragged N, mixed types), which inlines to ~7000 instructions per kernel.  Short-K layers are instruction-issue bound (23 scalar/vector instructions per MFMA,
 //     profiles/r01_pmc_conv3.txt), so both specialisations exist to cut executed instructions, not bytes.
-template <int BM, int BN, int BKT, int NSTAGE, int WN, int AK, bool SEPI>
+template <int BM, int BN, int BKT, int NSTAGE, int WN, int AK, int EPI>
 __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     constexpr bool SMALLC = AK == 1, FLAT = AK == 2;
     constexpr int NW = 2 * WN;                      // waves per workgroup
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
                     }
         }
         __syncthreads();
-        if (SEPI) {
+        if (EPI != 0) {
             const int mrow = m0 + half * (BM / 2) + tid / VPR;
             long oidx = (long)mrow * p.ldc + n;
             long ridx = (long)mrow * p.Cout + n;
@@ -349,19 +350,39 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
 #pragma unroll
                 for (int e = 0; e < EROWS; ++e) {
                     if (mrow + e * ERPP < p.M) {
-                        // vector forms: the compiler emits packed fp32 adds and packed fp16 max for these.  ReLU after the
-                        // rounding equals ReLU before it (rounding is monotonic and keeps 0), so it runs on the halves.
+                        // vector forms: the compiler emits packed fp32 adds and packed fp16 max for these
                         float4v lo = *reinterpret_cast<const float4v*>(csp + e * ERPP * CP) + b_lo;
                         float4v hi = *reinterpret_cast<const float4v*>(csp + e * ERPP * CP + 4) + b_hi;
-                        if (has_res) {
-                            const half8 rv = pre_ok ? rpre[half][PRE ? e : 0] : *reinterpret_cast<const half8*>(resp + ridx);
-                            lo += __builtin_convertvector(__builtin_shufflevector(rv, rv, 0, 1, 2, 3), float4v);
-                            hi += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
+                        if (EPI == 2) {
+                            if (has_res) {
+                                lo += *reinterpret_cast<const float4v*>(reinterpret_cast<const float*>(p.res) + ridx);
+                                hi += *reinterpret_cast<const float4v*>(reinterpret_cast<const float*>(p.res) + ridx + 4);
+                            }
+                            if (p.relu) {
+                                lo = __builtin_elementwise_max(lo, float4v{0.f, 0.f, 0.f, 0.f});
+                                hi = __builtin_elementwise_max(hi, float4v{0.f, 0.f, 0.f, 0.f});
+                            }
+                            *reinterpret_cast<float4v*>(reinterpret_cast<float*>(p.out) + oidx) = lo;
+                            *reinterpret_cast<float4v*>(reinterpret_cast<float*>(p.out) + oidx + 4) = hi;
+                        } else {
+                            if (EPI == 1 && has_res) {
+                                const half8 rv = pre_ok ? rpre[half][PRE ? e : 0] : *reinterpret_cast<const half8*>(resp + ridx);
+                                lo += __builtin_convertvector(__builtin_shufflevector(rv, rv, 0, 1, 2, 3), float4v);
+                                hi += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
+                            }
+                            if (EPI == 3) {          // exact GELU (nn.GELU default)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    lo[q] = 0.5f * lo[q] * (1.f + erff(lo[q] * 0.70710678118654752440f));
+                                    hi[q] = 0.5f * hi[q] * (1.f + erff(hi[q] * 0.70710678118654752440f));
+                                }
+                            }
+                            const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hi, half4);
+                            half8 hv = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                            // ReLU after the rounding equals ReLU before it (rounding is monotonic and keeps 0)
+                            if (EPI == 1 && p.relu) hv = __builtin_elementwise_max(hv, half8{0, 0, 0, 0, 0, 0, 0, 0});
+                            *reinterpret_cast<half8*>(outp + oidx) = hv;
                         }
-                        const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hi, half4);
-                        half8 hv = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        if (p.relu) hv = __builtin_elementwise_max(hv, half8{0, 0, 0, 0, 0, 0, 0, 0});
-                        *reinterpret_cast<half8*>(outp + oidx) = hv;
                     }
                     oidx += (long)ERPP * p.ldc;
                     ridx += (long)ERPP * p.Cout;
@@ -378,26 +399,32 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     }
 }
 
-template <int BM, int BN, int BKT, int NSTAGE, int WN, int AK, bool SEPI>
+template <int BM, int BN, int BKT, int NSTAGE, int WN, int AK, int EPI>
 int launch2k(const IgemmParams& p, hipStream_t s) {
     constexpr int smem = Smem2<BM, BN, BKT, NSTAGE>::kBytes;
     if (smem > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, AK, SEPI>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, AK, EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
     }
     const int nsplit = p.splitk > 1 ? p.splitk : 1;
-    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, WN, AK, SEPI>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(128 * WN), smem, s, p);
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, BKT, NSTAGE, WN, AK, EPI>), dim3(p.tiles_m * p.tiles_n * nsplit), dim3(128 * WN), smem, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
 }
 
-// the lean epilogue covers: fp16 output and residual, N and ldc multiples of 8, residual none / same shape, ReLU / none
-bool lean_epilogue_ok(const IgemmParams& p) {
-    return !p.out_f32 && !p.res_f32 && (p.Cout & 7) == 0 && (p.ldc & 7) == 0 && p.res_mode <= 1 && p.relu <= 1 && p.splitk <= 1;
+// which epilogue specialisation covers the launch (0: none, the general one)
+int epilogue_kind(const IgemmParams& p) {
+    if ((p.Cout & 7) || p.splitk > 1 || p.res_mode > 1) return 0;
+    if (!p.out_f32 && (p.ldc & 7) == 0 && !(p.res_mode && p.res_f32)) {
+        if (p.relu <= 1) return 1;
+        if (p.relu == 2 && !p.res_mode) return 3;
+    }
+    if (p.out_f32 && (p.ldc & 3) == 0 && p.relu <= 1 && (!p.res_mode || p.res_f32)) return 2;
+    return 0;
 }
 // FLAT addressing: 1x1 / linear, pad 0, K = Cin (stride 1 must cover the whole input: row m = pixel m)
 bool flat_ok(const IgemmParams& p) {
@@ -413,13 +440,19 @@ int launch2(const IgemmParams& p0, hipStream_t s) {
     // compare the specialised paths against it bit for bit
     const char* g = getenv("DVID_IGEMM_GENERIC");
     const bool generic = g && g[0] == '1';
-    const bool sepi = !generic && lean_epilogue_ok(p);
+    const int epi = generic ? 0 : epilogue_kind(p);
     if constexpr (SMALLC) {
-        return sepi ? launch2k<BM, BN, BKT, NSTAGE, WN, 1, true>(p, s) : launch2k<BM, BN, BKT, NSTAGE, WN, 1, false>(p, s);
+        return epi == 1 ? launch2k<BM, BN, BKT, NSTAGE, WN, 1, 1>(p, s) : launch2k<BM, BN, BKT, NSTAGE, WN, 1, 0>(p, s);
     } else {
-        if (!generic && flat_ok(p))
-            return sepi ? launch2k<BM, BN, BKT, NSTAGE, WN, 2, true>(p, s) : launch2k<BM, BN, BKT, NSTAGE, WN, 2, false>(p, s);
-        return sepi ? launch2k<BM, BN, BKT, NSTAGE, WN, 0, true>(p, s) : launch2k<BM, BN, BKT, NSTAGE, WN, 0, false>(p, s);
+        if (!generic && flat_ok(p)) {
+            switch (epi) {
+                case 1: return launch2k<BM, BN, BKT, NSTAGE, WN, 2, 1>(p, s);
+                case 2: return launch2k<BM, BN, BKT, NSTAGE, WN, 2, 2>(p, s);
+                case 3: return launch2k<BM, BN, BKT, NSTAGE, WN, 2, 3>(p, s);
+                default: return launch2k<BM, BN, BKT, NSTAGE, WN, 2, 0>(p, s);
+            }
+        }
+        return epi == 1 ? launch2k<BM, BN, BKT, NSTAGE, WN, 0, 1>(p, s) : launch2k<BM, BN, BKT, NSTAGE, WN, 0, 0>(p, s);
     }
 }
 

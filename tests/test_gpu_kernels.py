@@ -382,6 +382,8 @@ def test_backbone_swin_small(dv):
     dict(n=2, h=19, w=27, cin=64, cout=128, k=3, stride=1, res=False, relu=1),    # 3x3, pad 1 (tap walk + lean epilogue)
     dict(n=2, h=19, w=27, cin=128, cout=128, k=3, stride=2, res=True, relu=1),    # 3x3 stride 2 with residual
     dict(n=1, h=1, w=333, cin=1024, cout=250, stride=1, res=False, relu=0),       # N not a multiple of 8 -> general epilogue
+    dict(n=1, h=1, w=640, cin=128, cout=512, stride=1, res=False, relu=2),        # fp16 out + GELU (Swin fc1)
+    dict(n=1, h=1, w=640, cin=512, cout=128, stride=1, res=False, relu=1, f32=True),    # fp32 out + ReLU (decoder linears)
 ])
 def test_igemm_configs_bit_identical(case):
     """Every tile configuration of the implicit-GEMM kernel must give bit-identical outputs (the per-shape tuner swaps
@@ -424,3 +426,24 @@ def test_igemm_configs_bit_identical(case):
         y = y + res.float()
     y = torch.relu(y) if case["relu"] == 1 else torch.nn.functional.gelu(y) if case["relu"] == 2 else y
     assert torch.allclose(ref.float(), y, rtol=2e-3, atol=4e-3)
+
+
+def test_swin_backbone_specialised_paths_bit_identical():
+    """Swin-FPN backbone (fp32 residual stream updated in place, GELU MLP): the specialised igemm code paths against the
+    general ones (DVID_IGEMM_GENERIC=1), bit for bit."""
+    from diffusionvid_amd import ops
+    from diffusionvid_amd.utils import synthetic
+    swin = dict(embed_dim=64, depths=(2, 2, 2, 1), heads=(2, 4, 8, 16), window=7)
+    sd = synthetic.make_state_dict(3, swin=swin)
+    m = ops.Model(sd, res_blocks=(0, 0, 0, 0), backbone="swin", swin_embed_dim=64, swin_depths=swin["depths"], swin_heads=swin["heads"])
+    x = torch.rand(2, 3, 160, 224, generator=torch.Generator().manual_seed(1)).cuda()
+    m.reserve(2, 160, 224, 300)
+    fast = [t.clone() for t in m.backbone(x)]
+    os.environ["DVID_IGEMM_GENERIC"] = "1"
+    try:
+        slow = [t.clone() for t in m.backbone(x)]
+    finally:
+        os.environ.pop("DVID_IGEMM_GENERIC", None)
+    for a, b in zip(fast, slow):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    m.close()
