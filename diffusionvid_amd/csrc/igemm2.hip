@@ -473,6 +473,8 @@ const TileCfg kCfgs[] = {
     {256, 256, 32, 3, &launch2<256, 256, 32, 3, false, 4>}, {256, 256, 32, 2, &launch2<256, 256, 32, 2, false, 4>},
     {128, 64, 32, 3, &launch2<128, 64, 32, 3, false>},      {128, 128, 32, 4, &launch2<128, 128, 32, 4, false>},
     {128, 256, 32, 4, &launch2<128, 256, 32, 4, false, 4>}, {128, 64, 32, 4, &launch2<128, 64, 32, 4, false>},
+    // 4 waves with 64x128 per wave (128 accumulator registers): half the per-MFMA address / loop overhead of the 8-wave form
+    {128, 256, 32, 3, &launch2<128, 256, 32, 3, false, 2>}, {128, 256, 64, 2, &launch2<128, 256, 64, 2, false, 2>},
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 const TileCfg kStemCfgs[] = {   // Cin == 8 stem (one filter tap per 16-byte chunk)
