@@ -19,7 +19,7 @@ host sync; --lookahead 1 is the reference's schedule and gives the same detectio
 
 Extra objects on the JSON line:
   roofline     the dominant kernel is the implicit-GEMM MFMA conv/linear kernel (igemm2_kernel<...>, ~80 % of the
-               GPU time, profiles/r01e_kernel_stats.txt).  An instrumented repeat of one step right after the timed
+               GPU time, profiles/r01f_kernel_stats.txt).  An instrumented repeat of one step right after the timed
                region brackets every launch with HIP events on its launch stream (sub-batch chains off, so launches
                do not overlap) and sums durations, algorithmic FLOP (2*M*N*K) and algorithmic HBM bytes (input +
                weights + output + residual, each once).  The bound is the lower roof at the measured intensity
@@ -50,7 +50,7 @@ from diffusionvid_amd.engine import inference as engine  # noqa: E402
 from diffusionvid_amd.modeling.detector import build_detection_model  # noqa: E402
 from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
-TRAFFIC_FILE = "r01e_pmc_igemm_traffic.json"
+TRAFFIC_FILE = "r01f_pmc_igemm_traffic.json"
 PEAK_FP16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
@@ -214,8 +214,8 @@ def main():
                     "achieved": round(gbs if hbm_bound else tflops, 2), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_FP16_TFLOPS,
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of tools/profile_round.sh on a 64-frame "
-                                      "video, bytes per launch; its own algorithmic figure is in the file)" % TRAFFIC_FILE,
+                    "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of tools/profile_round.sh on this "
+                                      "workload, bytes per launch; its own algorithmic figure is in the file)" % TRAFFIC_FILE,
                     "alg_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
                     "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_FP16_TFLOPS, 4),
                     "mfma_busy_pmc": None if mfma_busy is None else round(mfma_busy, 4),

@@ -13,11 +13,10 @@ CMD="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
 export DVID_IGEMM_TUNE_CACHE=/tmp/dvid_tune_cache.txt
 rm -f $DVID_IGEMM_TUNE_CACHE
 $CMD > /tmp/prof_pre.log 2>&1
-$CMD --frames 64 > /tmp/prof_pre64.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- $CMD > /tmp/prof_stats.log 2>&1
 grep '^{"metric"' /tmp/prof_stats.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -o pmc -- $CMD --frames 64 > /tmp/prof_$C.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -o pmc -- $CMD --warmup 0 > /tmp/prof_$C.log 2>&1
 done
 python - "$TAG" "$OUT" <<'PY'
 import csv, glob, json, sys
@@ -66,7 +65,7 @@ if res["FETCH_SIZE"][1] and res["WRITE_SIZE"][1]:
                "mfma_busy_method": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs over sum(GRBM_GUI_ACTIVE) / 8 XCDs, igemm2 launches only",
                "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 "
-                         "--warmup 1 --frames 64 --no-cpu-baseline, DVID_CHAINS=1; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                         "--warmup 0 --no-cpu-baseline (the bench workload itself, 304-frame videos), DVID_CHAINS=1; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                          "(gfx950 counts 128-B requests at 64 B); WRITE_SIZE uncorrected", "round": 1},
               open(f"{out}/{tag}_pmc_igemm_traffic.json", "w"), indent=1)
 else:
