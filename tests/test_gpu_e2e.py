@@ -286,3 +286,39 @@ def test_lookahead_batches_do_not_change_results(sample_step):
         assert torch.allclose(a.get_field("scores"), b.get_field("scores"), atol=1e-5, rtol=0)
         n_exact += int(torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores")))
     print(f"[x{sample_step}] lookahead 4 vs 1: {n_exact}/44 frames bit-identical")
+
+
+def test_lookahead_invariance_full_size():
+    """BASELINE.json's full configuration (ResNet-101, 1000x600, 300 boxes, x1) on one 120-frame video: groups of 6 and
+    13 batches (48 / 104 frames per launch group, the bench schedules) must reproduce the detections of the reference
+    schedule (1) -- a size-independent property that also guards the index arithmetic at the largest launch sizes."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    outs = {}
+    for la in (1, 6, 13):
+        cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["INPUT.LOOKAHEAD_BATCHES", la], "configs/BASE_RCNN_1gpu.yaml")
+        cfg.freeze()
+        model = build_detection_model(cfg)
+        model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+        model = model.to("cuda").eval()
+        model.noise_fn = synthetic.noise_fn
+        ds = SyntheticVIDDataset([120], cfg, height=600, width=1000, device="cuda", smooth=True)
+        res = []
+        with torch.no_grad():
+            for idx in range(len(ds)):
+                res += model(ds[idx][0])
+        assert len(res) == 120
+        outs[la] = [r.to(torch.device("cpu")) for r in res]
+        del model, ds
+        torch.cuda.empty_cache()
+    for la in (6, 13):
+        worst = 0.0
+        for a, b in zip(outs[1], outs[la]):
+            assert len(a) == len(b) and len(a) > 0
+            assert torch.equal(a.get_field("labels"), b.get_field("labels"))
+            worst = max(worst, (a.bbox - b.bbox).abs().max().item())
+            assert torch.allclose(a.bbox, b.bbox, atol=1e-3, rtol=0)
+            assert torch.allclose(a.get_field("scores"), b.get_field("scores"), atol=1e-5, rtol=0)
+        print(f"look-ahead {la} vs 1 at full size: max |dbox| = {worst:.2e} px over 120 frames")
