@@ -13,7 +13,7 @@ value = frames emitted by all ranks / max-over-ranks wall time (barrier + device
 N > 1: one process per GPU, each rank owns whole videos (weak scaling, no data-path collective); the
 single RCCL gather of the predictions to rank 0 is inside the timed region.
 
-Schedule: INPUT.LOOKAHEAD_BATCHES (--lookahead, default 6 = 48 frames) 8-frame batches are processed as one group:
+Schedule: INPUT.LOOKAHEAD_BATCHES (--lookahead, default 13 = 104 frames) 8-frame batches are processed as one group:
 every stage is per-frame independent given the video's global memory, so the group shares its launches and its one
 host sync; --lookahead 1 is the reference's schedule and gives the same detections (tests/test_gpu_e2e.py::test_lookahead_batches_do_not_change_results).
 
@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--frames", type=int, default=304, help="frames per synthetic video")
     ap.add_argument("--lookahead", type=int, default=0,
                     help="INPUT.LOOKAHEAD_BATCHES: INFER_BATCH groups whose backbone + extraction heads share one launch sequence "
-                         "(1 = the reference's schedule; default 0 = 48 frames' worth: 6 for R101, 12 for Swin-B)")
+                         "(1 = the reference's schedule; default 0 = 104 frames' worth: 13 for R101, 26 for Swin-B)")
     ap.add_argument("--arch", choices=("r101", "swinb"), default="r101",
                     help="r101 = the BASELINE.json headline configuration; swinb = configs/vid_Swin_B_DiffusionVID.yaml (INFER_BATCH 4)")
     ap.add_argument("--sample-step", type=int, default=1, help="MODEL.DiffusionDet.SAMPLE_STEP (4 = the x4 configuration)")
@@ -133,7 +133,7 @@ def main():
     headline = args.arch == "r101" and args.sample_step == 1
     yaml = "configs/vid_R_101_DiffusionVID.yaml" if args.arch == "r101" else "configs/vid_Swin_B_DiffusionVID.yaml"
     if args.lookahead <= 0:
-        args.lookahead = 6 if args.arch == "r101" else 12
+        args.lookahead = 13 if args.arch == "r101" else 26
     cfg = get_cfg(os.path.join(ROOT, yaml), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", args.lookahead,
                                              "MODEL.DiffusionDet.SAMPLE_STEP", args.sample_step],
                   os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
