@@ -326,3 +326,37 @@ def test_lookahead_invariance_full_size(arch, sample_step, groups):
             assert torch.allclose(a.get_field("scores"), b.get_field("scores"), atol=1e-5, rtol=0)
         assert sum(len(a) for a in outs[1]) > 0
         print(f"{arch} x{sample_step}: look-ahead {la} vs 1 at full size: max |dbox| = {worst:.2e} px over 120 frames")
+
+
+def test_video_e2e_full_configuration():
+    """BASELINE.json configs[1] as it is benchmarked -- ResNet-101 (3,4,23,3), 1000x600 frames, 300 boxes, x1 -- on the
+    first call of an 8-frame video (8 local + 24 global frames through backbone and extraction heads, memory pruning,
+    final stage): extraction logits / boxes / object features, detections and AP50 against the CPU oracle, same
+    tolerances as the reduced-size test."""
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.utils import synthetic
+    cfg, model = _build(1, None)
+    L, H0, W0 = 8, 600, 1000
+    ds = SyntheticVIDDataset([L], cfg, height=H0, width=W0, device="cuda", smooth=True)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    oracle = odet.OracleDiffusionDet(sd, odet.DetCfg(), synthetic.noise_fn)
+    model.noise_fn = synthetic.noise_fn
+    model.debug_taps = {}
+    images, oitem, ids = _oracle_items(ds, 0)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        ref_out = oracle.forward(oitem)
+        got_out = model(images)
+    assert len(got_out) == len(ref_out) == L
+    ocl, obx, opf = oracle.taps["extract"]
+    gcl = torch.cat([e[0] for e in model.debug_taps["extract"]]).cpu()
+    gbx = torch.cat([e[1] for e in model.debug_taps["extract"]]).cpu()
+    gpf = torch.cat([e[2] for e in model.debug_taps["extract"]]).cpu().view(-1, 300, 256)
+    _stage_check("[R101 x1 full size] extraction", gpf, opf, gcl, ocl, gbx, obx)
+    rates = [_match_rate(r, g) for r, g in zip(ref_out, got_out)]
+    ap = _ap50_vs_oracle(ref_out, got_out, (W0, H0))
+    print(f"[R101 x1 full size] detections kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]}; "
+          f"match {['%.2f' % r for r in rates]}; AP50(GPU | oracle) = {ap:.4f}")
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write(f"[R101 x1 full size] AP50(GPU | oracle detections as ground truth) = {ap:.4f}; match rates {['%.2f' % r for r in rates]}\n")
+    assert min(rates) >= 0.9 and ap >= 0.95

@@ -25,8 +25,8 @@ f = glob.glob("/tmp/prof_stats/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(f"{out}/{tag}_kernel_stats.txt", "w") as o:
-    o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline  (DVID_CHAINS=1; 4 videos of 304 frames:\n")
-    o.write("# warm-up, timed step, tuner warm-up and instrumented pass)\n")
+    o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline  (DVID_CHAINS=1; 5 videos of 304 frames:\n")
+    o.write("# set-up, warm-up, timed step, chains=1 pass and instrumented pass)\n")
     o.write("total kernel time %.1f ms\n" % (tot / 1e6))
     ig = [r for r in rows if "igemm2_kernel" in r["Name"]]
     igt = sum(float(r["TotalDurationNs"]) for r in ig); igc = sum(int(r["Calls"]) for r in ig)
