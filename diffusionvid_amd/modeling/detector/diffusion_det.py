@@ -243,8 +243,6 @@ class DiffusionDet(nn.Module):
         ref_g = infos["ref_g"]
         h, w = imgs.image_sizes[0]
         whwh = (float(w), float(h))
-        eng = self._get_engine()
-        M = self.num_proposals
         batch = min(self.infer_batch, end_id - frame_id + 1)
         pairs = self._time_pairs()
         ahead = infos.get("ref_ahead") or {}
@@ -254,85 +252,23 @@ class DiffusionDet(nn.Module):
         # DDIM draws of every batch finished in this call, keyed and shaped exactly as that batch's own call would draw them
         ddim_draws = {fb: self._ddim_draws(nb, fb, pairs) for fb, nb in nb_of.items()} if self.sampling_timesteps > 1 else {}
 
-        # 1. features + extraction pass over [local frames | global frames] in splits of INFER_BATCH.  Every stage here
-        # (backbone, the 3 RCNNHeads, top-k feature selection) is per-frame independent, so the splits -- and with
-        # INPUT.LOOKAHEAD_BATCHES > 1 the frames of the next batches (`ref_ahead`) -- run as launches of up to
-        # INFER_BATCH * LOOKAHEAD_BATCHES frames; a batch extracted early waits in `_ahead` for its own call.
+        # 1. features + extraction pass over [local frames | global frames] (+ the look-ahead batches)
         local_split = self._ahead.pop(frame_id, None) if not ref_g else None
-        if local_split is not None:
-            ref_l_run = []
-        else:
-            ref_l_run = ref_l
-        len_l = len(ref_l_run)
-        splits, k1_all, k2_all = [], [], []
-        if ref_l_run or ref_g or ahead:
-            frames = [im.tensors for im in ref_l_run] + [im.tensors for im in ref_g]
-            n_own = len(frames)
-            # random draws: one (B, M, 4) tensor per reference split `bi` of this call, then one per look-ahead batch
-            # (drawn as that batch's own call would: split 0 of call `fb`).  All uploads happen BEFORE any kernel is
-            # queued: a host->device copy from pageable memory blocks the host until the stream has drained.
-            sizes = [min(self.infer_batch, n_own - a) for a in range(0, n_own, self.infer_batch)]
-            noise = [self._noise("box_init", frame_id, bi, 0, (b, M, 4)) for bi, b in enumerate(sizes)]
-            for fb in ahead_keys:
-                group = [to_image_list(im).tensors for im in ahead[fb]]
-                frames += group
-                noise.append(self._noise("box_init", fb, 0, 0, (len(group), M, 4)))
-            total = torch.cat(frames).to(self.device, torch.float32)
-            box_init_all = torch.cat(noise)
-            cap = self.infer_batch * self.lookahead
-            eng.reserve(min(cap, total.shape[0]), total.shape[-2], total.shape[-1], M)
-            per_frame = []          # (chunk result dict, index inside the chunk) for every frame slot of `total`
-            for ci, a in enumerate(range(0, total.shape[0], cap)):
-                chunk = total[a:a + cap].contiguous()
-                feats = eng.backbone(chunk)
-                B = chunk.shape[0]
-                t = torch.full((B,), 999, dtype=torch.long)
-                (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init_all[a:a + B], t, box_extract=ci + 1)
-                res = {"feats": feats, "logits": cl, "boxes": bx, "obj": pf[0].view(B, M, self.hidden_dim),
-                       "k1": k1.view(B, self.top_k[0], self.hidden_dim), "k2": k2.view(B, self.top_k[1], self.hidden_dim)}
-                per_frame += [(res, i) for i in range(B)]
-                if self.debug_taps is not None:
-                    self.debug_taps.setdefault("extract", []).append((cl, bx, pf[0], feats))
-
-            def take(a, b):
-                """result slots [a, b) as one split: views when they sit in one launch, else a concatenation"""
-                runs = []
-                for j in range(a, b):
-                    src, i = per_frame[j]
-                    if runs and runs[-1][0] is src:
-                        runs[-1][2] = i + 1
-                    else:
-                        runs.append([src, i, i + 1])
-                keys = ("logits", "boxes", "obj", "k1", "k2")
-                if len(runs) == 1:
-                    src, i0, i1 = runs[0]
-                    out = {k: src[k][i0:i1] for k in keys}
-                    out["feats"] = [f[i0:i1] for f in src["feats"]]
-                    out["_src"], out["_i0"], out["_i1"] = src, i0, i1          # lets neighbouring splits be re-joined as views
-                    return out
-                out = {k: torch.cat([src[k][i0:i1] for src, i0, i1 in runs]) for k in keys}
-                out["feats"] = [torch.cat([src["feats"][l][i0:i1] for src, i0, i1 in runs]) for l in range(3)]
-                return out
-
-            if len_l > self.infer_batch:
-                raise NotImplementedError("more local frames than INFER_BATCH in one call")
-            if len_l:
-                local_split = take(0, len_l)
-            if ref_g:
-                gsplit = take(len_l, n_own)
-                k1_all = [gsplit["k1"].reshape(-1, self.hidden_dim)]
-                k2_all = [gsplit["k2"].reshape(-1, self.hidden_dim)]
-            pos = n_own
-            for fb in ahead_keys:
-                nb = len(ahead[fb])
-                self._ahead[fb] = take(pos, pos + nb)
-                pos += nb
+        ref_l_run = [] if local_split is not None else ref_l
+        if len(ref_l_run) > self.infer_batch:
+            raise NotImplementedError("more local frames than INFER_BATCH in one call")
+        gsplit = None
+        if ref_l_run or ref_g or ahead_keys:
+            fresh_local, gsplit, fresh_ahead = self._extract(frame_id, ref_l_run, ref_g, {fb: ahead[fb] for fb in ahead_keys}, whwh)
+            if fresh_local is not None:
+                local_split = fresh_local
+            self._ahead.update(fresh_ahead)
         splits = [local_split]
 
         # 2. global memory, once per video with the shipped config (diffusion_det.py:479-488)
         if ref_g:
-            g1 = torch.cat(k1_all, dim=0)
-            g2 = torch.cat(k2_all, dim=0)
+            g1 = gsplit["k1"].reshape(-1, self.hidden_dim)
+            g2 = gsplit["k2"].reshape(-1, self.hidden_dim)
             m0, _ = ops.update_erase_memory(g1, self.head.proposal_feats_global[0], self.mem_management_size_test)
             m1, _ = ops.update_erase_memory(g2, self.head.proposal_feats_global[1], 150)
             self.head.proposal_feats_global = [m0, m1]
@@ -352,8 +288,9 @@ class DiffusionDet(nn.Module):
         # 4. final stage.  Per frame it needs the frame's own extraction results and the video's global memory, nothing
         # of its neighbours, so the batches extracted ahead in this call are finished here as well -- in one pass per
         # run of adjacent frames -- and their detections wait on the host side for their own calls.
-        group = [(fb, nb_of[fb], self._ahead.pop(fb)) for fb in ahead_keys if fb in self._ahead]
-        if group and n_local == self.infer_batch and batch == self.infer_batch and splits[0].get("_src") is not None:
+        joinable = n_local == self.infer_batch and batch == self.infer_batch and splits[0].get("_src") is not None
+        group = [(fb, nb_of[fb], self._ahead.pop(fb)) for fb in ahead_keys if fb in self._ahead] if joinable else []
+        if group:
             group = [(frame_id, batch, splits[0])] + group
             runs = []
             for fb, nb, sp in group:
@@ -384,6 +321,70 @@ class DiffusionDet(nn.Module):
         entries = [self.queue[i] for i in range(self.key_frame_location, self.key_frame_location + batch)]
         feats_cur, cached = self._gather_entries(entries)
         return self._final_stage(feats_cur, cached, whwh, w, h, pairs, [(frame_id, batch)], ddim_draws, slots=batch)
+
+    def _extract(self, frame_id, ref_l, ref_g, ahead, whwh):
+        """Backbone + the 3 extraction RCNNHeads + top-k feature selection over [local | global | look-ahead] frames.
+        Every stage here is per-frame independent, so the reference's splits of INFER_BATCH -- and with
+        INPUT.LOOKAHEAD_BATCHES > 1 the frames of the next batches -- run as launches of up to INFER_BATCH *
+        LOOKAHEAD_BATCHES frames.  -> (local split | None, global split | None, {batch start: split}); a split is a dict
+        of per-frame tensors (feats, logits, boxes, obj, k1, k2), views into the launch's outputs where possible."""
+        eng = self._get_engine()
+        M = self.num_proposals
+        frames = [im.tensors for im in ref_l] + [im.tensors for im in ref_g]
+        len_l, n_own = len(ref_l), len(frames)
+        # random draws: one (B, M, 4) tensor per reference split `bi` of this call, then one per look-ahead batch (drawn
+        # as that batch's own call would: split 0 of call `fb`).  All uploads happen BEFORE any kernel is queued: a
+        # host->device copy from pageable memory blocks the host until the stream has drained.
+        sizes = [min(self.infer_batch, n_own - a) for a in range(0, n_own, self.infer_batch)]
+        noise = [self._noise("box_init", frame_id, bi, 0, (b, M, 4)) for bi, b in enumerate(sizes)]
+        for fb in sorted(ahead):
+            group = [to_image_list(im).tensors for im in ahead[fb]]
+            frames += group
+            noise.append(self._noise("box_init", fb, 0, 0, (len(group), M, 4)))
+        total = torch.cat(frames).to(self.device, torch.float32)
+        box_init_all = torch.cat(noise)
+        cap = self.infer_batch * self.lookahead
+        eng.reserve(min(cap, total.shape[0]), total.shape[-2], total.shape[-1], M)
+        per_frame = []          # (launch result dict, index inside the launch) for every frame slot of `total`
+        for ci, a in enumerate(range(0, total.shape[0], cap)):
+            chunk = total[a:a + cap].contiguous()
+            feats = eng.backbone(chunk)
+            B = chunk.shape[0]
+            t = torch.full((B,), 999, dtype=torch.long)
+            (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init_all[a:a + B], t, box_extract=ci + 1)
+            res = {"feats": feats, "logits": cl, "boxes": bx, "obj": pf[0].view(B, M, self.hidden_dim),
+                   "k1": k1.view(B, self.top_k[0], self.hidden_dim), "k2": k2.view(B, self.top_k[1], self.hidden_dim)}
+            per_frame += [(res, i) for i in range(B)]
+            if self.debug_taps is not None:
+                self.debug_taps.setdefault("extract", []).append((cl, bx, pf[0], feats))
+
+        def take(a, b):
+            """result slots [a, b) as one split: views when they sit in one launch, else a concatenation"""
+            runs = []
+            for j in range(a, b):
+                src, i = per_frame[j]
+                if runs and runs[-1][0] is src:
+                    runs[-1][2] = i + 1
+                else:
+                    runs.append([src, i, i + 1])
+            keys = ("logits", "boxes", "obj", "k1", "k2")
+            if len(runs) == 1:
+                src, i0, i1 = runs[0]
+                out = {k: src[k][i0:i1] for k in keys}
+                out["feats"] = [f[i0:i1] for f in src["feats"]]
+                out["_src"], out["_i0"], out["_i1"] = src, i0, i1          # lets neighbouring splits be re-joined as views
+                return out
+            out = {k: torch.cat([src[k][i0:i1] for src, i0, i1 in runs]) for k in keys}
+            out["feats"] = [torch.cat([src["feats"][l][i0:i1] for src, i0, i1 in runs]) for l in range(3)]
+            return out
+
+        local = take(0, len_l) if len_l else None
+        glob = take(len_l, n_own) if ref_g else None
+        out_ahead, pos = {}, n_own
+        for fb in sorted(ahead):
+            out_ahead[fb] = take(pos, pos + len(ahead[fb]))
+            pos += len(ahead[fb])
+        return local, glob, out_ahead
 
     def _final_stage(self, feats, cached, whwh, w, h, pairs, items, ddim_draws, slots=None):
         """Global attention + conditioned head (+ DDIM loop) + top-k/NMS over `R` frame slots holding the batches `items`
