@@ -360,3 +360,30 @@ def test_video_e2e_full_configuration():
     with open("gpurun_out/parity_report.txt", "a") as f:
         f.write(f"[R101 x1 full size] AP50(GPU | oracle detections as ground truth) = {ap:.4f}; match rates {['%.2f' % r for r in rates]}\n")
     assert min(rates) >= 0.9 and ap >= 0.95
+
+
+@pytest.mark.parametrize("num_proposals", [100, 500])
+def test_other_num_proposals(num_proposals):
+    """MODEL.DiffusionDet.NUM_PROPOSALS other than the shipped 300 (nothing in the kernels may be tied to it): first call
+    of an 8-frame video against the CPU oracle, detections matched one to one."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.DiffusionDet.NUM_PROPOSALS", num_proposals], "configs/BASE_RCNN_1gpu.yaml")
+    cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+    model = model.to("cuda").eval()
+    model.noise_fn = synthetic.noise_fn
+    ds = SyntheticVIDDataset([8], cfg, height=250, width=380, device="cuda", smooth=True)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    oracle = odet.OracleDiffusionDet(sd, odet.DetCfg(blocks=(1, 1, 1, 1), num_proposals=num_proposals), synthetic.noise_fn)
+    images, oitem, _ = _oracle_items(ds, 0)
+    with torch.no_grad():
+        ref_out = oracle.forward(oitem)
+        got_out = model(images)
+    rates = [_match_rate(r, g) for r, g in zip(ref_out, got_out)]
+    print(f"[{num_proposals} boxes] kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]}; match {['%.2f' % r for r in rates]}")
+    assert min(rates) >= 0.9
