@@ -265,14 +265,18 @@ class Model:
             call("dvid_workspace_reserve", self.handle, *key)
             self._ws = key
 
-    def backbone(self, images):
-        """images fp32 NCHW [n,3,H,W] in [0,1] -> (p3, p4, p5) fp16 NHWC."""
+    def backbone(self, images, frames_per_launch=None):
+        """images fp32 NCHW [n,3,H,W] in [0,1] -> (p3, p4, p5) fp16 NHWC.  frames_per_launch: run the n frames as
+        consecutive launch sequences of at most that many frames (same results; smaller activation working set)."""
         images = _cuda(images, torch.float32)
         n, _, h, w = images.shape
         dev = images.device
         outs = [torch.empty((n, h >> s, w >> s, self.hidden_dim), dtype=torch.float16, device=dev) for s in (3, 4, 5)]
         fn = "dvid_backbone_swin_fpn" if self.backbone_kind == "swin" else "dvid_backbone_resnet_fpn"
-        call(fn, self.handle, ptr(images), n, h, w, ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream_ptr())
+        step = n if not frames_per_launch else max(1, min(n, int(frames_per_launch)))
+        for a in range(0, n, step):
+            b = min(n, a + step)
+            call(fn, self.handle, ptr(images[a:b]), b - a, h, w, ptr(outs[0][a:b]), ptr(outs[1][a:b]), ptr(outs[2][a:b]), stream_ptr())
         return outs
 
     def rcnn_head(self, head_index, feats_nhwc, height, width, boxes, pro_features, t, cond=None, bad_flag=None):
