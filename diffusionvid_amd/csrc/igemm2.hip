@@ -99,6 +99,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     const char* a_ptr[A_IT];
     unsigned a_mask[A_IT];
     int a_iy[A_IT], a_ix[A_IT], a_lch[A_IT];       // only used by the SMALLC (stem) path
+    int a_ty[A_IT], a_tx[A_IT];                    // SMALLC: filter tap of this lane's chunk in the current K tile
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int row = RPP * (wave + NW * i) + lrow;
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         a_ptr[i] = zero;
         a_iy[i] = -(1 << 28);
         a_ix[i] = 0;
+        a_ty[i] = SMALLC ? a_lch[i] / p.KW : 0;
+        a_tx[i] = SMALLC ? a_lch[i] - a_ty[i] * p.KW : 0;
         if (FLAT) {
             if (m < p.M) {
                 long pix = m;
@@ -173,12 +176,17 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         char* sb = sa + A_BYTES;
         if (i < A_IT) {
             if (SMALLC) {                                        // Cin == 8: one tap per 16-byte chunk
-                const int tp = kt * CHUNKS + a_lch[i];
-                const int tky = tp / p.KW, tkx = tp - tky * p.KW;
+                // this lane's tap (a_ty, a_tx) walks the filter CHUNKS taps per K step -- no division in the loop
+                const int tky = a_ty[i], tkx = a_tx[i];
                 const int iy = a_iy[i] + tky, ix = a_ix[i] + tkx;
-                const bool ok = tp < p.ntaps && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const bool ok = tky < p.KH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const char* src = ok ? a_ptr[i] + (long)((tky * p.W + tkx) * p.Cin) * 2 : zero;
                 glds16(src, sa + (wave + NW * i) * 1024);
+                a_tx[i] += CHUNKS;
+                while (a_tx[i] >= p.KW) {
+                    a_tx[i] -= p.KW;
+                    ++a_ty[i];
+                }
             } else if (FLAT) {
                 glds16(a_ptr[i], sa + (wave + NW * i) * 1024);
                 a_ptr[i] += a_mask[i];
