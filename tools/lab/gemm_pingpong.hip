@@ -1,0 +1,230 @@
+// LAB (not part of libdvid_hip): 256x256 GEMM tile with two wave groups in anti-phase.
+//
+// C[M,N] (fp16) = A[M,K] . B[N,K]^T, fp16 operands, fp32 accumulate on v_mfma_f32_32x32x16_f16 -- the same MFMA, K order
+// and LDS tile format (BK 32: 64-byte rows, XOR key (row >> 2) & 3) as csrc/igemm2.hip, so a production version stays
+// bit-identical to the other tile configurations.  8 waves = 2 groups x 4; group g owns rows [128 g, 128 g + 128) of the
+// tile, wave (g, wn) the 128 x 64 block at columns 64 wn.  Every K tile (32 wide) is handled in two slots per group,
+//   R(t): issue this wave's 4 DMA pieces of tile t + 3, read the 12 fragments of tile t, wait for them, wait for the own
+//         pieces of tile t + 1, barrier
+//   M(t): 16 MFMAs, barrier
+// and group 1 runs one slot behind group 0, so that on every SIMD one wave is in its MFMA slot while the other is in its
+// LDS / DMA slot.  Four 32-KiB stages: tile t + 3 re-uses the stage of tile t - 1, whose last fragment reads (group 1,
+// previous slot) were retired by the lgkmcnt(0) in front of that slot's barrier.
+//
+// Measured on MI355X (round 1): correct (max rel err 4e-4 vs an fp32 reference); 933 / 957 TFLOP/s at 4096^3 / 8192^3
+// (igemm2's 256x256x64/2: 806 / 923) but 680 / 758 TFLOP/s on 58368x256x1024 / x2304, i.e. no better than the tuned igemm2
+// configurations on the backbone's shapes (719 / 811-873): the coarse two-slot alternation alone is not the lever.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_pingpong.hip -o tools/lab/gemm_pingpong && tools/lab/gemm_pingpong
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+#define CHECK(x)                                                                  \
+    do {                                                                          \
+        hipError_t e_ = (x);                                                      \
+        if (e_ != hipSuccess) {                                                   \
+            printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); \
+            exit(1);                                                              \
+        }                                                                         \
+    } while (0)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void glds16(const void* g, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+constexpr int BM = 256, BN = 256, BK = 32, NSTAGE = 4;
+constexpr int STAGE = (BM + BN) * BK * 2;        // 32 KiB
+constexpr int A_BYTES = BM * BK * 2;
+
+__global__ __launch_bounds__(512) void gemm_pingpong(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C,
+                                                     int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int tiles_n = N / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = K / BK;
+
+    // DMA: wave w stages pieces {w, w + 8} of A and of B (16 rows x 64 B each); lane -> row 16 j + lane / 4, chunk lane % 4
+    const char* a_src[2];
+    const char* b_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * (wave + 8 * i) + (lane >> 2);
+        const int lch = (lane & 3) ^ ((row >> 2) & 3);
+        a_src[i] = reinterpret_cast<const char*>(A + (long)(m0 + row) * K + lch * 8);
+        b_src[i] = reinterpret_cast<const char*>(B + (long)(n0 + row) * K + lch * 8);
+    }
+    auto issue = [&](int t) {
+        char* st = smem + (t % NSTAGE) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            glds16(a_src[i] + (long)t * BK * 2, st + (wave + 8 * i) * 1024);
+            glds16(b_src[i] + (long)t * BK * 2, st + A_BYTES + (wave + 8 * i) * 1024);
+        }
+    };
+    constexpr int P = 4;      // DMA instructions per wave per tile
+
+    // fragment addressing
+    const int frow = lane & 31;
+    const int sw = (frow >> 2) & 3;
+    const int fa_off = (grp * 128 + frow) * 64;
+    const int fb_off = A_BYTES + (wn * 64 + frow) * 64;
+    int choff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) choff[ks] = ((2 * ks + (lane >> 5)) ^ sw) * 16;
+
+    float16v acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: tiles 0..2 in flight, tile 0 landed
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    if (nk > 2) wait_vmcnt<2 * P>(); else if (nk > 1) wait_vmcnt<P>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one slot behind group 0
+
+    for (int t = 0; t < nk; ++t) {
+        // ---- R(t) ---------------------------------------------------------------------------------------------
+        if (t + 3 < nk) issue(t + 3);
+        const char* st = smem + (t % NSTAGE) * STAGE;
+        half8 fa[4][2], fb[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i][ks] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * 64 + choff[ks]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j][ks] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * 64 + choff[ks]);
+        }
+        wait_lgkm0();
+        // own pieces of tile t + 1 landed (tiles t + 2, t + 3 may stay in flight; fewer exist at the tail)
+        {
+            const int later = min(nk - 1, t + 3) - (t + 1);
+            if (later >= 2) wait_vmcnt<2 * P>(); else if (later == 1) wait_vmcnt<P>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M(t) ---------------------------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // balance the extra barrier of group 1
+    __syncthreads();
+
+    // ---- epilogue: each wave stages 64 rows x 64 cols fp32 at a time in its own 16-KiB LDS slice ----------------------
+    float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 64);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = j * 32 + (lane & 31);
+                    cs[row * 64 + col] = acc[hh * 2 + i][j][r];
+                }
+        wait_lgkm0();
+        // a wave reads back only what it wrote itself: 8 lanes cover one 64-col row (8 halves each), 8 rows per pass
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+            half8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = (half_t)cs[row * 64 + c8 + e];
+            const long m = m0 + grp * 128 + hh * 64 + row;
+            *reinterpret_cast<half8*>(C + m * N + n0 + wn * 64 + c8) = hv;
+        }
+        wait_lgkm0();
+    }
+}
+
+__global__ void gemm_naive(const half_t* A, const half_t* B, float* C, int M, int N, int K) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += (float)A[(long)m * K + k] * (float)B[(long)n * K + k];
+    C[(long)m * N + n] = s;
+}
+
+int main() {
+    const int smem = NSTAGE * STAGE;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pingpong), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    struct Shape { int M, N, K; };
+    const Shape shapes[] = {{512, 512, 96}, {1024, 768, 2304}, {4096, 4096, 4096}, {8192, 8192, 8192}, {58368, 256, 1024},
+                            {58368, 256, 2304}, {126464, 256, 2304}, {14592, 512, 4608}, {58368, 1024, 512}};
+    for (const Shape& sh : shapes) {
+        const long na = (long)sh.M * sh.K, nb = (long)sh.N * sh.K, nc = (long)sh.M * sh.N;
+        std::vector<half_t> ha(na), hb(nb);
+        unsigned s = 12345u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 9) & 0xffff) / 65536.f - 0.5f; };
+        for (auto& v : ha) v = (half_t)rnd();
+        for (auto& v : hb) v = (half_t)(rnd() * 0.25f);
+        half_t *dA, *dB, *dC;
+        CHECK(hipMalloc(&dA, na * 2)); CHECK(hipMalloc(&dB, nb * 2)); CHECK(hipMalloc(&dC, nc * 2));
+        CHECK(hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dB, hb.data(), nb * 2, hipMemcpyHostToDevice));
+        const int grid = (sh.M / BM) * (sh.N / BN);
+        gemm_pingpong<<<grid, 512, smem>>>(dA, dB, dC, sh.M, sh.N, sh.K);
+        CHECK(hipDeviceSynchronize());
+        double worst = 0;
+        if ((double)sh.M * sh.N * sh.K < 3e10) {
+            float* dR;
+            CHECK(hipMalloc(&dR, nc * 4));
+            gemm_naive<<<dim3((sh.N + 255) / 256, sh.M), 256>>>(dA, dB, dR, sh.M, sh.N, sh.K);
+            std::vector<float> hr(nc);
+            std::vector<half_t> hc(nc);
+            CHECK(hipMemcpy(hr.data(), dR, nc * 4, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(hc.data(), dC, nc * 2, hipMemcpyDeviceToHost));
+            for (long i = 0; i < nc; ++i) worst = fmax(worst, fabs((double)hc[i] - hr[i]) / (1.0 + fabs(hr[i])));
+            CHECK(hipFree(dR));
+        } else {
+            worst = -1;
+        }
+        hipEvent_t a, b;
+        CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+        float best = 1e9;
+        for (int rep = 0; rep < 3; ++rep) {
+            CHECK(hipEventRecord(a));
+            for (int it = 0; it < 5; ++it) gemm_pingpong<<<grid, 512, smem>>>(dA, dB, dC, sh.M, sh.N, sh.K);
+            CHECK(hipEventRecord(b));
+            CHECK(hipEventSynchronize(b));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, a, b));
+            best = fminf(best, ms / 5);
+        }
+        printf("pingpong %6d x %5d x %5d : %8.2f us  %7.1f TFLOP/s   max rel err %s%.3e\n", sh.M, sh.N, sh.K, best * 1e3,
+               2.0 * sh.M * sh.N * sh.K / best / 1e9, worst < 0 ? "(unchecked) " : "", worst < 0 ? 0.0 : worst);
+        CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dC));
+    }
+    return 0;
+}
