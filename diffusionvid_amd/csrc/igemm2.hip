@@ -35,7 +35,8 @@ struct Smem2 {
     static constexpr int kStage = (BM + BN) * BKT * 2;
     static constexpr int kCPitch = BN + 4;
     static constexpr int kCHalf = (BM / 2) * kCPitch * 4;
-    static constexpr int kBytes = (NSTAGE * kStage > kCHalf) ? NSTAGE * kStage : kCHalf;
+    static constexpr int kRing = NSTAGE == 5 ? 4 : NSTAGE;        // NSTAGE 5 = the anti-phase schedule over a 4-stage ring
+    static constexpr int kBytes = (kRing * kStage > kCHalf) ? kRing * kStage : kCHalf;
 };
 
 template <int N>
@@ -52,6 +53,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 // NSTAGE 3, 4: ring of stages, NSTAGE - 1 DMA tiles in flight across a raw `s_barrier`; each wave waits with a
 //           COUNTED `s_waitcnt vmcnt((NSTAGE - 2) * P)` (P = its DMA pieces per tile) so only the tile about to be
 //           read has landed, and re-fills the stage freed by the previous step right after the barrier.
+// NSTAGE 5: anti-phase schedule (8 waves, 4-stage ring of BK 32 tiles).  The two wave rows (wm = 0 / 1) alternate between a
+//           read slot R(t) -- the 12 fragment reads of tile t, wait for them and for the own DMA pieces of tile t + 1 --
+//           and an MFMA slot M(t) -- 16 MFMAs with the 4 DMA pieces of tile t + 3 issued between them (a DMA piece
+//           costs its wave ~100 issue cycles; in front of the MFMAs or inside the read slot it costs 15 % throughput,
+//           tools/lab/gemm_pingpong.hip) -- one barrier per slot, row 1 one slot behind row 0, so each SIMD has one
+//           wave in its MFMA slot while the other reads.  Tile t + 3 re-uses the stage of tile t - 1, whose last reads
+//           were retired (lgkmcnt(0)) in front of the barrier that ended the previous slot.
 // WN: waves along N (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads); always 2 waves along M.
 // AK: how the A operand is addressed -- 0: filter-tap walk (KHxKW convolutions), 1: the Cin = 8 stem (one tap per
 //     16-byte chunk), 2: FLAT = 1x1 / linear with pad 0: a row of A is K contiguous halves, no taps, no masks (stride 1
@@ -72,7 +80,8 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     constexpr int KEY_SHIFT = (BKT == 64) ? 1 : 2;  // swizzle key = (row >> KEY_SHIFT) & (CHUNKS - 1)
     constexpr int TM = BM / 64, TN = BN / (32 * WN);   // 32x32 MFMA tiles per wave (waves 2 x WN)
     constexpr int A_IT = BM / RPP / NW, B_IT = BN / RPP / NW;   // DMA pieces per wave per K tile
-    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 5, "ring depth");
+    static_assert(NSTAGE != 5 || (WN == 4 && AK != 1), "the anti-phase schedule is written for 8 waves");
     static_assert(A_IT >= 1 && B_IT >= 1 && A_IT * RPP * NW == BM && B_IT * RPP * NW == BN, "tile / wave-count mismatch");
     constexpr int A_BYTES = BM * ROW_BYTES;
     constexpr int STAGE = Smem2<BM, BN, BKT, NSTAGE>::kStage;
@@ -290,7 +299,49 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         }
     };
 
-    if (NSTAGE == 2) {
+    if constexpr (NSTAGE == 5) {
+        constexpr int P = A_IT + B_IT, NM = TM * TN * KS;
+        static_assert(NSTAGE != 5 || NM % P == 0, "DMA pieces are spread evenly over the MFMAs of a tile");
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < nk) issue(kt0 + d, d);
+        if (nk > 2) wait_vmcnt<2 * P>(); else if (nk > 1) wait_vmcnt<P>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();                 // wave row 1 runs one slot behind row 0
+        for (int t = 0; t < nk; ++t) {
+            // ---- R(t)
+            const char* st = smem + (t & 3) * STAGE;
+            half8 fa[TM][KS], fb[TN][KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i][ks] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * ROW_BYTES + choff[ks]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j][ks] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * ROW_BYTES + choff[ks]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // issued so far: tiles <= t + 2; the own pieces of tile t + 1 must have landed
+            if (t + 2 < nk) wait_vmcnt<P>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- M(t)
+            const bool dma = t + 3 < nk;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                const int ks = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+                if (dma && q % (NM / P) == 1) issue_piece(kt0 + t + 3, (t + 3) & 3, q / (NM / P));
+            }
+            if (dma) advance();
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();                 // balances the extra barrier of row 1
+        __syncthreads();
+    } else if constexpr (NSTAGE == 2) {
         issue(kt0, 0);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
@@ -483,6 +534,8 @@ const TileCfg kCfgs[] = {
     {128, 256, 32, 4, &launch2<128, 256, 32, 4, false, 4>}, {128, 64, 32, 4, &launch2<128, 64, 32, 4, false>},
     // 4 waves with 64x128 per wave (128 accumulator registers): half the per-MFMA address / loop overhead of the 8-wave form
     {128, 256, 32, 3, &launch2<128, 256, 32, 3, false, 2>}, {128, 256, 64, 2, &launch2<128, 256, 64, 2, false, 2>},
+    // nstage 5: the anti-phase schedule over a 4-stage ring (see igemm2_kernel)
+    {256, 256, 32, 5, &launch2<256, 256, 32, 5, false, 4>},
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 const TileCfg kStemCfgs[] = {   // Cin == 8 stem (one filter tap per 16-byte chunk)
@@ -491,6 +544,8 @@ const TileCfg kStemCfgs[] = {   // Cin == 8 stem (one filter tap per 16-byte chu
 };
 
 bool cfg_valid(const TileCfg& c, const IgemmParams& p) {
+    static const int no_stage = getenv("DVID_IGEMM_NO_NSTAGE") ? atoi(getenv("DVID_IGEMM_NO_NSTAGE")) : -1;   // A/B measurements
+    if (c.nstage == no_stage) return false;
     if (p.splitk > 1 && (p.Kpad / c.bkt) % p.splitk) return false;
     if (c.bm > 128 && p.M < 2 * c.bm) return false;
     if (c.bn > 64 && p.Cout <= c.bn / 2) return false;          // more than half of the tile would be padding

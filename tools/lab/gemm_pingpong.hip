@@ -11,9 +11,14 @@
 // LDS / DMA slot.  Four 32-KiB stages: tile t + 3 re-uses the stage of tile t - 1, whose last fragment reads (group 1,
 // previous slot) were retired by the lgkmcnt(0) in front of that slot's barrier.
 //
-// Measured on MI355X (round 1): correct (max rel err 4e-4 vs an fp32 reference); 933 / 957 TFLOP/s at 4096^3 / 8192^3
-// (igemm2's 256x256x64/2: 806 / 923) but 680 / 758 TFLOP/s on 58368x256x1024 / x2304, i.e. no better than the tuned igemm2
-// configurations on the backbone's shapes (719 / 811-873): the coarse two-slot alternation alone is not the lever.
+// Measured on MI355X (round 1; profiles/r01_lab_gemm_pingpong.txt), TFLOP/s at 4096^3 | 58368x256x1024 | 58368x256x2304:
+//   R slot also issues the DMA (first version)            933 | 680 | 758
+//   all 4 DMA pieces between the MFMAs of the M slot     1130 | 791 | 885      <- adopted as igemm2 configuration 256x256x32/5
+//   same, both wave rows in lock-step                     975 | 687 | 783
+//   "pipe": no read slot, fragments read one tile ahead  1038 | 736 | 840
+//   same loop with the DMA removed (garbage results)     1557 | 973 | 1272
+// i.e. a DMA piece costs its wave ~100 issue cycles wherever it is placed, and that -- not LDS bandwidth, not the MFMA
+// pipe -- is what separates this structure from ~1.5 PFLOP/s.  (igemm2's 256x256x64/2: 806 | 719 | 811-873.)
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_pingpong.hip -o tools/lab/gemm_pingpong && tools/lab/gemm_pingpong
 #include <hip/hip_runtime.h>
@@ -21,6 +26,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 typedef _Float16 half_t;
@@ -47,6 +53,7 @@ constexpr int BM = 256, BN = 256, BK = 32, NSTAGE = 4;
 constexpr int STAGE = (BM + BN) * BK * 2;        // 32 KiB
 constexpr int A_BYTES = BM * BK * 2;
 
+template <bool STAGGER, bool PRIO, int RP, int ABL = 0>      // ABL (diagnostics): 1 no DMA in the loop, 2 no fragment reads; RP: DMA pieces (of 4 per tile) issued in the R slot; the rest go between the MFMAs
 __global__ __launch_bounds__(512) void gemm_pingpong(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C,
                                                      int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,42 +108,58 @@ __global__ __launch_bounds__(512) void gemm_pingpong(const half_t* __restrict__ 
     if (nk > 2) issue(2);
     if (nk > 2) wait_vmcnt<2 * P>(); else if (nk > 1) wait_vmcnt<P>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one slot behind group 0
+    if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one slot behind group 0
 
     for (int t = 0; t < nk; ++t) {
         // ---- R(t) ---------------------------------------------------------------------------------------------
-        if (t + 3 < nk) issue(t + 3);
         const char* st = smem + (t % NSTAGE) * STAGE;
         half8 fa[4][2], fb[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i][ks] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * 64 + choff[ks]);
+            for (int i = 0; i < 4; ++i) fa[i][ks] = *reinterpret_cast<const half8*>(st + ((ABL & 2) ? 0 : fa_off + i * 32 * 64 + choff[ks]));
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[j][ks] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * 64 + choff[ks]);
         }
         wait_lgkm0();
+        if (RP > 0 && t + 3 < nk && !(ABL & 1)) {
+            char* dst = smem + ((t + 3) % NSTAGE) * STAGE;
+#pragma unroll
+            for (int pc = 0; pc < RP; ++pc) {
+                if (pc < 2) glds16(a_src[pc] + (long)(t + 3) * BK * 2, dst + (wave + 8 * pc) * 1024);
+                else glds16(b_src[pc - 2] + (long)(t + 3) * BK * 2, dst + A_BYTES + (wave + 8 * (pc - 2)) * 1024);
+            }
+        }
         // own pieces of tile t + 1 landed (tiles t + 2, t + 3 may stay in flight; fewer exist at the tail)
         {
-            const int later = min(nk - 1, t + 3) - (t + 1);
-            if (later >= 2) wait_vmcnt<2 * P>(); else if (later == 1) wait_vmcnt<P>(); else wait_vmcnt<0>();
+            // issued so far: tiles <= t + 2 completely, RP pieces of tile t + 3; tile t + 1 must have landed
+            const bool t2 = t + 2 < nk, t3 = t + 3 < nk;
+            if (ABL & 1) wait_vmcnt<0>(); else if (t3) wait_vmcnt<P + RP>(); else if (t2) wait_vmcnt<P>(); else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- M(t) ---------------------------------------------------------------------------------------------
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        {
+            const bool dma = RP < 4 && t + 3 < nk && !(ABL & 1);
+            char* dst = smem + ((t + 3) % NSTAGE) * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+            for (int q = 0; q < 16; ++q) {
+                const int ks = q >> 3, i = (q >> 1) & 3, j = q & 1;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+                if (dma && (q & 3) == 1 && (q >> 2) >= RP) {          // remaining DMA pieces after MFMAs 1, 5, 9, 13
+                    const int pc = q >> 2;          // 0, 1: A pieces; 2, 3: B pieces
+                    if (pc < 2) glds16(a_src[pc] + (long)(t + 3) * BK * 2, dst + (wave + 8 * pc) * 1024);
+                    else glds16(b_src[pc - 2] + (long)(t + 3) * BK * 2, dst + A_BYTES + (wave + 8 * (pc - 2)) * 1024);
+                }
+            }
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();          // balance the extra barrier of group 1
+    if (STAGGER && grp == 0) __builtin_amdgcn_s_barrier();          // balance the extra barrier of group 1
     __syncthreads();
 
     // ---- epilogue: each wave stages 64 rows x 64 cols fp32 at a time in its own 16-KiB LDS slice ----------------------
@@ -168,6 +191,121 @@ __global__ __launch_bounds__(512) void gemm_pingpong(const half_t* __restrict__ 
     }
 }
 
+// Variant "pipe": no separate read slot.  The fragments of tile t + 1 are read (into a second register set) at the head
+// of tile t's MFMA block, the DMA pieces of tile t + 3 go between the MFMAs, one barrier per K tile.
+__global__ __launch_bounds__(512) void gemm_pipe(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C,
+                                                 int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int tiles_n = N / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = K / BK;
+    const char* a_src[2];
+    const char* b_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * (wave + 8 * i) + (lane >> 2);
+        const int lch = (lane & 3) ^ ((row >> 2) & 3);
+        a_src[i] = reinterpret_cast<const char*>(A + (long)(m0 + row) * K + lch * 8);
+        b_src[i] = reinterpret_cast<const char*>(B + (long)(n0 + row) * K + lch * 8);
+    }
+    auto piece = [&](int t, int pc) {
+        char* dst = smem + (t % NSTAGE) * STAGE;
+        if (pc < 2) glds16(a_src[pc] + (long)t * BK * 2, dst + (wave + 8 * pc) * 1024);
+        else glds16(b_src[pc - 2] + (long)t * BK * 2, dst + A_BYTES + (wave + 8 * (pc - 2)) * 1024);
+    };
+    constexpr int P = 4;
+    const int frow = lane & 31;
+    const int sw = (frow >> 2) & 3;
+    const int fa_off = (grp * 128 + frow) * 64;
+    const int fb_off = A_BYTES + (wn * 64 + frow) * 64;
+    int choff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) choff[ks] = ((2 * ks + (lane >> 5)) ^ sw) * 16;
+    float16v acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    half8 fa[2][4][2], fb[2][2][2];
+    auto read_frags = [&](int t, int buf) {
+        const char* st = smem + (t % NSTAGE) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[buf][i][ks] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * 64 + choff[ks]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[buf][j][ks] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * 64 + choff[ks]);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (d < nk)
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) piece(d, pc);
+    if (nk > 2) wait_vmcnt<2 * P>(); else if (nk > 1) wait_vmcnt<P>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0);
+    if (nk > 2) wait_vmcnt<P>(); else wait_vmcnt<0>();          // tile 1
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+
+    auto step = [&](int t, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        if (t + 1 < nk) read_frags(t + 1, buf ^ 1);
+        const bool dma = t + 3 < nk;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ks = q >> 3, i = (q >> 1) & 3, j = q & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[buf][i][ks], fb[buf][j][ks], acc[i][j], 0, 0, 0);
+            if (dma && (q & 3) == 1) piece(t + 3, q >> 2);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        wait_lgkm0();
+        // own pieces of tile t + 2 landed; tile t + 3 (if issued) may stay in flight
+        if (t + 3 < nk) wait_vmcnt<P>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    };
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        step(t, std::integral_constant<int, 0>{});
+        step(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (t < nk) step(t, std::integral_constant<int, 0>{});
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 64);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = j * 32 + (lane & 31);
+                    cs[row * 64 + col] = acc[hh * 2 + i][j][r];
+                }
+        wait_lgkm0();
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+            half8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = (half_t)cs[row * 64 + c8 + e];
+            const long m = m0 + grp * 128 + hh * 64 + row;
+            *reinterpret_cast<half8*>(C + m * N + n0 + wn * 64 + c8) = hv;
+        }
+        wait_lgkm0();
+    }
+}
+
 __global__ void gemm_naive(const half_t* A, const half_t* B, float* C, int M, int N, int K) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (n >= N) return;
@@ -178,10 +316,14 @@ __global__ void gemm_naive(const half_t* A, const half_t* B, float* C, int M, in
 
 int main() {
     const int smem = NSTAGE * STAGE;
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pingpong), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    typedef void (*kern_t)(const half_t*, const half_t*, half_t*, int, int, int);
+    const kern_t kerns[3] = {gemm_pingpong<true, true, 0>, gemm_pingpong<true, true, 0, 1>, gemm_pingpong<true, false, 0>};
+    const char* names[3] = {"pingpong R0/M4", "  ... without DMA", "  ... no setprio"};
+    for (int v = 0; v < 3; ++v) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    for (int v = 0; v < 3; ++v) {
+    const kern_t gemm_kernel = kerns[v];
     struct Shape { int M, N, K; };
-    const Shape shapes[] = {{512, 512, 96}, {1024, 768, 2304}, {4096, 4096, 4096}, {8192, 8192, 8192}, {58368, 256, 1024},
-                            {58368, 256, 2304}, {126464, 256, 2304}, {14592, 512, 4608}, {58368, 1024, 512}};
+    const Shape shapes[] = {{512, 512, 96}, {4096, 4096, 4096}, {58368, 256, 1024}, {58368, 256, 2304}, {126464, 256, 2304}};
     for (const Shape& sh : shapes) {
         const long na = (long)sh.M * sh.K, nb = (long)sh.N * sh.K, nc = (long)sh.M * sh.N;
         std::vector<half_t> ha(na), hb(nb);
@@ -194,7 +336,7 @@ int main() {
         CHECK(hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(dB, hb.data(), nb * 2, hipMemcpyHostToDevice));
         const int grid = (sh.M / BM) * (sh.N / BN);
-        gemm_pingpong<<<grid, 512, smem>>>(dA, dB, dC, sh.M, sh.N, sh.K);
+        gemm_kernel<<<grid, 512, smem>>>(dA, dB, dC, sh.M, sh.N, sh.K);
         CHECK(hipDeviceSynchronize());
         double worst = 0;
         if ((double)sh.M * sh.N * sh.K < 3e10) {
@@ -215,16 +357,17 @@ int main() {
         float best = 1e9;
         for (int rep = 0; rep < 3; ++rep) {
             CHECK(hipEventRecord(a));
-            for (int it = 0; it < 5; ++it) gemm_pingpong<<<grid, 512, smem>>>(dA, dB, dC, sh.M, sh.N, sh.K);
+            for (int it = 0; it < 5; ++it) gemm_kernel<<<grid, 512, smem>>>(dA, dB, dC, sh.M, sh.N, sh.K);
             CHECK(hipEventRecord(b));
             CHECK(hipEventSynchronize(b));
             float ms;
             CHECK(hipEventElapsedTime(&ms, a, b));
             best = fminf(best, ms / 5);
         }
-        printf("pingpong %6d x %5d x %5d : %8.2f us  %7.1f TFLOP/s   max rel err %s%.3e\n", sh.M, sh.N, sh.K, best * 1e3,
+        printf("%-14s %6d x %5d x %5d : %8.2f us  %7.1f TFLOP/s   max rel err %s%.3e\n", names[v], sh.M, sh.N, sh.K, best * 1e3,
                2.0 * sh.M * sh.N * sh.K / best / 1e9, worst < 0 ? "(unchecked) " : "", worst < 0 ? 0.0 : worst);
         CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dC));
+    }
     }
     return 0;
 }
