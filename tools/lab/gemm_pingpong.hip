@@ -16,9 +16,11 @@
 //   all 4 DMA pieces between the MFMAs of the M slot     1130 | 791 | 885      <- adopted as igemm2 configuration 256x256x32/5
 //   same, both wave rows in lock-step                     975 | 687 | 783
 //   "pipe": no read slot, fragments read one tile ahead  1038 | 736 | 840
+//   "bdirect": B fragments global -> VGPR, only A by DMA   789 | 589 | 569     (fragment-shaped loads are dear)
+//   all DMA pieces in the R slot after its reads         1023 | 740 | 820
 //   same loop with the DMA removed (garbage results)     1557 | 973 | 1272
-// i.e. a DMA piece costs its wave ~100 issue cycles wherever it is placed, and that -- not LDS bandwidth, not the MFMA
-// pipe -- is what separates this structure from ~1.5 PFLOP/s.  (igemm2's 256x256x64/2: 806 | 719 | 811-873.)
+// i.e. the global -> LDS DMA of the two operands costs ~0.25 us per 256x256x32 step wherever its instructions are placed
+// (between MFMAs, in the read slot, after the reads), and that is what separates this structure from ~1.5 PFLOP/s.  (igemm2's 256x256x64/2: 806 | 719 | 811-873.)
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_pingpong.hip -o tools/lab/gemm_pingpong && tools/lab/gemm_pingpong
 #include <hip/hip_runtime.h>
@@ -306,6 +308,136 @@ __global__ __launch_bounds__(512) void gemm_pipe(const half_t* __restrict__ A, c
     }
 }
 
+// Variant "bdirect": the B operand never touches LDS.  Every wave loads its own B fragments (64 columns x 32 k) straight
+// from global / L2 into registers in MFMA layout, two tiles ahead; only A goes through the DMA ring.  Halves the LDS writes
+// and removes a third of the fragment reads.  Anti-phase schedule as above; loads beyond the last tile are clamped
+// re-loads so that every slot issues the same number of VMEM operations (uniform vmcnt bookkeeping).
+__global__ __launch_bounds__(512) void gemm_bdirect(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C,
+                                                    int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ASTAGE = BM * BK * 2;          // 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int tiles_n = N / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = K / BK;
+    const char* a_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * (wave + 8 * i) + (lane >> 2);
+        const int lch = (lane & 3) ^ ((row >> 2) & 3);
+        a_src[i] = reinterpret_cast<const char*>(A + (long)(m0 + row) * K + lch * 8);
+    }
+    // B fragment (j, ks): row n0 + 64 wn + 32 j + (lane & 31), halves [32 t + 16 ks + 8 (lane >> 5), +8)
+    const char* b_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_src[j] = reinterpret_cast<const char*>(B + (long)(n0 + wn * 64 + j * 32 + (lane & 31)) * K + (lane >> 5) * 8);
+    auto a_piece = [&](int t, int pc) {
+        const int tc = min(t, nk - 1);
+        glds16(a_src[pc] + (long)tc * BK * 2, smem + (t & 3) * ASTAGE + (wave + 8 * pc) * 1024);
+    };
+    const int frow = lane & 31;
+    const int sw = (frow >> 2) & 3;
+    const int fa_off = (grp * 128 + frow) * 64;
+    int choff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) choff[ks] = ((2 * ks + (lane >> 5)) ^ sw) * 16;
+    float16v acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    half8 fbr[3][2][2];
+    auto b_load = [&](int t, auto setc) {
+        constexpr int set = decltype(setc)::value;
+        const int tc = min(t, nk - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fbr[set][j][ks] = *reinterpret_cast<const half8*>(b_src[j] + ((long)tc * BK + ks * 16) * 2);
+    };
+    // prologue: A tiles 0..2 (6 ops), B sets for tiles 0, 1 (8 ops)
+    a_piece(0, 0); a_piece(0, 1); a_piece(1, 0); a_piece(1, 1);
+    b_load(0, std::integral_constant<int, 0>{});
+    a_piece(2, 0); a_piece(2, 1);
+    b_load(1, std::integral_constant<int, 1>{});
+    // A tile 0 landed everywhere: everything but the last 6 ops (A(2) x2, B(1) x4) of this wave
+    wait_vmcnt<6>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    auto step = [&](int t, auto setc) {
+        constexpr int set = decltype(setc)::value;
+        constexpr int set2 = (set + 2) % 3;
+        // ---- R(t): A fragments from LDS
+        const char* st = smem + (t & 3) * ASTAGE;
+        half8 fa[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i][ks] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * 64 + choff[ks]);
+        wait_lgkm0();
+        // VMEM order so far: ... [M(t-2): B(t) x4, A(t+1) x2] [M(t-1): B(t+1) x4, A(t+2) x2]; B(t) and A(t+1) must be complete
+        wait_vmcnt<6>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M(t): 16 MFMAs; B(t+2) loads and A(t+3) DMA pieces between them
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ks = q >> 3, i = (q >> 1) & 3, j = q & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fbr[set][j][ks], acc[i][j], 0, 0, 0);
+            if (q == 1) b_load(t + 2, std::integral_constant<int, set2>{});
+            if (q == 9) a_piece(t + 3, 0);
+            if (q == 13) a_piece(t + 3, 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int t = 0;
+    for (; t + 2 < nk; t += 3) {
+        step(t, std::integral_constant<int, 0>{});
+        step(t + 1, std::integral_constant<int, 1>{});
+        step(t + 2, std::integral_constant<int, 2>{});
+    }
+    if (t < nk) step(t, std::integral_constant<int, 0>{});
+    if (t + 1 < nk) step(t + 1, std::integral_constant<int, 1>{});
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    wait_vmcnt<0>();
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 64);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = j * 32 + (lane & 31);
+                    cs[row * 64 + col] = acc[hh * 2 + i][j][r];
+                }
+        wait_lgkm0();
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+            half8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = (half_t)cs[row * 64 + c8 + e];
+            const long m = m0 + grp * 128 + hh * 64 + row;
+            *reinterpret_cast<half8*>(C + m * N + n0 + wn * 64 + c8) = hv;
+        }
+        wait_lgkm0();
+    }
+}
+
 __global__ void gemm_naive(const half_t* A, const half_t* B, float* C, int M, int N, int K) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (n >= N) return;
@@ -317,8 +449,8 @@ __global__ void gemm_naive(const half_t* A, const half_t* B, float* C, int M, in
 int main() {
     const int smem = NSTAGE * STAGE;
     typedef void (*kern_t)(const half_t*, const half_t*, half_t*, int, int, int);
-    const kern_t kerns[3] = {gemm_pingpong<true, true, 0>, gemm_pingpong<true, true, 0, 1>, gemm_pingpong<true, false, 0>};
-    const char* names[3] = {"pingpong R0/M4", "  ... without DMA", "  ... no setprio"};
+    const kern_t kerns[3] = {gemm_pingpong<true, true, 0>, gemm_bdirect, gemm_pipe};
+    const char* names[3] = {"pingpong R0/M4", "bdirect", "pipe"};
     for (int v = 0; v < 3; ++v) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     for (int v = 0; v < 3; ++v) {
     const kern_t gemm_kernel = kerns[v];
