@@ -19,7 +19,7 @@ host sync; --lookahead 1 is the reference's schedule and gives the same detectio
 
 Extra objects on the JSON line:
   roofline     the dominant kernel is the implicit-GEMM MFMA conv/linear kernel (igemm2_kernel<...>, ~80 % of the
-               GPU time, profiles/r01g_kernel_stats.txt).  An instrumented repeat of one step right after the timed
+               GPU time, profiles/r01h_kernel_stats.txt).  An instrumented repeat of one step right after the timed
                region brackets every launch with HIP events on its launch stream (sub-batch chains off, so launches
                do not overlap) and sums durations, algorithmic FLOP (2*M*N*K) and algorithmic HBM bytes (input +
                weights + output + residual, each once).  The bound is the lower roof at the measured intensity
@@ -50,7 +50,7 @@ from diffusionvid_amd.engine import inference as engine  # noqa: E402
 from diffusionvid_amd.modeling.detector import build_detection_model  # noqa: E402
 from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
-TRAFFIC_FILE = "r01g_pmc_igemm_traffic.json"
+TRAFFIC_FILE = "r01h_pmc_igemm_traffic.json"
 PEAK_FP16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
