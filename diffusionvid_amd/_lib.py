@@ -40,6 +40,7 @@ SIGNATURES = {
     "dvid_rcnn_head": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                c_void_p, C.POINTER(c_int64), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvid_global_xattn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "dvid_global_memory_project": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "dvid_roialign_v2_multilevel": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                             c_void_p, c_void_p, c_void_p]),
     "dvid_select_topk_features": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,

@@ -182,6 +182,8 @@ struct dvid_model {
     std::map<std::pair<int, std::vector<int64_t>>, DevBuf> ss_tables;   // (head slot, t vector) -> device scale/shift table
     std::map<std::pair<int, int64_t>, std::vector<float>> ss_rows;     // (head slot, t) -> host row [bt_out]
 
+    int mem_lk = 0;       // rows of the global memory whose K/V projections sit in kvproj (0: none)
+
     // sub-batch chains (see dvid_backbone_resnet_fpn)
     int nchain = 2;
     hipStream_t cs[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -773,8 +775,9 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
     g_err[0] = 0;
     if (!m || !m->finalized || !m->has_backbone || m->cfg.backbone_type != 0)
         FAIL(DVID_ERR_STATE, "model not finalized or built without a ResNet backbone");
-    if (n > m->ws_frames || height != m->ws_h || width != m->ws_w)
-        FAIL(DVID_ERR_STATE, "workspace reserved for %d frames of %dx%d, got %d of %dx%d", m->ws_frames, m->ws_h, m->ws_w, n,
+    // capacity, not equality: a set mixes frame sizes (ImageNet-VID has 16:9 and 4:3 videos) and the workspace only grows
+    if (n > m->ws_frames || height > m->ws_h || width > m->ws_w || height % 32 || width % 32)
+        FAIL(DVID_ERR_STATE, "workspace reserved for %d frames of up to %dx%d, got %d of %dx%d", m->ws_frames, m->ws_h, m->ws_w, n,
              height, width);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float mean[3], inv_std[3];
@@ -788,7 +791,6 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
     const int nchain = (m->nchain > 1 && n >= 2 * m->nchain) ? m->nchain : 1;
     if (nchain > 1) TRY(m->ensure_streams());
     const int per = (n + nchain - 1) / nchain;
-    const size_t cap_frames = (size_t)(m->ws_frames + nchain - 1) / nchain;      // workspace slice of one chain
     const size_t px = (size_t)height * width, px4 = px / 16;
     if (nchain > 1) {
         HIP_TRY(hipEventRecord(m->ev_fork, s));
@@ -798,19 +800,21 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
         const int f0 = c * per, nf = (f0 + per <= n) ? per : n - f0;
         if (nf <= 0) continue;
         hipStream_t cs = nchain > 1 ? m->cs[c] : s;
-        // this chain's slice of every workspace buffer (sized for cap_frames frames)
-        half_t* img8 = m->img8.as<half_t>() + c * cap_frames * px * 8;
-        const size_t big = cap_frames * px4 * 256;
-        half_t* bx = m->bufX.as<half_t>() + c * big;
-        half_t* by = m->bufY.as<half_t>() + c * big;
-        half_t* t1 = m->bufT1.as<half_t>() + c * big;
-        half_t* t2 = m->bufT2.as<half_t>() + c * big;
-        half_t* sc = m->bufSC.as<half_t>() + c * big;
-        half_t* stage_out[4] = {nullptr, m->c3.as<half_t>() + c * cap_frames * (px4 / 4) * 512,
-                                m->c4.as<half_t>() + c * cap_frames * (px4 / 16) * 1024,
-                                m->c5.as<half_t>() + c * cap_frames * (px4 / 64) * 2048};
+        // this chain's slice of every workspace buffer starts at its first frame (f0 + nf <= n <= ws_frames for any
+        // chain count, so no slice can run past the end)
+        const size_t fo = (size_t)f0;
+        half_t* img8 = m->img8.as<half_t>() + fo * px * 8;
+        const size_t big = fo * px4 * 256;
+        half_t* bx = m->bufX.as<half_t>() + big;
+        half_t* by = m->bufY.as<half_t>() + big;
+        half_t* t1 = m->bufT1.as<half_t>() + big;
+        half_t* t2 = m->bufT2.as<half_t>() + big;
+        half_t* sc = m->bufSC.as<half_t>() + big;
+        half_t* stage_out[4] = {nullptr, m->c3.as<half_t>() + fo * (px4 / 4) * 512,
+                                m->c4.as<half_t>() + fo * (px4 / 16) * 1024,
+                                m->c5.as<half_t>() + fo * (px4 / 64) * 2048};
         half_t* lat[3];
-        for (int l = 0; l < 3; ++l) lat[l] = m->lat[l].as<half_t>() + c * cap_frames * (px4 / (4 << (2 * l))) * 256;
+        for (int l = 0; l < 3; ++l) lat[l] = m->lat[l].as<half_t>() + fo * (px4 / (4 << (2 * l))) * 256;
 
         TRY(dvid_prep_images_launch(images + (size_t)f0 * 3 * px, img8, nf, height, width, mean, inv_std, cs));
         int h = height, w = width;
@@ -863,8 +867,9 @@ int dvid_backbone_swin_fpn(dvid_model* m, const float* images, int n, int height
                            void* stream) {
     g_err[0] = 0;
     if (!m || !m->finalized || !m->has_backbone || m->cfg.backbone_type != 1) FAIL(DVID_ERR_STATE, "model has no Swin backbone");
-    if (n > m->ws_frames || height != m->ws_h || width != m->ws_w)
-        FAIL(DVID_ERR_STATE, "workspace reserved for %d frames of %dx%d, got %d of %dx%d", m->ws_frames, m->ws_h, m->ws_w, n,
+    // capacity, not equality: a set mixes frame sizes (ImageNet-VID has 16:9 and 4:3 videos) and the workspace only grows
+    if (n > m->ws_frames || height > m->ws_h || width > m->ws_w || height % 32 || width % 32)
+        FAIL(DVID_ERR_STATE, "workspace reserved for %d frames of up to %dx%d, got %d of %dx%d", m->ws_frames, m->ws_h, m->ws_w, n,
              height, width);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float mean[3], inv_std[3];
@@ -981,13 +986,12 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
         for (int c = 0; c < nchain; ++c) HIP_TRY(hipStreamWaitEvent(m->cs[c], m->ev_fork, 0));
     }
     const int per = (n_frames + nchain - 1) / nchain;
-    const size_t cap_rows = (size_t)((m->ws_frames + nchain - 1) / nchain) * m->ws_boxes;    // workspace slice of one chain
     const size_t lk_pad = ((size_t)M + 31) / 32 * 32 + 32;
     for (int c = 0; c < nchain; ++c) {
         const int f0 = c * per, nf = (f0 + per <= n_frames) ? per : n_frames - f0;
         if (nf <= 0) continue;
         TRY(rcnn_head_chain(m, hw, is_cond, p3, p4, p5, f0, nf, height, width, M, boxes, pro_features, cond, logits, boxes_out,
-                            obj_features, bad_box_flag, ss_dev, c * cap_rows, c * (size_t)((m->ws_frames + nchain - 1) / nchain) * m->cfg.nheads * 32 * lk_pad,
+                            obj_features, bad_box_flag, ss_dev, (size_t)f0 * M, (size_t)f0 * m->cfg.nheads * 32 * lk_pad,
                             nchain > 1 ? m->cs[c] : s));
         if (nchain > 1) {
             HIP_TRY(hipEventRecord(m->ev_join[c], m->cs[c]));
@@ -997,18 +1001,37 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
     return DVID_OK;
 }
 
+// K/V projections of the global memory (box_head.py:366-380 recomputes them on every call; they depend on the per-video
+// memory only): projected once per memory update and kept until the next one.
+int dvid_global_memory_project(dvid_model* m, const float* memory, int lk, void* stream) {
+    g_err[0] = 0;
+    if (!m || !m->finalized || !m->gq.w) FAIL(DVID_ERR_STATE, "model not finalized or has no global attention");
+    if (!memory || lk <= 0) FAIL(DVID_ERR_ARG, "empty memory");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int d = m->cfg.hidden_dim;
+    m->mem_lk = 0;
+    TRY(m->kvproj.ensure((size_t)lk * 2 * d * 4));
+    TRY(m->mem16.ensure((size_t)lk * d * 2));
+    TRY(dvid_f32_to_f16_launch(memory, m->mem16.as<half_t>(), (long)lk * d, s));
+    TRY(linear_run(m->gkv, m->mem16.as<half_t>(), lk, m->kvproj.p, 0, 0, s));
+    m->mem_lk = lk;
+    return DVID_OK;
+}
+
 int dvid_global_xattn(dvid_model* m, const float* query, int rows, const float* memory, int lk, float* out, void* stream) {
     g_err[0] = 0;
     if (!m || !m->finalized || !m->gq.w) FAIL(DVID_ERR_STATE, "model not finalized or has no global attention");
     if (rows > m->ws_frames * m->ws_boxes) FAIL(DVID_ERR_STATE, "workspace too small");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int d = m->cfg.hidden_dim;
-    TRY(m->kvproj.ensure((size_t)lk * 2 * d * 4));
-    TRY(m->mem16.ensure((size_t)lk * d * 2));
+    if (memory) {
+        TRY(dvid_global_memory_project(m, memory, lk, stream));
+    } else if (m->mem_lk <= 0 || (lk > 0 && lk != m->mem_lk)) {
+        FAIL(DVID_ERR_STATE, "no projected global memory of %d rows (call dvid_global_memory_project)", lk);
+    }
+    lk = m->mem_lk;
     TRY(dvid_f32_to_f16_launch(query, m->h16a.as<half_t>(), (long)rows * d, s));
-    TRY(dvid_f32_to_f16_launch(memory, m->mem16.as<half_t>(), (long)lk * d, s));
     TRY(linear_run(m->gq, m->h16a.as<half_t>(), rows, m->h16b.p, 0, 0, s));
-    TRY(linear_run(m->gkv, m->mem16.as<half_t>(), lk, m->kvproj.p, 0, 0, s));
     const half_t* kv = m->kvproj.as<half_t>();
     TRY(m->vt.ensure((size_t)m->cfg.nheads * 32 * (((size_t)lk + 31) / 32 * 32 + 32) * 2));
     TRY(dvid_mha_mfma_launch(m->h16b.as<half_t>(), kv, kv + d, m->attn16.as<half_t>(), m->vt.as<half_t>(), 1, rows, lk, m->cfg.nheads,

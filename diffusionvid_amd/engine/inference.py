@@ -35,11 +35,23 @@ def compute_on_dataset(model, dataset, indices, device, timer=None):
     return results
 
 
-def pack_predictions(results, max_det):
+def max_detections(results):
+    """largest per-frame detection count of a shard (the x4 ensemble keeps up to 3 x NUM_PROPOSALS candidates through
+    NMS, diffusion_det.py:607-627, so the count is a property of the data, not of the config)"""
+    return max((len(bl) for bl in results.values()), default=0)
+
+
+def pack_predictions(results, max_det=None):
     """dict{id: BoxList} -> (ids [n] int64, counts [n] int32, dets [n, max_det, 6] fp32 = box4, score, label,
-    sizes [n,2] int32)."""
+    sizes [n,2] int32).  max_det None = the shard's own maximum; a smaller explicit value is an error (nothing is
+    truncated silently)."""
     ids = sorted(results.keys())
     n = len(ids)
+    need = max_detections(results)
+    if max_det is None:
+        max_det = need
+    elif need > max_det:
+        raise ValueError("a frame holds %d detections but max_det is %d" % (need, max_det))
     dets = torch.zeros((n, max_det, 6), dtype=torch.float32)
     counts = torch.zeros((n,), dtype=torch.int32)
     sizes = torch.zeros((n, 2), dtype=torch.int32)
@@ -66,17 +78,21 @@ def unpack_predictions(ids, counts, dets, sizes):
     return out
 
 
-def gather_predictions(results, max_det, device=None):
-    """Gather every rank's {image_id: BoxList} on rank 0 (returns None elsewhere)."""
+def gather_predictions(results, max_det=None, device=None):
+    """Gather every rank's {image_id: BoxList} on rank 0 (returns None elsewhere).  The padded per-frame capacity is
+    the maximum detection count over all ranks (exchanged with the shard sizes) unless `max_det` forces a larger one."""
     world = comm.get_world_size()
     if world == 1:
         return results
     dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
-    ids, counts, dets, sizes = pack_predictions(results, max_det)
-    n_local = torch.tensor([ids.numel()], dtype=torch.int64, device=dev)
+    n_local = torch.tensor([len(results), max_detections(results)], dtype=torch.int64, device=dev)
     all_n = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(all_n, n_local)                       # 8 bytes per rank: shard sizes
-    n_max = int(max(int(x.item()) for x in all_n))
+    dist.all_gather(all_n, n_local)                       # 16 bytes per rank: shard size, largest detection count
+    all_n = [x.cpu() for x in all_n]
+    n_max = int(max(int(x[0]) for x in all_n))
+    det_max = max([int(x[1]) for x in all_n] + [int(max_det or 0), 1])
+    ids, counts, dets, sizes = pack_predictions(results, det_max)
+    all_n = [x[:1] for x in all_n]
 
     def pad(t):
         p = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype)
@@ -106,7 +122,7 @@ def predictions_list(merged):
     return [merged[i] for i in ids]
 
 
-def inference(model, dataset, indices, device, output_folder=None, gt_boxlists=None, max_det=300):
+def inference(model, dataset, indices, device, output_folder=None, gt_boxlists=None, max_det=None):
     """Reference `inference` (mega_core/engine/inference.py:118-181) for the in-scope path: run this rank's
     contiguous share, gather on rank 0, write `predictions.pth`, and -- when ground truth is supplied -- the
     VID AP50 of data/evaluation/vid_eval.py.  Returns (predictions list | None off rank 0, eval dict | None)."""

@@ -77,6 +77,18 @@ class DiffusionDet(nn.Module):
         self.infer_batch = cfg.INPUT.INFER_BATCH
         self.lookahead = max(1, int(getattr(cfg.INPUT, "LOOKAHEAD_BATCHES", 1)))
         self.size_divisibility = 32
+        if self.lookahead > 1:
+            # The look-ahead schedule finishes later batches inside the group's call: that equals the reference only when
+            # a batch is exactly one full local queue starting at its key frame, and the global memory is final after the
+            # video's first call (later `ref_g` deliveries would otherwise be missed by the batches finished early).
+            ok = (self.key_frame_location == 0 and self.all_frame_interval == self.infer_batch == mega.MAX_OFFSET + 1
+                  and (not mega.GLOBAL.ENABLE or mega.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST))
+            if not ok:
+                raise NotImplementedError(
+                    "INPUT.LOOKAHEAD_BATCHES > 1 needs KEY_FRAME_LOCATION 0, ALL_FRAME_INTERVAL == INFER_BATCH == MAX_OFFSET + 1 "
+                    "and GLOBAL.STOP_UPDATE_AFTER_INIT_TEST True (got %d, %d, %d, %d, %s)"
+                    % (self.key_frame_location, self.all_frame_interval, self.infer_batch, mega.MAX_OFFSET,
+                       mega.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST))
         if list(self.in_features) != ["p3", "p4", "p5"]:
             raise NotImplementedError("ROI_HEADS.IN_FEATURES must be [p3, p4, p5] (configs/vid_*_DiffusionVID.yaml)")
         self.swin = None
@@ -154,6 +166,8 @@ class DiffusionDet(nn.Module):
         if self._engine is None:
             d = self.cfg.MODEL.DiffusionDet
             sd = {k: v for k, v in self.state_dict().items()}
+            if self.device.type == "cuda" and self.device.index is not None:
+                torch.cuda.set_device(self.device)        # the library allocates on the current device
             self._engine = ops.Model(
                 sd, hidden_dim=d.HIDDEN_DIM, nheads=d.NHEADS, dim_feedforward=d.DIM_FEEDFORWARD, dim_dynamic=d.DIM_DYNAMIC,
                 num_classes=d.NUM_CLASSES, num_cls=d.NUM_CLS, num_reg=d.NUM_REG, num_heads=d.NUM_HEADS,
@@ -164,6 +178,21 @@ class DiffusionDet(nn.Module):
                                                       swin_depths=tuple(self.swin["depths"]), swin_heads=tuple(self.swin["heads"]),
                                                       swin_window=self.swin["window"])))
         return self._engine
+
+    def _apply(self, fn, *args, **kwargs):
+        """`.to()` / `.cuda()` move parameters through here: keep `self.device` (noise, time steps, the engine's
+        device) in step with them, and drop an engine built for another device."""
+        out = super()._apply(fn, *args, **kwargs)
+        try:
+            dev = next(self.parameters()).device
+        except StopIteration:
+            return out
+        if dev != self.device:
+            self.device = dev
+            if self._engine is not None:
+                self._engine.close()
+                self._engine = None
+        return out
 
     def load_state_dict(self, state_dict, strict=True):
         out = super().load_state_dict(state_dict, strict=strict)
@@ -253,7 +282,9 @@ class DiffusionDet(nn.Module):
         ddim_draws = {fb: self._ddim_draws(nb, fb, pairs) for fb, nb in nb_of.items()} if self.sampling_timesteps > 1 else {}
 
         # 1. features + extraction pass over [local frames | global frames] (+ the look-ahead batches)
-        local_split = self._ahead.pop(frame_id, None) if not ref_g else None
+        local_split = self._ahead.pop(frame_id, None)
+        if ref_g:
+            local_split = None          # a call that delivers global frames re-extracts its local frames with them
         ref_l_run = [] if local_split is not None else ref_l
         if len(ref_l_run) > self.infer_batch:
             raise NotImplementedError("more local frames than INFER_BATCH in one call")

@@ -251,6 +251,7 @@ class Model:
             _lib.check(lib.dvid_model_set_tensor(h, name.encode(), t.data_ptr(), shape, t.dim()), f"set_tensor({name})")
         _lib.check(lib.dvid_model_finalize(h), "dvid_model_finalize")
         self._ws = None
+        self._kv_src = None
 
     def set_chains(self, n):
         """concurrent sub-batch chains inside the library (1 = sequential kernels, for per-kernel profiling)"""
@@ -301,9 +302,16 @@ class Model:
         return logits, boxes_out, obj
 
     def global_xattn(self, query, memory):
-        query, memory = _cuda(query, torch.float32), _cuda(memory, torch.float32)
+        """cond = MHA(query, memory, memory).  The K/V projections of `memory` are computed when the tensor object (or its
+        in-place version counter) differs from the one projected last, i.e. once per memory update of a video."""
+        query = _cuda(query, torch.float32)
+        key = (memory, memory._version)
+        if self._kv_src is None or self._kv_src[0] is not memory or self._kv_src[1] != memory._version:
+            mem = _cuda(memory, torch.float32)
+            call("dvid_global_memory_project", self.handle, ptr(mem), mem.shape[0], stream_ptr())
+            self._kv_src = key               # holds the tensor: its storage cannot be recycled under the cache
         out = torch.empty_like(query)
-        call("dvid_global_xattn", self.handle, ptr(query), query.shape[0], ptr(memory), memory.shape[0], ptr(out), stream_ptr())
+        call("dvid_global_xattn", self.handle, ptr(query), query.shape[0], None, memory.shape[0], ptr(out), stream_ptr())
         return out
 
     def close(self):

@@ -109,8 +109,12 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
                    const int64_t* t, const float* cond, float* logits, float* boxes_out, float* obj_features,
                    int* bad_box_flag, void* stream);
 
-/* cond[R,hidden] = MHA(query = obj_features[R,hidden], key = value = memory[lk,hidden]) */
+/* cond[R,hidden] = MHA(query = obj_features[R,hidden], key = value = memory[lk,hidden]).  memory == NULL: use the K/V
+ * projections kept by the last dvid_global_memory_project (lk 0 or the same row count). */
 int dvid_global_xattn(dvid_model* m, const float* query, int rows, const float* memory, int lk, float* out, void* stream);
+/* Project the video's global memory [lk, hidden] to K/V once (box_head.py:366-380 re-projects the same rows on every
+ * call); valid until the next call of this function. */
+int dvid_global_memory_project(dvid_model* m, const float* memory, int lk, void* stream);
 
 /* ---- stand-alone ops (also used by the parity tests) -------------------------------------- */
 int dvid_roialign_v2_multilevel(const void* p3, const void* p4, const void* p5, int n_frames, int height, int width,

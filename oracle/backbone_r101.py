@@ -10,6 +10,9 @@ Parameter names follow detectron2 (`backbone.bottom_up.*`, `backbone.fpn_*`).
 import torch
 import torch.nn.functional as F
 
+from . import precision
+from .precision import a16, w16
+
 R101_BLOCKS = (3, 4, 23, 3)
 R50_BLOCKS = (3, 4, 6, 3)
 
@@ -27,9 +30,22 @@ def _frozen_bn(x, sd, name, eps=1e-5):
                         sd[name + ".weight"], sd[name + ".bias"], training=False, eps=eps)
 
 
-def _conv_bn(x, sd, name, stride=1, padding=0, relu=False):
+def _conv_bn(x, sd, name, stride=1, padding=0, relu=False, residual=None):
+    if precision.is_fp16():
+        # the runtime's repack (csrc/model.hip make_conv_bn): FrozenBN folded into the weights before the fp16 rounding,
+        # fp32 bias; one fp16 store after bias (+ residual) (+ ReLU)
+        eps = 1e-5
+        sc = sd[name + ".norm.weight"] / torch.sqrt(sd[name + ".norm.running_var"] + eps)
+        w = w16(sd[name + ".weight"] * sc.view(-1, 1, 1, 1))
+        b = sd[name + ".norm.bias"] - sd[name + ".norm.running_mean"] * sc
+        x = F.conv2d(x, w, b, stride=stride, padding=padding)
+        if residual is not None:
+            x = x + residual
+        return a16(F.relu(x) if relu else x)
     x = F.conv2d(x, sd[name + ".weight"], None, stride=stride, padding=padding)
     x = _frozen_bn(x, sd, name + ".norm")
+    if residual is not None:
+        x = x + residual
     return F.relu(x) if relu else x
 
 
@@ -37,14 +53,13 @@ def bottleneck(x, sd, pfx, stride, has_shortcut):
     """detectron2 BottleneckBlock, stride on the 3x3 conv (STRIDE_IN_1X1: False)."""
     out = _conv_bn(x, sd, pfx + ".conv1", 1, 0, relu=True)
     out = _conv_bn(out, sd, pfx + ".conv2", stride, 1, relu=True)
-    out = _conv_bn(out, sd, pfx + ".conv3", 1, 0, relu=False)
     sc = _conv_bn(x, sd, pfx + ".shortcut", stride, 0) if has_shortcut else x
-    return F.relu(out + sc)
+    return _conv_bn(out, sd, pfx + ".conv3", 1, 0, relu=True, residual=sc)      # relu(conv3 + shortcut)
 
 
 def resnet_bottom_up(x, sd, pfx="backbone.bottom_up.", blocks=R101_BLOCKS):
     """Returns dict res2..res5 (NCHW fp32)."""
-    x = _conv_bn(x, sd, pfx + "stem.conv1", 2, 3, relu=True)
+    x = _conv_bn(a16(x), sd, pfx + "stem.conv1", 2, 3, relu=True)
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     outs = {}
     for si, nb in enumerate(blocks):
@@ -62,11 +77,11 @@ def fpn(feats, sd, pfx="backbone.", in_features=("res3", "res4", "res5")):
     results = {}
     prev = None
     for s in reversed(stages):
-        lat = F.conv2d(feats[f"res{s}"], sd[f"{pfx}fpn_lateral{s}.weight"], sd[f"{pfx}fpn_lateral{s}.bias"])
+        lat = F.conv2d(feats[f"res{s}"], w16(sd[f"{pfx}fpn_lateral{s}.weight"]), sd[f"{pfx}fpn_lateral{s}.bias"])
         if prev is not None:
             lat = lat + F.interpolate(prev, scale_factor=2.0, mode="nearest")
-        prev = lat
-        results[f"p{s}"] = F.conv2d(prev, sd[f"{pfx}fpn_output{s}.weight"], sd[f"{pfx}fpn_output{s}.bias"], padding=1)
+        prev = a16(lat)
+        results[f"p{s}"] = a16(F.conv2d(prev, w16(sd[f"{pfx}fpn_output{s}.weight"]), sd[f"{pfx}fpn_output{s}.bias"], padding=1))
     top = stages[-1]
     results[f"p{top + 1}"] = F.max_pool2d(results[f"p{top}"], kernel_size=1, stride=2, padding=0)  # LastLevelMaxPool
     return results

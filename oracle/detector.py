@@ -40,6 +40,27 @@ class DetCfg:
     head: HeadCfg = field(default_factory=HeadCfg)
 
 
+def renew_and_ddim_step(buf, logits, pred_noise, x_start, time, time_next, noise, fresh, keep_thr=0.5):
+    """diffusion_det.py:559-596 for time_next >= 0: box renewal (keep boxes whose best sigmoid score exceeds 0.5, in
+    index order) + DDIM update with eta = 1 + replenishment with fresh N(0,1) boxes.
+    logits [B, M, C]; pred_noise, x_start [B, M, 4]; noise[i], fresh[i]: full [M, 4] draws of image i, of which the leading
+    `num_remain` / `M - num_remain` rows are consumed (:587, :595).  -> img [B, M, 4]."""
+    batch, M = logits.shape[:2]
+    score = torch.sigmoid(logits)                               # :560
+    value, _ = torch.max(score, dim=-1)                         # :562
+    keep_idx = value > keep_thr                                 # :563
+    num_remain = torch.sum(keep_idx, dim=-1)                    # :565
+    pred_noise_l = [pred_noise[i, keep_idx[i]] for i in range(batch)]       # :567-572
+    x_start_l = [x_start[i, keep_idx[i]] for i in range(batch)]
+    sqrt_an, cc, sigma = schedule.ddim_coefficients(buf["alphas_cumprod"], time, time_next)     # :577-584
+    img_l = []
+    for i in range(batch):                                      # :586-595
+        nr = int(num_remain[i])
+        x = x_start_l[i] * sqrt_an + cc * pred_noise_l[i] + sigma * noise[i][:nr]
+        img_l.append(torch.cat((x, fresh[i][:M - nr]), dim=0))
+    return torch.stack(img_l, dim=0)
+
+
 class OracleDiffusionDet:
     def __init__(self, sd, cfg: DetCfg, noise_fn, backbone_fn=None):
         self.sd = sd
@@ -142,28 +163,15 @@ class OracleDiffusionDet:
         ensemble = []
         for step, (time, time_next) in enumerate(pairs):
             t = torch.full((batch,), time, dtype=torch.long)
+            self.taps[f"img_{step}"] = img
             (pred_noise, x_start), outputs_class, outputs_coord = self.model_predictions(
                 feats_cur, images_whwh, img, t, cached=cached, mem=self.mem)
             self.taps[f"final_{step}"] = (outputs_class[-1], outputs_coord[-1])
-            # box renewal :559-572
-            score = torch.sigmoid(outputs_class[-1])
-            value, _ = torch.max(score, dim=-1)
-            keep_idx = value > 0.5
-            num_remain = torch.sum(keep_idx, dim=-1)
-            pred_noise_l = [pred_noise[i, keep_idx[i]] for i in range(batch)]
-            x_start_l = [x_start[i, keep_idx[i]] for i in range(batch)]
-            img_l = [img[i, keep_idx[i]] for i in range(batch)]
-            if time_next < 0:                                   # :573-575
-                img = x_start_l
+            if time_next < 0:                                   # :573-575 (the renewed lists are never read again)
                 continue
-            sqrt_an, cc, sigma = schedule.ddim_coefficients(self.buf["alphas_cumprod"], time, time_next)
-            for i in range(batch):                              # :586-595
-                nr = int(num_remain[i])
-                noise = self.noise_fn("ddim", frame_id, step, i, (c.num_proposals, 4))[:nr]
-                img_l[i] = x_start_l[i] * sqrt_an + cc * pred_noise_l[i] + sigma * noise
-                fresh = self.noise_fn("renew", frame_id, step, i, (c.num_proposals, 4))[:c.num_proposals - nr]
-                img_l[i] = torch.cat((img_l[i], fresh), dim=0)
-            img = torch.stack(img_l, dim=0)
+            noise = [self.noise_fn("ddim", frame_id, step, i, (c.num_proposals, 4)) for i in range(batch)]
+            fresh = [self.noise_fn("renew", frame_id, step, i, (c.num_proposals, 4)) for i in range(batch)]
+            img = renew_and_ddim_step(self.buf, outputs_class[-1], pred_noise, x_start, time, time_next, noise, fresh)
             if c.sample_step > 1:                               # :598-604
                 cands = [postproc.topk_candidates(outputs_class[-1][b], outputs_coord[-1][b], c.num_classes)[:3]
                          for b in range(batch)]

@@ -15,6 +15,8 @@ from dataclasses import dataclass
 import torch
 import torch.nn.functional as F
 
+from . import precision
+from .precision import a16, w16
 from .roi_align import roi_pooler
 from .schedule import time_mlp
 
@@ -45,8 +47,36 @@ def _ln(x, sd, name, eps=1e-5):
     return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], eps)
 
 
+def _lin(x, sd, name, bias=True):
+    """F.linear with the policy's weight rounding (fp32 policy: the plain call)"""
+    return F.linear(x, w16(sd[name + ".weight"]), sd[name + ".bias"] if bias else None)
+
+
+def _mha_fp16_policy(sd, pfx, query, key, value, nheads):
+    """nn.MultiheadAttention under the fp16 storage policy (see precision.py): fp16 inputs / q / k / v / probabilities /
+    per-head outputs, fp32 scores, softmax sums and accumulation.  The probabilities that enter P.V are exp(s - rowmax)
+    rounded to fp16, normalised afterwards by the fp32 sum of the un-rounded ones (csrc/attention.hip)."""
+    Lq, B, d = query.shape
+    Lk = key.shape[0]
+    hd = d // nheads
+    W, bvec = w16(sd[pfx + ".in_proj_weight"]), sd[pfx + ".in_proj_bias"]
+    q = a16(F.linear(a16(query), W[:d], bvec[:d]))
+    k = a16(F.linear(a16(key), W[d:2 * d], bvec[d:2 * d]))
+    v = a16(F.linear(a16(value), W[2 * d:], bvec[2 * d:]))
+    q = q.view(Lq, B * nheads, hd).transpose(0, 1)
+    k = k.view(Lk, B * nheads, hd).transpose(0, 1)
+    v = v.view(Lk, B * nheads, hd).transpose(0, 1)
+    s_ = torch.bmm(q, k.transpose(1, 2)) * (1.0 / math.sqrt(hd))
+    p_ = torch.exp(s_ - s_.amax(-1, keepdim=True))
+    o = torch.bmm(a16(p_), v) / p_.sum(-1, keepdim=True)
+    o = a16(o).transpose(0, 1).reshape(Lq, B, d)
+    return F.linear(o, w16(sd[pfx + ".out_proj.weight"]), sd[pfx + ".out_proj.bias"])
+
+
 def _mha(sd, pfx, query, key, value, nheads):
     """nn.MultiheadAttention(d, nheads)(query, key, value)[0]; inputs [L, B, d]."""
+    if precision.is_fp16():
+        return _mha_fp16_policy(sd, pfx, query, key, value, nheads)
     out, _ = F.multi_head_attention_forward(
         query, key, value, query.shape[-1], nheads,
         sd[pfx + ".in_proj_weight"], sd[pfx + ".in_proj_bias"],
@@ -61,15 +91,15 @@ def dynamic_conv(sd, pfx, pro_features, roi_features, cfg):
     d, dd = cfg.hidden_dim, cfg.dim_dynamic
     num_params = d * dd
     features = roi_features.permute(1, 0, 2)
-    parameters = F.linear(pro_features, sd[pfx + ".dynamic_layer.weight"], sd[pfx + ".dynamic_layer.bias"]).permute(1, 0, 2)
+    parameters = a16(_lin(a16(pro_features), sd, pfx + ".dynamic_layer")).permute(1, 0, 2)
     param1 = parameters[:, :, :num_params].reshape(-1, d, dd)
     param2 = parameters[:, :, num_params:].reshape(-1, dd, d)
     features = torch.bmm(features, param1)
-    features = F.relu(_ln(features, sd, pfx + ".norm1"))
+    features = a16(F.relu(_ln(features, sd, pfx + ".norm1")))
     features = torch.bmm(features, param2)
-    features = F.relu(_ln(features, sd, pfx + ".norm2"))
+    features = a16(F.relu(_ln(features, sd, pfx + ".norm2")))
     features = features.flatten(1)
-    features = F.linear(features, sd[pfx + ".out_layer.weight"], sd[pfx + ".out_layer.bias"])
+    features = _lin(features, sd, pfx + ".out_layer")
     features = F.relu(_ln(features, sd, pfx + ".norm3"))
     return features
 
@@ -112,7 +142,8 @@ def rcnn_head(sd, pfx, features, bboxes, pro_features, time_emb, cfg, cond=None,
     N, nr = bboxes.shape[:2]
     roi = roi_pooler(features, bboxes, cfg.pooler_resolution, cfg.scales, cfg.sampling_ratio)
     if pro_features is None:
-        pro_features = roi.view(N, nr, d, -1).mean(-1)
+        pro_features = roi.view(N, nr, d, -1).mean(-1)          # fp16 policy: mean of the un-rounded bins (csrc/roialign.hip)
+    roi = a16(roi)
     roi_features = roi.view(N * nr, d, -1).permute(2, 0, 1)
     if taps is not None:
         taps["roi"] = roi
@@ -131,8 +162,7 @@ def rcnn_head(sd, pfx, features, bboxes, pro_features, time_emb, cfg, cond=None,
         taps["dynconv"] = pro_features2.clone()
     obj_features = _ln(pro_features + pro_features2, sd, pfx + ".norm2")
     # obj_feature.
-    obj_features2 = F.linear(F.relu(F.linear(obj_features, sd[pfx + ".linear1.weight"], sd[pfx + ".linear1.bias"])),
-                             sd[pfx + ".linear2.weight"], sd[pfx + ".linear2.bias"])
+    obj_features2 = _lin(a16(F.relu(_lin(a16(obj_features), sd, pfx + ".linear1"))), sd, pfx + ".linear2")
     obj_features = _ln(obj_features + obj_features2, sd, pfx + ".norm3")
 
     fc_feature = obj_features.transpose(0, 1).reshape(N * nr, -1)
@@ -141,21 +171,21 @@ def rcnn_head(sd, pfx, features, bboxes, pro_features, time_emb, cfg, cond=None,
         scale_shift = torch.repeat_interleave(scale_shift, nr, dim=0)
         scale, shift = scale_shift.chunk(2, dim=1)
     else:
-        shift = F.linear(F.silu(cond), sd[pfx + ".c_mlp.1.weight"], sd[pfx + ".c_mlp.1.bias"])
+        shift = _lin(a16(F.silu(cond)), sd, pfx + ".c_mlp.1")
         scale = F.linear(F.silu(time_emb), sd[pfx + ".block_time_mlp.1.weight"], sd[pfx + ".block_time_mlp.1.bias"])
         scale = torch.repeat_interleave(scale, nr, dim=0)
-    fc_feature = fc_feature * (scale + 1) + shift
+    fc_feature = a16(fc_feature * (scale + 1) + shift)
     if taps is not None:
         taps["fc_feature"] = fc_feature.clone()
 
     cls_feature = fc_feature
     reg_feature = fc_feature
     for i in range(cfg.num_cls):
-        cls_feature = F.relu(_ln(F.linear(cls_feature, sd[f"{pfx}.cls_module.{3 * i}.weight"]), sd, f"{pfx}.cls_module.{3 * i + 1}"))
+        cls_feature = a16(F.relu(_ln(_lin(cls_feature, sd, f"{pfx}.cls_module.{3 * i}", bias=False), sd, f"{pfx}.cls_module.{3 * i + 1}")))
     for i in range(cfg.num_reg):
-        reg_feature = F.relu(_ln(F.linear(reg_feature, sd[f"{pfx}.reg_module.{3 * i}.weight"]), sd, f"{pfx}.reg_module.{3 * i + 1}"))
-    class_logits = F.linear(cls_feature, sd[pfx + ".class_logits.weight"], sd[pfx + ".class_logits.bias"])
-    bboxes_deltas = F.linear(reg_feature, sd[pfx + ".bboxes_delta.weight"], sd[pfx + ".bboxes_delta.bias"])
+        reg_feature = a16(F.relu(_ln(_lin(reg_feature, sd, f"{pfx}.reg_module.{3 * i}", bias=False), sd, f"{pfx}.reg_module.{3 * i + 1}")))
+    class_logits = _lin(cls_feature, sd, pfx + ".class_logits")
+    bboxes_deltas = _lin(reg_feature, sd, pfx + ".bboxes_delta")
     if taps is not None:
         taps["deltas"] = bboxes_deltas.clone()
     pred_bboxes = apply_deltas(bboxes_deltas, bboxes.reshape(-1, 4), cfg)

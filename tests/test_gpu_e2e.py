@@ -59,17 +59,17 @@ def _iou(a, b):
     return inter / ua if ua > 0 else 1.0
 
 
-def _stage_check(tag, gpf, opf, gcl, ocl, gbx, obx, frac_ok=0.99):
+def _stage_check(tag, gpf, opf, gcl, ocl, gbx, obx, frac_ok=0.99, b_logit=0.08, b_feat=0.08, b_px=0.75, b_rel=0.02):
     """per-box errors against the stated bounds; >= frac_ok of the boxes must be inside all of them"""
     e_cl = (gcl - ocl).abs().amax(-1).reshape(-1)
     size = (obx[..., 2:] - obx[..., :2]).clamp(min=1).max(-1).values
-    e_bx = ((gbx - obx).abs().max(-1).values / torch.maximum(size * 0.02, torch.tensor(0.75))).reshape(-1)
-    ok = (e_cl <= 0.08) & (e_bx <= 1.0)
+    e_bx = ((gbx - obx).abs().max(-1).values / torch.maximum(size * b_rel, torch.tensor(b_px))).reshape(-1)
+    ok = (e_cl <= b_logit) & (e_bx <= 1.0)
     msg = f"{tag}: |dlogit| median={e_cl.median():.2e} p99={e_cl.quantile(0.99):.2e} max={e_cl.max():.2e}; "
     msg += f"box err/bound median={e_bx.median():.2e} p99={e_bx.quantile(0.99):.2e} max={e_bx.max():.2e}"
     if gpf is not None:
         e_pf = (gpf - opf).abs().amax(-1).reshape(-1)
-        ok &= e_pf <= 0.08
+        ok &= e_pf <= b_feat
         msg += f"; |dfeat| median={e_pf.median():.2e} p99={e_pf.quantile(0.99):.2e} max={e_pf.max():.2e}"
     frac = ok.float().mean().item()
     print(msg + f"; boxes within bounds {frac:.4f}")
@@ -78,6 +78,7 @@ def _stage_check(tag, gpf, opf, gcl, ocl, gbx, obx, frac_ok=0.99):
     with open("gpurun_out/parity_report.txt", "a") as f:
         f.write(msg + f"; boxes within bounds {frac:.4f}\n")
     assert frac >= frac_ok, msg
+    return frac
 
 
 def _match_rate(ref, got):
@@ -107,6 +108,32 @@ def _ap50_vs_oracle(ref_out, got_out, size):
         gts.append(gt)
         preds.append(g.to(torch.device("cpu")))
     return vid_eval.eval_detection_vid(preds, gts)["map"]
+
+
+def _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, **bounds):
+    """Final stage (global attention + conditioned head) of every DDIM step with the ORACLE's memory, and for steps > 0
+    the oracle's renewed boxes, injected: logits / boxes per step within the stated bounds."""
+    from diffusionvid_amd.utils import synthetic
+    M, d = model.num_proposals, model.hidden_dim
+    model.head.proposal_feats_global = [oracle.mem[0].cuda(), oracle.mem[1].cuda()]
+    entries = [model.queue[i] for i in range(L)]
+    feats_cur, cached = model._gather_entries(entries)
+    for step, (time, _) in enumerate(model._time_pairs()):
+        with torch.no_grad():
+            t = torch.full((L,), time, dtype=torch.long)
+            if sample_step == 1:
+                model.head.proposals_feat_cur = [[cached[0], cached[1], cached[2].reshape(1, L * M, d)]]
+                img = torch.zeros(L, M, 4, device="cuda")
+            elif step == 0:
+                img = synthetic.noise_fn("img", 0, 0, 0, (L, M, 4)).cuda()
+            else:
+                # one flipped keep decision shifts every later slot of its frame, so each step starts from the oracle's
+                # renewed boxes (the renewal itself is compared in test_gpu_kernels.py::test_ddim_renew_step)
+                img = oracle.taps[f"img_{step}"].cuda()
+            oc_, ob_ = model.model_predictions(feats_cur, (float(W0), float(H0)), img, t)
+        ref_cl, ref_bx = oracle.taps[f"final_{step}"]
+        _stage_check(f"{tag} final stage, DDIM step {step} (t = {time}; oracle memory"
+                     + (", oracle boxes)" if step else ")"), None, None, oc_[-1].cpu(), ref_cl, ob_[-1].cpu(), ref_bx, **bounds)
 
 
 @pytest.mark.parametrize("sample_step", [1, 4])
@@ -158,26 +185,9 @@ def test_video_e2e(sample_step):
     print(f"[x{sample_step}] memory: oracle rows with a GPU row within 0.5: {(dmin < 0.5).float().mean():.3f}")
     assert (dmin < 0.5).float().mean() > 0.8
 
-    # 3. final stage with the oracle's memory injected
-    model.head.proposal_feats_global = [oracle.mem[0].cuda(), oracle.mem[1].cuda()]
+    # 3. final stage with the oracle's memory injected (every DDIM step of x4)
     model.debug_taps = {}
-    # re-run the final stage only: rebuild the batch from the queue exactly as _forward_test does
-    entries = [model.queue[i] for i in range(L)]
-    feats_cur, cached = model._gather_entries(entries)
-    with torch.no_grad():
-        if sample_step == 1:
-            model.head.proposals_feat_cur = [[cached[0], cached[1], cached[2].reshape(1, L * 300, 256)]]
-            t = torch.full((L,), 999, dtype=torch.long)
-            oc_, ob_ = model.model_predictions(feats_cur, (float(W0), float(H0)), torch.zeros(L, 300, 4, device="cuda"), t)
-            fin_cl, fin_bx = oc_[-1].cpu(), ob_[-1].cpu()
-            ref_cl, ref_bx = oracle.taps["final_0"]
-        else:
-            img = synthetic.noise_fn("img", 0, 0, 0, (L, 300, 4)).cuda()
-            t = torch.full((L,), 999, dtype=torch.long)
-            oc_, ob_ = model.model_predictions(feats_cur, (float(W0), float(H0)), img, t)
-            fin_cl, fin_bx = oc_[-1].cpu(), ob_[-1].cpu()
-            ref_cl, ref_bx = oracle.taps["final_0"]
-    _stage_check(f"[x{sample_step}] final stage (oracle memory)", None, None, fin_cl, ref_cl, fin_bx, ref_bx)
+    _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, f"[x{sample_step}]")
 
     # detections of the un-modified end-to-end run
     rates = [_match_rate(r, g) for r, g in zip(ref_out, got_out)]
@@ -328,18 +338,38 @@ def test_lookahead_invariance_full_size(arch, sample_step, groups):
         print(f"{arch} x{sample_step}: look-ahead {la} vs 1 at full size: max |dbox| = {worst:.2e} px over 120 frames")
 
 
-def test_video_e2e_full_configuration():
-    """BASELINE.json configs[1] as it is benchmarked -- ResNet-101 (3,4,23,3), 1000x600 frames, 300 boxes, x1 -- on the
-    first call of an 8-frame video (8 local + 24 global frames through backbone and extraction heads, memory pruning,
-    final stage): extraction logits / boxes / object features, detections and AP50 against the CPU oracle, same
-    tolerances as the reduced-size test."""
+@pytest.mark.parametrize("arch,sample_step", [("r101", 1), ("r101", 4), ("swinb", 1)])
+def test_video_e2e_full_configuration(arch, sample_step):
+    """BASELINE.json configs[1..3] as they are benchmarked -- ResNet-101 (3,4,23,3) x1 and x4, Swin-Base (embed 128,
+    depths 2-2-18-2, heads 4-8-16-32) x1; 1000x600 frames, 300 boxes -- on the first call of a one-batch video (8 / 4
+    local + 24 global frames through backbone and extraction heads, memory pruning, final stage with every DDIM step):
+    extraction logits / boxes / object features, per-step final-stage logits / boxes, detections and AP50 against the
+    CPU oracle, same tolerances as the reduced-size tests."""
+    from diffusionvid_amd.config import get_cfg
     from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.modeling.detector import build_detection_model
     from diffusionvid_amd.utils import synthetic
-    cfg, model = _build(1, None)
-    L, H0, W0 = 8, 600, 1000
+    if arch == "r101":
+        cfg, model = _build(sample_step, None)
+        L = 8
+    else:
+        cfg = get_cfg("configs/vid_Swin_B_DiffusionVID.yaml", ["MODEL.DiffusionDet.SAMPLE_STEP", sample_step], "configs/BASE_RCNN_1gpu.yaml")
+        cfg.freeze()
+        model = build_detection_model(cfg)
+        model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+        model = model.to("cuda").eval()
+        L = 4
+    H0, W0 = 600, 1000
+    tag = f"[{arch} x{sample_step} full size]"
     ds = SyntheticVIDDataset([L], cfg, height=H0, width=W0, device="cuda", smooth=True)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    oracle = odet.OracleDiffusionDet(sd, odet.DetCfg(), synthetic.noise_fn)
+    ocfg = odet.DetCfg(sample_step=sample_step, infer_batch=L, all_frame_interval=L)
+    ocfg.head.sampling_timesteps = sample_step
+    backbone_fn = None
+    if arch == "swinb":
+        from oracle import swin as oswin
+        backbone_fn = lambda x: oswin.backbone_swin_fpn(x, sd, "backbone.", **{k: v for k, v in oswin.SWIN_B.items() if k != "window"})  # noqa: E731
+    oracle = odet.OracleDiffusionDet(sd, ocfg, synthetic.noise_fn, backbone_fn=backbone_fn)
     model.noise_fn = synthetic.noise_fn
     model.debug_taps = {}
     images, oitem, ids = _oracle_items(ds, 0)
@@ -352,13 +382,15 @@ def test_video_e2e_full_configuration():
     gcl = torch.cat([e[0] for e in model.debug_taps["extract"]]).cpu()
     gbx = torch.cat([e[1] for e in model.debug_taps["extract"]]).cpu()
     gpf = torch.cat([e[2] for e in model.debug_taps["extract"]]).cpu().view(-1, 300, 256)
-    _stage_check("[R101 x1 full size] extraction", gpf, opf, gcl, ocl, gbx, obx)
+    assert gcl.shape[0] == L + 24
+    _stage_check(f"{tag} extraction", gpf, opf, gcl, ocl, gbx, obx)
     rates = [_match_rate(r, g) for r, g in zip(ref_out, got_out)]
     ap = _ap50_vs_oracle(ref_out, got_out, (W0, H0))
-    print(f"[R101 x1 full size] detections kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]}; "
+    print(f"{tag} detections kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]}; "
           f"match {['%.2f' % r for r in rates]}; AP50(GPU | oracle) = {ap:.4f}")
     with open("gpurun_out/parity_report.txt", "a") as f:
-        f.write(f"[R101 x1 full size] AP50(GPU | oracle detections as ground truth) = {ap:.4f}; match rates {['%.2f' % r for r in rates]}\n")
+        f.write(f"{tag} AP50(GPU | oracle detections as ground truth) = {ap:.4f}; match rates {['%.2f' % r for r in rates]}\n")
+    _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag)
     assert min(rates) >= 0.9 and ap >= 0.95
 
 
@@ -387,3 +419,80 @@ def test_other_num_proposals(num_proposals):
     rates = [_match_rate(r, g) for r, g in zip(ref_out, got_out)]
     print(f"[{num_proposals} boxes] kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]}; match {['%.2f' % r for r in rates]}")
     assert min(rates) >= 0.9
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_video_e2e_fp16_policy_oracle_bench_regime(full):
+    """The regime bench.py runs in -- UNTAMED random-init heads, white-noise frames -- against the oracle
+    under the fp16 storage policy of the MI355X path (oracle/precision.py: fp16-rounded weights and stored activations,
+    fp32 accumulation; what apex O1 gives the reference).  Against the fp32 oracle this regime is chaotic (rounding the
+    oracle's OWN feature maps to fp16 moves stage-3 features by O(1), utils/synthetic.py), so that comparison says
+    nothing about the kernels; against the fp16-policy oracle what is left is summation order and the rare last-bit flip
+    at an fp16 store.  Bounds (extraction pass = backbone + 3 chained heads, 32 frames x 300 boxes):
+    |dlogit| <= 0.02, |dfeature| <= 0.02, box <= max(0.25 px, 0.5 %) for >= 99 % of the boxes -- 4x tighter than the fp32
+    comparison on tamed weights.  AP50 of the GPU detections is reported against both oracles' detections, and the
+    fp16-policy oracle's against the fp32 oracle's (= the cost of the precision policy itself in this regime)."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    from diffusionvid_amd.utils import synthetic
+    from oracle import precision
+    blocks = None if full else (1, 1, 2, 1)
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", None, "configs/BASE_RCNN_1gpu.yaml")
+    if blocks:
+        cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = blocks
+    cfg.freeze()
+    model = build_detection_model(cfg).to("cuda").eval()          # untamed: the state dict bench.py runs
+    L, H0, W0 = (8, 600, 1000) if full else (8, 250, 380)
+    ds = SyntheticVIDDataset([L], cfg, height=H0, width=W0, device="cuda", smooth=False)       # white noise, as in bench.py
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    kw = {} if blocks is None else {"blocks": blocks}
+    model.noise_fn = synthetic.noise_fn
+    model.debug_taps = {}
+    images, oitem, ids = _oracle_items(ds, 0)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    tag = "[bench regime%s]" % (" full size" if full else "")
+    with torch.no_grad():
+        got_out = model(images)
+        o16 = odet.OracleDiffusionDet(sd, odet.DetCfg(**kw), synthetic.noise_fn)
+        with precision.use("fp16"):
+            ref16 = o16.forward(oitem)
+        o32 = ref32 = None
+        if not full:            # the fp32 comparison is a report, not a gate: once, at the reduced size (CPU time)
+            o32 = odet.OracleDiffusionDet(sd, odet.DetCfg(**kw), synthetic.noise_fn)
+            ref32 = o32.forward(oitem)
+    gcl = torch.cat([e[0] for e in model.debug_taps["extract"]]).cpu()
+    gbx = torch.cat([e[1] for e in model.debug_taps["extract"]]).cpu()
+    gpf = torch.cat([e[2] for e in model.debug_taps["extract"]]).cpu().view(-1, 300, 256)
+    ocl, obx, opf = o16.taps["extract"]
+    _stage_check(f"{tag} extraction vs fp16-policy oracle", gpf, opf, gcl, ocl, gbx, obx, b_logit=0.02, b_feat=0.02, b_px=0.25, b_rel=0.005)
+    # the same comparison against the fp32 oracle, reported only: it measures the precision policy, not the kernels
+    line = tag
+    if o32 is not None:
+        f32 = o32.taps["extract"]
+        e = (gcl - f32[0]).abs().amax(-1).reshape(-1)
+        e16 = (ocl - f32[0]).abs().amax(-1).reshape(-1)
+        line += (f" vs fp32 oracle (reported): |dlogit| GPU median {e.median():.2e} p99 {e.quantile(0.99):.2e}; "
+                 f"fp16-policy oracle vs fp32 oracle median {e16.median():.2e} p99 {e16.quantile(0.99):.2e};")
+    size = (W0, H0)
+
+    def as_boxlists(ref):
+        out = []
+        for r in ref:
+            bl = BoxList(torch.as_tensor(r["boxes"], dtype=torch.float32).reshape(-1, 4), size)
+            bl.add_field("scores", torch.as_tensor(r["scores"], dtype=torch.float32).reshape(-1))
+            bl.add_field("labels", torch.as_tensor(r["labels"], dtype=torch.int64).reshape(-1))
+            out.append(bl)
+        return out
+    ap_16 = _ap50_vs_oracle(ref16, got_out, size)
+    rates = [_match_rate(r, g) for r, g in zip(ref16, got_out)]
+    line += f" AP50(GPU | fp16-policy oracle) = {ap_16:.4f}; detections matched vs fp16-policy oracle {['%.2f' % r for r in rates]}"
+    if ref32 is not None:
+        line += (f"; AP50(GPU | fp32 oracle) = {_ap50_vs_oracle(ref32, got_out, size):.4f}, "
+                 f"AP50(fp16-policy oracle | fp32 oracle) = {_ap50_vs_oracle(ref32, as_boxlists(ref16), size):.4f}")
+    print(line)
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write(line + "\n")
+    # final stage on the oracle's memory: per-box bounds as above
+    _final_stage_vs_oracle(model, o16, L, W0, H0, 1, tag + " vs fp16-policy oracle", b_logit=0.02, b_px=0.25, b_rel=0.005)

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from oracle import backbone_r101, head as ohead, memory as omem, postproc as opost, roi_align as oroi, schedule as osch  # noqa: E402
+from oracle import backbone_r101, detector as odet, head as ohead, memory as omem, postproc as opost, roi_align as oroi, schedule as osch  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -264,6 +264,52 @@ def test_noise_to_boxes_and_topk_select(dv):
     k1, k2 = ohead.select_topk_features(logits, feats, ohead.HeadCfg())
     o1, o2 = dv.select_topk_features(logits.cuda(), feats[0].cuda(), 75, 25)
     assert torch.equal(o1.cpu(), k1) and torch.equal(o2.cpu(), k2)      # pure selection: bit-exact
+
+
+@pytest.mark.parametrize("time,time_next", [(999, 749), (749, 499), (499, 249)])
+def test_ddim_renew_step(dv, time, time_next):
+    """A11 (diffusion_det.py:559-596) directly: keep mask, index-order compaction, DDIM update (eta 1), refill.
+    Logits sit around the sigmoid 0.5 threshold (|logit| >= 1e-3 so that no keep decision rides on the last ulp of
+    expf), include frames with no box kept and with every box kept.  Kept rows must land in the oracle's slots
+    (checked through the refill rows, which are copied bit for bit) and agree to 1e-6 relative / 2e-6 absolute:
+    the kernel evaluates (sra * x - v) / srm1 in fp32 like the reference, with its own operation order."""
+    g = torch.Generator().manual_seed(40 + time)
+    n, M, C = 6, 300, 30
+    W, H, scale = 1000.0, 600.0, 2.0
+    logits = torch.randn(n, M, C, generator=g) * 0.6 - 1.2          # best-of-30 logit straddles 0
+    logits[1] = -4.0                                                 # nothing kept
+    logits[2] = 3.0                                                  # everything kept
+    tiny = logits.abs() < 1e-3
+    logits[tiny] = 1e-3
+    boxes = _cluster_boxes(g, n, M)
+    boxes[:, ::7, 2:] = boxes[:, ::7, :2] + 1500.0                   # x_start beyond the clamp
+    x_t = torch.randn(n, M, 4, generator=g) * 1.5
+    noise = torch.randn(n, M, 4, generator=g)
+    fresh = torch.randn(n, M, 4, generator=g)
+    buf = osch.schedule_buffers(1000)
+    whwh = torch.tensor([[W, H, W, H]]).repeat(n, 1)
+    t = torch.full((n,), time, dtype=torch.long)
+    x_start = osch.boxes_to_x_start(boxes, whwh, scale)
+    pred_noise = osch.predict_noise_from_start(buf, x_t, t, x_start)
+    ref = odet.renew_and_ddim_step(buf, logits, pred_noise, x_start, time, time_next, list(noise), list(fresh))
+    sqrt_an, cc, sigma = osch.ddim_coefficients(buf["alphas_cumprod"], time, time_next)
+    got = dv.ddim_renew_step(logits.cuda(), boxes.cuda(), x_t.cuda(), noise.cuda(), fresh.cuda(), (W, H), scale,
+                             float(buf["sqrt_recip_alphas_cumprod"][time]), float(buf["sqrt_recipm1_alphas_cumprod"][time]),
+                             float(sqrt_an), float(cc), float(sigma), 0.5).cpu()
+    keep = torch.sigmoid(logits).amax(-1) > 0.5
+    nr = keep.sum(-1)
+    assert int(nr[1]) == 0 and int(nr[2]) == M and 20 < int(nr[0]) < M - 20
+    for f in range(n):
+        k = int(nr[f])
+        assert torch.equal(got[f, k:], fresh[f, :M - k]), f"frame {f}: refill rows differ (kept {k})"     # bit-exact copies
+        np.testing.assert_allclose(got[f, :k].numpy(), ref[f, :k].numpy(), rtol=1e-6, atol=2e-6)
+    # the slot of a kept box is its rank among the kept boxes: recompute one frame's rows from scratch, per box
+    f = 0
+    idx = torch.nonzero(keep[f]).flatten()
+    for slot in (0, len(idx) // 2, len(idx) - 1):
+        i = int(idx[slot])
+        want = x_start[f, i] * sqrt_an + cc * pred_noise[f, i] + sigma * noise[f, slot]
+        np.testing.assert_allclose(got[f, slot].numpy(), want.numpy(), rtol=1e-6, atol=2e-6)
 
 
 def _separated_logits(g, n, M, C):
