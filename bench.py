@@ -104,6 +104,50 @@ def cpu_baseline(cfg, sd, frames, height, width):
                       "16..%d probe)" % (nb, dt, torch.get_num_threads(), os.cpu_count())}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N ...` -> N ranks of this same command line under torch.distributed.run (127.0.0.1
+    rendezvous on a free port); returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL between processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """--dry: no GPU work.  Proves the launch + collective path: N processes, gloo group, each rank fabricates the
+    predictions of its own synthetic video, one gather to rank 0, one JSON line."""
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        comm.init_dist("gloo")
+        assert dist.get_world_size() == args.gpus
+    L = args.frames
+    res = {}
+    for f in range(L):
+        k = (f * 7 + rank) % 5
+        bl = BoxList(torch.full((k, 4), float(rank)), (1000, 600))
+        bl.add_field("scores", torch.linspace(0.9, 0.5, k))
+        bl.add_field("labels", torch.full((k,), rank % 30 + 1))
+        res[rank * L + f] = bl
+    merged = engine.gather_predictions(res) if world > 1 else res
+    if rank == 0:
+        ranks_seen = sorted({int(k) // L for k in merged})
+        print(json.dumps({"metric": "dry run (launcher + gather only)", "n_gpus": world, "ranks_seen": ranks_seen,
+                          "frames_gathered": len(merged), "backend": "gloo" if world > 1 else "none"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,18 +161,33 @@ def main():
                     help="r101 = the BASELINE.json headline configuration; swinb = configs/vid_Swin_B_DiffusionVID.yaml (INFER_BATCH 4)")
     ap.add_argument("--sample-step", type=int, default=1, help="MODEL.DiffusionDet.SAMPLE_STEP (4 = the x4 configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry", action="store_true",
+                    help="launcher / collective check without a GPU: every rank fabricates its shard's predictions, the gather to "
+                         "rank 0 runs over gloo, and the JSON line reports the ranks seen (tests/test_dist_gloo.py)")
     args = ap.parse_args()
 
+    # One process per GPU (the reference: `python -m torch.distributed.launch --nproc_per_node N tools/test_net.py`,
+    # README.md:100-106, mega_core/utils/dist_env.py:18-23).  Started bare with --gpus N > 1, this process becomes the
+    # launcher: it re-executes itself N times through torch.distributed.run and relays the exit code.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the DiffusionVID hot path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU: %d visible device(s) for --gpus %d" % (rank, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         comm.init_dist("nccl")
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
 
     headline = args.arch == "r101" and args.sample_step == 1
     yaml = "configs/vid_R_101_DiffusionVID.yaml" if args.arch == "r101" else "configs/vid_Swin_B_DiffusionVID.yaml"
@@ -165,7 +224,7 @@ def main():
             r = run_video(model, ds, device)
             frames += len(r)
             results.update({k + s * L + rank * args.steps * L: v.to("cpu") for k, v in r.items()})
-        merged = engine.gather_predictions(results, max_det=300, device=device) if world > 1 else results
+        merged = engine.gather_predictions(results, device=device) if world > 1 else results
         barrier()
         dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -239,7 +298,10 @@ def main():
                                    % ("ResNet-101" if args.arch == "r101" else "Swin-Base", args.sample_step, args.sample_step, L, L,
                                       -(-L // cfg.INPUT.INFER_BATCH), cfg.INPUT.INFER_BATCH),
                        "frames_per_step_per_gpu": L, "infer_batch": cfg.INPUT.INFER_BATCH, "lookahead_batches": args.lookahead,
-                       "parallelism": "videos sharded across ranks"},
+                       "parallelism": "videos sharded across ranks (one process per GPU, %s)"
+                                      % ("RCCL group of %d ranks: one gather of the predictions to rank 0" % dist.get_world_size()
+                                         if world > 1 else "single rank, no collective"),
+                       "ranks": world},
             "roofline": roofline,
         }
         if world == 1 and headline and not args.no_cpu_baseline:

@@ -41,6 +41,61 @@ def max_detections(results):
     return max((len(bl) for bl in results.values()), default=0)
 
 
+def video_shard_plan(num_frames, infer_batch, lookahead, world):
+    """One video over `world` ranks (single-video case).  The unit is a look-ahead group (`infer_batch *
+    lookahead` frames): given the video's global memory every group is independent -- the memory is final after the
+    first call (GLOBAL.STOP_UPDATE_AFTER_INIT_TEST), local attention is off, the local queue is exactly one batch, and the
+    random draws are keyed by (video, call frame, step), not by RNG stream position.  Group g runs on rank g % world; group 0
+    (whose first call also carries the global frames) therefore on rank 0.  Returns, per rank, the list of inclusive
+    dataset-offset ranges (first call, last call) to feed: a group's first batch needs the `infer_batch - 1` calls before
+    it, which only queue their local frame (diffusion_det.py:410-412)."""
+    unit = infer_batch * lookahead
+    plan = [[] for _ in range(world)]
+    for g, f0 in enumerate(range(0, num_frames, unit)):
+        last_batch = min(f0 + unit, -(-num_frames // infer_batch) * infer_batch) - infer_batch
+        last_batch = min(last_batch, (num_frames - 1) // infer_batch * infer_batch)
+        plan[g % world].append((max(0, f0 - (infer_batch - 1)), last_batch))
+    return plan
+
+
+def compute_on_video_sharded(model, dataset, start, num_frames, device, rank=None, world=None, broadcast=None):
+    """Run ONE video (dataset indices [start, start + num_frames)) across the ranks of the process group following
+    `video_shard_plan`: rank 0 runs the first call (24 global + the first local frames) and the memory it builds --
+    [900, d] + [150, d] fp32, 1.07 MB -- is broadcast (RCCL over xGMI; the only data-path exchange of this mode);
+    every rank then runs its own groups.  Returns this rank's {image id: BoxList}; merge with gather_predictions.
+    `broadcast(tensors, src)`: injected for tests; default torch.distributed.broadcast of each tensor."""
+    rank = comm.get_rank() if rank is None else rank
+    world = comm.get_world_size() if world is None else world
+    plan = video_shard_plan(num_frames, model.infer_batch, model.lookahead, world)[rank]
+    results = {}
+    cpu = torch.device("cpu")
+
+    def feed(a, b):
+        for off in range(a, b + 1):
+            images, _, ids = dataset[start + off]
+            with torch.no_grad():
+                out = model(images)
+            results.update({i: o.to(cpu) for i, o in zip(ids, out)})
+
+    todo = list(plan)
+    if rank == 0:
+        feed(0, 0)
+        mem = [m.contiguous() for m in model.global_memory()]
+    else:
+        mem = [torch.empty(s, dtype=torch.float32, device=device) for s in model.global_memory_shapes()]
+    if world > 1:
+        if broadcast is not None:
+            mem = broadcast(mem, 0)
+        else:
+            for m in mem:
+                dist.broadcast(m, src=0)
+    if rank != 0:
+        model.adopt_video_memory(mem)
+    for a, b in todo:
+        feed(max(a, 1) if (rank == 0 and a == 0) else a, b)
+    return results
+
+
 def pack_predictions(results, max_det=None):
     """dict{id: BoxList} -> (ids [n] int64, counts [n] int32, dets [n, max_det, 6] fp32 = box4, score, label,
     sizes [n,2] int32).  max_det None = the shard's own maximum; a smaller explicit value is an error (nothing is

@@ -246,6 +246,21 @@ class DiffusionDet(nn.Module):
         self.queue = deque(maxlen=n)      # entries: (split_outputs, frame index inside the split)
         self.video_index += 1
 
+    # ---- one video over several ranks (engine/inference.py: compute_on_video_sharded) -------------------------
+    def global_memory(self):
+        """[memory 900 x d, memory 150 x d] of the current video (diffusion_det.py:479-488)"""
+        return list(self.head.proposal_feats_global)
+
+    def global_memory_shapes(self):
+        g = self.cfg.MODEL.VID.MEGA.GLOBAL.SIZE
+        return [(min(self.mem_management_size_test, g * self.top_k[0]), self.hidden_dim), (min(150, g * self.top_k[1]), self.hidden_dim)]
+
+    def adopt_video_memory(self, memory):
+        """Start a video whose global memory was built by another rank: per-video reset, then the memory as if this
+        process had seen the global frames."""
+        self._reset_video()
+        self.head.proposal_feats_global = [m.to(self.device, torch.float32) for m in memory]
+
     def model_predictions(self, backbone_feats, images_whwh, x, t, box_extract=0):
         """diffusion_det.py:655-677.  images_whwh: (w, h) of the un-padded frame (same for all frames)."""
         w, h = images_whwh

@@ -12,16 +12,24 @@ import numpy as np
 import torch
 
 
-def nms_fp32(boxes, scores, iou_threshold):
+def nms_fp32(boxes, scores, iou_threshold, legacy=False):
     """torchvision.ops.nms CPU kernel (nms_kernel_impl), fp32 arithmetic in the same order.
-    boxes [n,4] float32, scores [n] float32 -> kept indices in descending score order."""
+    boxes [n,4] float32, scores [n] float32 -> kept indices in descending score order.
+
+    legacy=True switches the two places where the reference's own `_C.nms`
+    (mega_core/csrc/cpu/nms_cpu.cpp:24, :57-62; cuda/nms.cu:13-21) differs from torchvision's: pixel-inclusive
+    extents (`x2 - x1 + 1`) and suppression at `ovr >= threshold` instead of `>`.  DiffusionVID does not call the
+    legacy op (it uses detectron2's batched_nms, diffusion_det.py:617,:793); the switch exists so that the greedy
+    sweep shared by both variants is pinned by the known-answer vectors of the reference's tests/test_nms.py:11-58
+    (golden g12), which that source file passes."""
+    one = np.float32(1 if legacy else 0)
     boxes = np.asarray(boxes, dtype=np.float32)
     scores = np.asarray(scores, dtype=np.float32)
     n = boxes.shape[0]
     if n == 0:
         return np.zeros((0,), dtype=np.int64)
     x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
-    areas = (x2 - x1) * (y2 - y1)
+    areas = (x2 - x1 + one) * (y2 - y1 + one)
     order = np.argsort(-scores, kind="stable")
     suppressed = np.zeros(n, dtype=bool)
     keep = []
@@ -38,11 +46,11 @@ def nms_fp32(boxes, scores, iou_threshold):
             yy1 = np.maximum(y1[i], y1[rest])
             xx2 = np.minimum(x2[i], x2[rest])
             yy2 = np.minimum(y2[i], y2[rest])
-            w = np.maximum(zero, xx2 - xx1)
-            h = np.maximum(zero, yy2 - yy1)
+            w = np.maximum(zero, xx2 - xx1 + one)
+            h = np.maximum(zero, yy2 - yy1 + one)
             inter = w * h
             ovr = inter / (areas[i] + areas[rest] - inter)
-            suppressed[rest[ovr > thr]] = True
+            suppressed[rest[(ovr >= thr) if legacy else (ovr > thr)]] = True
     return np.asarray(keep, dtype=np.int64)
 
 

@@ -271,6 +271,40 @@ def g11_vid_eval():
     save("g11_vid_eval", nframes=np.array(12), ap=res[0]["ap"], map=np.array(res[0]["map"]), **flat)
 
 
+def g12_nms_known_answers():
+    """The known-answer vectors of the reference's own NMS tests (tests/test_nms.py:11-58 `test_nms_cpu`, :60-230
+    `test_nms1_cpu`, themselves caffe2's UtilsNMSTest vectors), captured as data by running those two test methods with
+    `box_nms` replaced by a recorder and `np.testing.assert_array_equal` by a collector: inputs (boxes, scores,
+    threshold) and the expected kept index sets."""
+    import importlib.util
+    import types
+    calls, expected = [], []
+    layers = types.ModuleType("mega_core.layers")
+    layers.nms = lambda boxes, scores, thresh: (calls.append((boxes.numpy().copy(), scores.numpy().copy(), float(thresh))), np.zeros(0, np.int64))[1]
+    saved = sys.modules.get("mega_core.layers")
+    sys.modules["mega_core.layers"] = layers
+    spec = importlib.util.spec_from_file_location("ref_test_nms", "/root/reference/tests/test_nms.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    real = np.testing.assert_array_equal
+    np.testing.assert_array_equal = lambda got, want, *a, **k: expected.append(np.asarray(want, dtype=np.int64))
+    try:
+        t = mod.TestNMS()
+        t.test_nms_cpu()
+        t.test_nms1_cpu()
+    finally:
+        np.testing.assert_array_equal = real
+        if saved is not None:
+            sys.modules["mega_core.layers"] = saved
+        else:
+            del sys.modules["mega_core.layers"]
+    assert len(calls) == len(expected) == 6
+    arrs = {"n_cases": np.array(len(calls))}
+    for i, ((b, sc, th), e) in enumerate(zip(calls, expected)):
+        arrs[f"boxes{i}"], arrs[f"scores{i}"], arrs[f"thresh{i}"], arrs[f"keep{i}"] = b, sc, np.array(th, np.float32), e
+    save("g12_nms_known_answers", **arrs)
+
+
 if __name__ == "__main__":
     # The reference targets torch 1.8 (INSTALL.md:3-13) where nn.MultiheadAttention.forward IS
     # F.multi_head_attention_forward; keep torch 2.x's fused inference fast path out of the goldens.
@@ -287,3 +321,4 @@ if __name__ == "__main__":
     g9_structures()
     g11_vid_eval()
     g10_sampler()
+    g12_nms_known_answers()

@@ -496,3 +496,47 @@ def test_video_e2e_fp16_policy_oracle_bench_regime(full):
         f.write(line + "\n")
     # final stage on the oracle's memory: per-box bounds as above
     _final_stage_vs_oracle(model, o16, L, W0, H0, 1, tag + " vs fp16-policy oracle", b_logit=0.02, b_px=0.25, b_rel=0.005)
+
+
+@pytest.mark.parametrize("sample_step,lookahead", [(1, 2), (4, 1)])
+def test_single_video_sharded_over_ranks_reproduces_sequential_run(sample_step, lookahead):
+    """SURVEY.md 8e, single-video case: look-ahead groups of ONE video distributed round-robin over 3 ranks, the global
+    memory built on rank 0 and handed to the others (here in-process; over RCCL it is one 1.07 MB broadcast,
+    engine/inference.compute_on_video_sharded) -- the union of the ranks' detections must equal the sequential run's
+    exactly: same launches, same shapes, draws keyed by (video, call frame, step)."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.engine import inference as eng
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.DiffusionDet.SAMPLE_STEP", sample_step,
+                                                          "INPUT.LOOKAHEAD_BATCHES", lookahead], "configs/BASE_RCNN_1gpu.yaml")
+    cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+    model = model.to("cuda").eval()
+    model.noise_fn = synthetic.noise_fn
+    L = 52
+    ds = SyntheticVIDDataset([L], cfg, height=120, width=200, device="cuda", smooth=True)
+    dev = torch.device("cuda")
+    seq = eng.compute_on_dataset(model, ds, range(L), dev)
+    assert sorted(seq) == list(range(L))
+    world, handed = 3, {}
+
+    def bcast(mem, src):
+        if not handed:
+            handed["mem"] = [m.clone() for m in mem]          # rank 0's memory
+        return [m.clone() for m in handed["mem"]]
+    merged = {}
+    for rank in range(world):
+        part = eng.compute_on_video_sharded(model, ds, 0, L, dev, rank=rank, world=world, broadcast=bcast)
+        assert not (set(part) & set(merged))
+        merged.update(part)
+    plan = eng.video_shard_plan(L, 8, lookahead, world)
+    assert all(plan[r] for r in range(world))                  # every rank really owned something
+    assert sorted(merged) == list(range(L))
+    for i in range(L):
+        a, b = seq[i], merged[i]
+        assert len(a) == len(b) and torch.equal(a.bbox, b.bbox)
+        assert torch.equal(a.get_field("scores"), b.get_field("scores")) and torch.equal(a.get_field("labels"), b.get_field("labels"))

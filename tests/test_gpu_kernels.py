@@ -358,6 +358,26 @@ def test_postproc_ensemble_exact(dv):
         np.testing.assert_array_equal(ob[b, :k].cpu().numpy(), ref[b]["boxes"])
 
 
+def test_postproc_on_reference_nms_vectors(dv):
+    """The reference's own NMS test boxes / scores (tests/test_nms.py, golden g12) through the HIP top-k + NMS kernels:
+    one class, one frame, so the kept set must equal the oracle's torchvision-convention sweep on the same data (whose
+    legacy twin is pinned to the reference's expected indices in tests/test_oracle_golden.py::test_g12_nms_known_answers)."""
+    from conftest import golden
+    z = golden("g12_nms_known_answers")
+    for i in range(int(z["n_cases"])):
+        b, sc, th = z[f"boxes{i}"], z[f"scores{i}"], float(z[f"thresh{i}"])
+        M, C = len(sc), 30
+        logits = torch.full((1, M, C), -20.0)
+        logits[0, :, 0] = torch.log(torch.from_numpy(sc) / (1 - torch.from_numpy(sc)))
+        boxes = torch.from_numpy(b)[None]
+        ref = opost.inference_x1(logits, boxes, (1000, 600), C, iou=th)
+        ob, osc, ol, oc = dv.postproc_topk_nms(logits.cuda(), boxes.cuda(), 1000.0, 600.0, iou=th)
+        k = int(oc[0])
+        assert k == len(ref[0]["scores"]), f"case {i}: kept {k} vs {len(ref[0]['scores'])}"
+        np.testing.assert_array_equal(ob[0, :k].cpu().numpy(), ref[0]["boxes"])
+        assert (ol[0, :k].cpu().numpy() == 1).all()
+
+
 def test_cdist_fps_gather(dv):
     g = torch.Generator().manual_seed(13)
     x = torch.randn(1800, 256, generator=g)

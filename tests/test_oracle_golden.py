@@ -150,3 +150,31 @@ def test_g8_swin_body():
     out = swin.swin_body(T(z["x"]), sd, "backbone.bottom_up.", embed_dim=16, depths=(2, 2, 2, 1), num_heads=(1, 2, 4, 8))
     for k in ("swin1", "swin2", "swin3"):
         close(out[k], z[k], rtol=1e-6, atol=1e-6)
+
+
+def test_g12_nms_known_answers():
+    """The reference's own NMS known-answer vectors (tests/test_nms.py:11-58, :60-230; golden g12): the oracle's greedy
+    sweep under the legacy switch (+1 extents, suppression at >=; mega_core/csrc/cpu/nms_cpu.cpp:24,:57-62) returns
+    exactly the expected index sets.  The torchvision variant used on the DiffusionVID path shares every line of that
+    sweep except the two switched ones; on these vectors it differs only where a pair sits between the two IoU
+    conventions, which the test also states."""
+    from oracle import postproc
+    z = golden("g12_nms_known_answers")
+    n_diff = 0
+    for i in range(int(z["n_cases"])):
+        b, sc, th, want = z[f"boxes{i}"], z[f"scores{i}"], float(z[f"thresh{i}"]), z[f"keep{i}"]
+        keep = np.sort(postproc.nms_fp32(b, sc, th, legacy=True))
+        np.testing.assert_array_equal(keep, want)
+        plain = np.sort(postproc.nms_fp32(b, sc, th))
+        n_diff += int(len(plain) != len(want) or (plain != want).any())
+        # kept boxes never overlap each other beyond the threshold, under the variant's own IoU
+        for legacy, kept in ((True, keep), (False, plain)):
+            one = 1.0 if legacy else 0.0
+            bb = b[kept].astype(np.float64)
+            for a in range(len(bb)):
+                for c in range(a + 1, len(bb)):
+                    w = max(0.0, min(bb[a, 2], bb[c, 2]) - max(bb[a, 0], bb[c, 0]) + one)
+                    h = max(0.0, min(bb[a, 3], bb[c, 3]) - max(bb[a, 1], bb[c, 1]) + one)
+                    ua = ((bb[a, 2] - bb[a, 0] + one) * (bb[a, 3] - bb[a, 1] + one) + (bb[c, 2] - bb[c, 0] + one) * (bb[c, 3] - bb[c, 1] + one) - w * h)
+                    assert w * h / ua <= th + 1e-6
+    assert n_diff <= 2           # the +1 / >= conventions matter on at most two of the six cases
