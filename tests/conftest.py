@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle's small ops are slower with one OpenMP thread per core of a 256-core host than with 32
+    import torch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
 
 
 def golden(name):
