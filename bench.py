@@ -53,6 +53,8 @@ from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 TRAFFIC_FILE = "r01h_pmc_igemm_traffic.json"
 PEAK_FP16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
+# algorithmic work per output frame: backbone + heads + global attention, faithful pass counts
+ALG_GFLOP_PER_FRAME = {("r101", 1): 249.3, ("r101", 4): 385.0, ("swinb", 1): 459.6}
 
 
 def run_video(model, ds, device):
@@ -66,7 +68,7 @@ def run_video(model, ds, device):
 
 
 def cpu_baseline(cfg, sd, frames, height, width):
-    """Oracle (CPU port) on one steady-state 8-frame batch; returns dict for the JSON line."""
+    """Oracle (CPU port) on one steady-state 8-frame batch after a warm-up batch; returns dict for the JSON line."""
     from oracle import backbone_r101, detector as odet
     # pick the thread count that is actually fastest on this host (256 OpenMP threads on small ops can
     # be an order of magnitude slower than 32): one-frame backbone probe per candidate
@@ -89,19 +91,25 @@ def cpu_baseline(cfg, sd, frames, height, width):
     oracle.mem = [torch.randn(900, 256, generator=g), torch.randn(150, 256, generator=g)]
     oracle.feats = deque(maxlen=8)
     oracle.classes_300, oracle.proposals_300, oracle.proposals_feat_300 = deque(maxlen=8), deque(maxlen=8), deque(maxlen=8)
-    nb = len(frames)
-    item = {"cur": frames[0], "image_size": (height, width), "ref_l": frames, "ref_g": [], "frame_category": 1,
-            "frame_id": 8, "start_id": 0, "end_id": 8 + nb - 1, "seg_len": 8 + nb, "last_queue_id": 15}
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        out = oracle.forward(item)
-    dt = time.perf_counter() - t0
-    assert len(out) == nb
+    nb = 8
+    assert len(frames) >= 2 * nb
+
+    def call(fr, frame_id):
+        item = {"cur": fr[0], "image_size": (height, width), "ref_l": fr, "ref_g": [], "frame_category": 1,
+                "frame_id": frame_id, "start_id": 0, "end_id": 303, "seg_len": 304, "last_queue_id": frame_id + 7}
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = oracle.forward(item)
+        assert len(out) == len(fr)
+        return time.perf_counter() - t0
+    warm = call(frames[:nb], 8)             # warm-up call: thread pools, allocator, oneDNN primitive caches
+    dt = call(frames[nb:2 * nb], 16)
     return {"value": round(nb / dt, 4), "unit": "frames/sec", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(),
             "kind": "port",
-            "sample": "1 steady-state call on %d frames 1000x600 (R101-FPN + 3 RCNNHead + global attention + RCNNHead_cond "
-                      "+ top-k/NMS; per-video init excluded), CPU oracle fp32, %.1f s wall, %d threads (fastest of a "
-                      "16..%d probe)" % (nb, dt, torch.get_num_threads(), os.cpu_count())}
+            "sample": "frames 16-23 of the bench video (one steady-state call of the reference's per-batch protocol: R101-FPN + 3 "
+                      "RCNNHead + global attention + RCNNHead_cond + top-k/NMS on 8 frames 1000x600; the per-video global-memory "
+                      "initialisation is excluded), after one warm-up call on frames 8-15 (%.1f s); CPU oracle fp32, %.1f s wall, "
+                      "%d threads (fastest of a 16..%d probe on one backbone pass)" % (warm, dt, torch.get_num_threads(), os.cpu_count())}
 
 
 def launch_ranks(n):
@@ -161,6 +169,9 @@ def main():
                     help="r101 = the BASELINE.json headline configuration; swinb = configs/vid_Swin_B_DiffusionVID.yaml (INFER_BATCH 4)")
     ap.add_argument("--sample-step", type=int, default=1, help="MODEL.DiffusionDet.SAMPLE_STEP (4 = the x4 configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned frames, H2D in the timed region) measurement")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the reference-protocol (look-ahead 1), x4 and Swin-B measurements reported inside the line")
     ap.add_argument("--dry", action="store_true",
                     help="launcher / collective check without a GPU: every rank fabricates its shard's predictions, the gather to "
                          "rank 0 runs over gloo, and the JSON line reports the ranks seen (tests/test_dist_gloo.py)")
@@ -190,19 +201,9 @@ def main():
         assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
 
     headline = args.arch == "r101" and args.sample_step == 1
-    yaml = "configs/vid_R_101_DiffusionVID.yaml" if args.arch == "r101" else "configs/vid_Swin_B_DiffusionVID.yaml"
     if args.lookahead <= 0:
         args.lookahead = 13 if args.arch == "r101" else 26
-    cfg = get_cfg(os.path.join(ROOT, yaml), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", args.lookahead,
-                                             "MODEL.DiffusionDet.SAMPLE_STEP", args.sample_step],
-                  os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
-    cfg.freeze()
-    model = build_detection_model(cfg).to(device).eval()
-    model.noise_fn = synthetic.noise_fn
-    model.results_on_host = True      # one D2H copy per 8-frame batch (results end up on the host either way)
     H, W, L = 600, 1000, args.frames
-    ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank)
-    ds.preload()
 
     def barrier():
         torch.cuda.synchronize()
@@ -210,29 +211,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def build(arch, sample_step, lookahead):
+        yaml = "configs/vid_R_101_DiffusionVID.yaml" if arch == "r101" else "configs/vid_Swin_B_DiffusionVID.yaml"
+        cfg = get_cfg(os.path.join(ROOT, yaml), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", lookahead,
+                                                 "MODEL.DiffusionDet.SAMPLE_STEP", sample_step],
+                      os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+        cfg.freeze()
+        model = build_detection_model(cfg).to(device).eval()
+        model.noise_fn = synthetic.noise_fn
+        model.results_on_host = True      # one D2H copy per batch group (results end up on the host either way)
+        return cfg, model
+
+    def timed(model, ds, steps, warmup, gather=False, before_step=None):
+        """W warm-up passes, then exactly K passes between barriers; -> (seconds max over ranks, frames of all ranks)"""
+        with torch.no_grad():
+            for _ in range(warmup):
+                if before_step:
+                    before_step()
+                run_video(model, ds, device)
+            barrier()
+            t0 = time.perf_counter()
+            frames = 0
+            results = {}
+            for s in range(steps):
+                if before_step:
+                    before_step()
+                r = run_video(model, ds, device)
+                frames += len(r)
+                results.update({k + s * L + rank * steps * L: v.to("cpu") for k, v in r.items()})
+            if gather and world > 1:
+                engine.gather_predictions(results, device=device)
+            barrier()
+            dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        ff = torch.tensor([frames], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+        return float(tt.item()), float(ff.item())
+
+    def release(model):
+        if model._engine is not None:
+            model._engine.close()
+            model._engine = None
+        torch.cuda.empty_cache()
+
+    cfg, model = build(args.arch, args.sample_step, args.lookahead)
+    ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank)
+    ds.preload()
     with torch.no_grad():
         # set-up, outside the step accounting: weight repack / upload and the per-shape tile tuner (it times every
         # configuration on the first launch of each GEMM shape; DVID_IGEMM_TUNE_CACHE makes that persistent)
         run_video(model, ds, device)
-        for _ in range(args.warmup):
-            run_video(model, ds, device)
-        barrier()
-        t0 = time.perf_counter()
-        frames = 0
-        results = {}
-        for s in range(args.steps):
-            r = run_video(model, ds, device)
-            frames += len(r)
-            results.update({k + s * L + rank * args.steps * L: v.to("cpu") for k, v in r.items()})
-        merged = engine.gather_predictions(results, device=device) if world > 1 else results
-        barrier()
-        dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=device)
-    ff = torch.tensor([frames], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
-    dt, total_frames = float(tt.item()), float(ff.item())
+    dt, total_frames = timed(model, ds, args.steps, args.warmup, gather=True)
+
+    # ---- the same workload fed from the HOST: pinned fp32 frames, double-buffered H2D inside the timed region (what the
+    # reference's loop times, mega_core/engine/inference.py:29-40) -------------------------------------------------
+    host_fed = None
+    if not args.no_host_fed:
+        from diffusionvid_amd.data.prefetch import HostFedVideo
+        hds = SyntheticVIDDataset([L], cfg, height=H, width=W, device="cpu", video_base=rank)
+        # cyclic: the pass after the last group is the same video again, as in a stream of videos -- its first group is
+        # staged under the previous pass's last group; every pass still copies every frame
+        hf = HostFedVideo(hds, device, cfg.INPUT.INFER_BATCH * args.lookahead, cyclic=True).pin()
+        hsteps = max(1, min(args.steps, 3))
+        hdt, hframes = timed(model, hf, hsteps, 1)
+        per_pass = hf.h2d_bytes / (1 + hsteps + 1.0 / max(1, -(-L // (cfg.INPUT.INFER_BATCH * args.lookahead))))
+        host_fed = {"value": round(hframes / hdt, 2), "unit": "frames/sec",
+                    "h2d_gbytes_per_video": round(per_pass / 1e9, 3), "h2d_gbs": round(per_pass * hframes / L / world / hdt / 1e9, 2),
+                    "what": "frames start in pinned host memory as fp32 [0,1] CHW (the reference's DataLoader output); per look-ahead group "
+                            "one batch of async copies on a side stream into one of two HBM staging buffers, overlapped with the previous "
+                            "group's kernels; copies are inside the timed region"}
+        del hf, hds
 
     # ---- roofline of the dominant kernel: instrumented repeat of one step -------------------------
     roofline = None
@@ -269,23 +319,57 @@ def main():
         sec = ms.value * 1e-3
         tflops = fl.value / sec / 1e12
         gbs = ab.value / sec / 1e9
-        intensity = fl.value / max(ab.value, 1.0)                    # algorithmic FLOP per HBM byte over all igemm launches
-        ridge = PEAK_FP16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)       # 312 FLOP/B: below it the HBM roof is the lower one
-        hbm_bound = intensity < ridge
-        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": "igemm2_kernel (implicit-GEMM conv/linear, fp16 MFMA)",
-                    "achieved": round(gbs if hbm_bound else tflops, 2), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_FP16_TFLOPS,
-                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of tools/profile_round.sh on this "
-                                      "workload, bytes per launch; its own algorithmic figure is in the file)" % TRAFFIC_FILE,
-                    "alg_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
-                    "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_FP16_TFLOPS, 4),
+        fps = total_frames / dt
+        # the path is MFMA-bound (249.3 GFLOP against 60-90 MB of ideal-fusion HBM traffic per frame, ~3-4
+        # kFLOP/B); `achieved` = algorithmic FLOP of the launches / their summed durations.  The layer-by-layer byte model
+        # (every layer's input + weights + output + residual once) and the measured traffic are printed next to it: their
+        # ratio to the ideal-fusion figure is the activation round-trip traffic that fusion has yet to remove.
+        roofline = {"bound": "mfma", "kernel": "igemm2_kernel (implicit-GEMM conv/linear, fp16 MFMA)",
+                    "achieved": round(tflops, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP16_TFLOPS, 4),
+                    "traffic": traffic,
+                    "traffic_source": "profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh on this "
+                                      "workload, bytes per launch; not collected in this run)" % TRAFFIC_FILE,
                     "mfma_busy_pmc": None if mfma_busy is None else round(mfma_busy, 4),
-                    "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
-                    "alg_mbytes_per_launch": round(ab.value / max(1, nl.value) / 1e6, 2),
+                    "end_to_end_tflops": round(fps / max(world, 1) * ALG_GFLOP_PER_FRAME.get((args.arch, args.sample_step), 0) / 1e3, 1),
+                    "end_to_end_frac": round(fps / max(world, 1) * ALG_GFLOP_PER_FRAME.get((args.arch, args.sample_step), 0) / 1e3 / PEAK_FP16_TFLOPS, 4),
+                    "layerwise_alg_gbs": round(gbs, 1), "layerwise_alg_hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "layerwise_alg_mbytes_per_launch": round(ab.value / max(1, nl.value) / 1e6, 2),
+                    "ideal_fusion_mbytes_per_frame": "60-90 (SURVEY.md 8d)",
+                    "layerwise_alg_mbytes_per_frame": round(ab.value / 1e6 / (L + 24), 1),
                     "alg_gflop_per_launch": round(fl.value / max(1, nl.value) / 1e9, 3),
                     "launches_per_step": int(nl.value), "avg_launch_us": round(ms.value * 1e3 / max(1, nl.value), 2),
                     "kernel_ms_per_step": round(ms.value, 2)}
+
+    # ---- the reference's own call protocol (no look-ahead hand-over from the dataset) and the other single-GPU
+    # configurations of BASELINE.json, each with its own model; reported inside the same line ---------------------
+    sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()} if (rank == 0 and headline) else None
+    frames8 = [ds.frame(0, i).tensors.cpu() for i in range(8, 24)] if (rank == 0 and headline) else None
+    infer_batch = cfg.INPUT.INFER_BATCH
+    release(model)
+    del model
+    others = {}
+
+    def side(name, arch, sample_step, lookahead, steps):
+        try:
+            c2, m2 = build(arch, sample_step, lookahead)
+            d2 = ds if arch == args.arch else SyntheticVIDDataset([L], c2, height=H, width=W, device=device, video_base=rank)
+            if lookahead != args.lookahead or arch != args.arch:
+                d2 = SyntheticVIDDataset([L], c2, height=H, width=W, device=device, video_base=rank)
+                d2._cache = ds._cache              # same frames, already resident
+            with torch.no_grad():
+                run_video(m2, d2, device)
+            t2, f2 = timed(m2, d2, steps, 1)
+            others[name] = {"value": round(f2 / t2, 2), "unit": "frames/sec", "ms_per_step": round(t2 / steps * 1e3, 2),
+                            "lookahead_batches": lookahead, "infer_batch": c2.INPUT.INFER_BATCH, "sample_step": sample_step, "steps": steps}
+            release(m2)
+        except Exception as e:                     # a side measurement must never take the headline line down
+            others[name] = {"error": repr(e)[:300]}
+
+    if not args.no_side_configs:
+        side("reference_protocol_lookahead_1", args.arch, args.sample_step, 1, 2)
+        if headline and world == 1:
+            side("r101_x4", "r101", 4, 13, 2)
+            side("swinb_x1", "swinb", 1, 26, 2)
 
     if rank == 0:
         line = {
@@ -296,18 +380,21 @@ def main():
             "config": {"workload": "%s DiffusionVID x%d fp16, 300 boxes, %d DDIM step(s); one step = one synthetic "
                                    "%d-frame 1000x600 video per GPU (24 global + %d local frames, %d batches of %d)"
                                    % ("ResNet-101" if args.arch == "r101" else "Swin-Base", args.sample_step, args.sample_step, L, L,
-                                      -(-L // cfg.INPUT.INFER_BATCH), cfg.INPUT.INFER_BATCH),
-                       "frames_per_step_per_gpu": L, "infer_batch": cfg.INPUT.INFER_BATCH, "lookahead_batches": args.lookahead,
+                                      -(-L // infer_batch), infer_batch),
+                       "frames_per_step_per_gpu": L, "infer_batch": infer_batch, "lookahead_batches": args.lookahead,
+                       "lookahead_note": "INPUT.LOOKAHEAD_BATCHES > 1 is an extension of the caller protocol (the dataset hands the next "
+                                         "batches' frames over early); the reference's unchanged protocol is the "
+                                         "reference_protocol_lookahead_1 entry of other_configs",
                        "parallelism": "videos sharded across ranks (one process per GPU, %s)"
                                       % ("RCCL group of %d ranks: one gather of the predictions to rank 0" % dist.get_world_size()
                                          if world > 1 else "single rank, no collective"),
                        "ranks": world},
             "roofline": roofline,
+            "host_fed": host_fed,
+            "other_configs": others,
         }
         if world == 1 and headline and not args.no_cpu_baseline:
-            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-            frames8 = [ds.frame(0, i).tensors.cpu() for i in range(8, 12)]
-            line["cpu_baseline"] = cpu_baseline(cfg, sd, frames8, H, W)
+            line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, frames8, H, W)
             line["gpu_over_cpu"] = round(line["value"] / max(line["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -547,3 +547,95 @@ def test_single_video_sharded_over_ranks_reproduces_sequential_run(sample_step, 
         a, b = seq[i], merged[i]
         assert len(a) == len(b) and torch.equal(a.bbox, b.bbox)
         assert torch.equal(a.get_field("scores"), b.get_field("scores")) and torch.equal(a.get_field("labels"), b.get_field("labels"))
+
+
+def test_checkpoint_ingest_reproduces_direct_load(tmp_path):
+    """a checkpoint under the reference's naming variations (`module.` prefix, DiffusionDet head
+    numbering) loaded through DetectronCheckpointer gives bit-identical detections to the same weights put in directly."""
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.utils import synthetic
+    from diffusionvid_amd.utils.checkpoint import DetectronCheckpointer
+    cfg, direct = _build(1, (1, 1, 1, 1))
+    g = torch.Generator().manual_seed(3)
+    sd = {k: (v.cpu() * (1 + 0.05 * torch.randn(v.shape, generator=g)) if (v.is_floating_point() and "running_var" not in k) else v.cpu())
+          for k, v in direct.state_dict().items()}
+    direct.load_state_dict(sd)
+    f = tmp_path / "ckpt.pth"
+    torch.save({"model": {"module." + k.replace("head_series_cond.0", "head_series.3"): v for k, v in sd.items()}}, f)
+    _, loaded = _build(1, (1, 1, 1, 1))
+    DetectronCheckpointer(cfg, loaded).load(str(f))
+    ds = SyntheticVIDDataset([8], cfg, height=120, width=200, device="cuda", smooth=True)
+    outs = []
+    for m in (direct, loaded):
+        m.noise_fn = synthetic.noise_fn
+        with torch.no_grad():
+            outs.append(m(ds[0][0]))
+    assert len(outs[0]) == 8 and sum(len(o) for o in outs[0]) > 0
+    for a, b in zip(*outs):
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
+        assert torch.equal(a.get_field("labels"), b.get_field("labels"))
+
+
+def test_streaming_mode_online_memory_update():
+    """the latency-oriented variant -- demo/demo.py:60-68 (INFER_BATCH 1, ALL_FRAME_INTERVAL 1,
+    MAX_OFFSET 0) with GLOBAL.STOP_UPDATE_AFTER_INIT_TEST False, i.e. one frame per call and one new global frame per call
+    after the first (vid_mega.py:213-215): every call merges 75 / 25 new rows into the 900 / 150-row memories and prunes
+    them back by farthest-point sampling (diffusion_det.py:479-488, :841-896).  Against the CPU oracle running the same
+    protocol: per call, the GPU's pruning on the ORACLE's merged rows returns the oracle's rows exactly (integer work);
+    the free-running GPU memory stays the same point set up to near-ties; detections match."""
+    from diffusionvid_amd import ops
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    blocks = (1, 1, 1, 1)
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml",
+                  ["INPUT.INFER_BATCH", 1, "MODEL.VID.MEGA.MAX_OFFSET", 0, "MODEL.VID.MEGA.MIN_OFFSET", 0,
+                   "MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 1, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 0,
+                   "MODEL.VID.MEGA.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST", False], "configs/BASE_RCNN_1gpu.yaml")
+    cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = blocks
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+    model = model.to("cuda").eval()
+    model.noise_fn = synthetic.noise_fn
+    L, H0, W0 = 30, 120, 200
+    ds = SyntheticVIDDataset([L], cfg, height=H0, width=W0, device="cuda", smooth=True)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    oracle = odet.OracleDiffusionDet(sd, odet.DetCfg(blocks=blocks, infer_batch=1, all_frame_interval=1), synthetic.noise_fn)
+    rates, mem_close = [], []
+    for idx in range(L):
+        images, oitem, ids = _oracle_items(ds, idx)
+        assert len(images["ref_l"]) == 1 and len(images["ref_g"]) == (24 if idx == 0 else 1) and ids == [idx]
+        mem_before = None if idx == 0 else [m.clone() for m in oracle.mem]
+        with torch.no_grad():
+            ref = oracle.forward(oitem)
+            got = model(images)
+        assert len(ref) == len(got) == 1
+        rates.append(_match_rate(ref[0], got[0]))
+        if idx > 0:
+            # the pruning step alone, on the oracle's own rows: cat(memory 900, new 75) -> cdist -> FPS(900) -> gather
+            new = oracle.taps["extract"][2][1:]                 # object features of the call's global frame
+            cls = oracle.taps["extract"][0][1:]
+            from oracle import head as ohead
+            k1, _ = ohead.select_topk_features(cls, new.reshape(1, -1, 256), oracle.cfg.head)
+            merged = torch.cat([mem_before[0], k1], dim=0)
+            assert merged.shape[0] == 975
+            got_mem, got_idx = ops.update_erase_memory(k1.cuda(), mem_before[0].cuda(), 900)
+            D = torch.cdist(merged, merged, p=2.0)
+            ref_idx = omem.fps_kernel_order(D.numpy(), 900)
+            same = (got_idx.cpu().numpy() == ref_idx).mean()
+            # cdist of the two paths differs in the last bits (fp32 order), so picks may swap at exact near-ties
+            assert same > 0.98, f"call {idx}: only {same:.3f} of the FPS picks agree"
+        gm, om = model.head.proposal_feats_global[0].cpu(), oracle.mem[0]
+        assert gm.shape == om.shape == (900, 256)
+        mem_close.append((torch.cdist(om, gm).min(dim=1).values < 0.5).float().mean().item())
+    print(f"[streaming] match rates min {min(rates):.2f} mean {sum(rates) / len(rates):.3f}; memory rows with a GPU twin: "
+          f"first {mem_close[0]:.3f} last {mem_close[-1]:.3f}")
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write(f"[streaming INFER_BATCH=1, online memory] detections matched min {min(rates):.2f} mean {sum(rates) / len(rates):.3f}; "
+                f"memory twins first {mem_close[0]:.3f} last {mem_close[-1]:.3f}\n")
+    assert min(rates) >= 0.85 and sum(rates) / len(rates) >= 0.95
+    # free-running memories drift apart as a point set (every call re-picks 900 of 975 rows from slightly different features:
+    # measured 0.87 -> 0.73 of the oracle's rows with a GPU row within 0.5 over 30 calls) while the detections stay matched
+    assert min(mem_close) > 0.5

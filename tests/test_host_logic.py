@@ -241,3 +241,68 @@ def test_dataset_lookahead_slots_match_later_calls():
         assert len(frames) == len(delivered[fb]) == 8
         for a, b in zip(frames, delivered[fb]):
             assert a is b                  # the same cached ImageList object -> the same frame
+
+
+def test_checkpoint_key_matching_matches_reference_golden():
+    """utils/checkpoint.py (strip `module.`, DiffusionDet -> DiffusionVID head renaming, longest-suffix matching) against
+    what the reference's own loader functions did with the same key sets (golden g13: model_serialization.py:12-138 run
+    under the import shims): every model key must take the same source key, or none."""
+    from conftest import golden
+    from diffusionvid_amd.utils import checkpoint as ck
+    z = golden("g13_checkpoint_matching")
+    model_keys = [str(k) for k in z["model_keys"]]
+    cases = sorted(k[len("loaded."):] for k in z.files if k.startswith("loaded."))
+    assert len(cases) == 5
+    for name in cases:
+        loaded = {str(k): str(k) for k in z["loaded." + name]}
+        loaded = ck.strip_prefix_if_present(loaded, "module.")
+        loaded = ck.remap_diffusiondet_heads(model_keys, loaded, None)
+        got = ck.match_keys(sorted(model_keys), sorted(loaded.keys()))
+        want = dict(zip(model_keys, (str(s) for s in z["source." + name])))
+        for k in model_keys:
+            src = loaded[got[k]] if got[k] is not None else ""
+            assert src == want[k], f"{name}: {k} <- {src!r}, reference {want[k]!r}"
+    # the cases are not vacuous
+    assert sum(1 for s in z["source.diffusiondet_heads"] if "head_series.3" in str(s)) > 40
+    assert sum(1 for s in z["source.backbone_pickle"] if str(s)) == 85
+    amb = dict(zip(model_keys, (str(s) for s in z["source.ambiguous_suffixes"])))
+    assert amb["backbone.bottom_up.res2.0.conv1.weight"] == "res2.0.conv1.weight"
+    assert amb["backbone.bottom_up.res3.0.conv1.weight"] == "0.conv1.weight"
+
+
+def test_detectron_checkpointer_round_trip(tmp_path):
+    """A released-style checkpoint -- `module.` prefix, DiffusionDet head numbering, wrapped in {"model": ...} -- and a
+    detectron2 torchvision pickle (numpy arrays, bare backbone names) load through DetectronCheckpointer into the model's
+    own names with the exact values (what dvid_model_finalize then folds / repacks)."""
+    import pickle
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils.checkpoint import DetectronCheckpointer
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.DEVICE", "cpu"], "configs/BASE_RCNN_1gpu.yaml")
+    cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    g = torch.Generator().manual_seed(99)
+    want = {k: (v + torch.randn(v.shape, generator=g) * 0.1 if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    ckpt = {"module." + k.replace("head_series_cond.0", "head_series.3"): v for k, v in want.items()}
+    f = tmp_path / "model_final.pth"
+    torch.save({"model": ckpt, "iteration": 7, "optimizer": {}}, f)
+    extra = DetectronCheckpointer(cfg, model).load(str(f))
+    assert extra == {"iteration": 7}
+    got = model.state_dict()
+    assert set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want)
+    # backbone-only pickle on top: body weights replaced, everything else untouched
+    body = {k[len("backbone.bottom_up."):]: (v * 2).numpy() for k, v in want.items() if k.startswith("backbone.bottom_up.")}
+    p = tmp_path / "torchvision-R-101.pkl"
+    with open(p, "wb") as fh:
+        pickle.dump({"model": body, "__author__": "x"}, fh)
+    ck = DetectronCheckpointer(cfg, model)
+    ck.load(str(p))
+    got = model.state_dict()
+    for k in want:
+        ref = want[k] * 2 if k.startswith("backbone.bottom_up.") else want[k]
+        assert torch.equal(got[k], ref), k
+    assert all(not k.startswith("backbone.bottom_up.") for k in ck.missed_keys) and "head.time_mlp.1.weight" in ck.missed_keys
+    with pytest.raises(NotImplementedError):
+        DetectronCheckpointer(get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.BACKBONE.CONV_BODY", "R-101-FPN", "MODEL.DEVICE", "cpu"],
+                                      "configs/BASE_RCNN_1gpu.yaml"), model).load(str(p))
