@@ -60,6 +60,8 @@ SIGNATURES = {
     "dvid_nhwc_from_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dvid_nchw_from_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dvid_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "dvid_resize_u8_to_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_int, c_void_p]),
     "dvid_igemm_num_configs": (c_int, []),
     "dvid_igemm_set_config": (c_int, [c_int]),
     "dvid_profile_enable": (c_int, [c_int]),

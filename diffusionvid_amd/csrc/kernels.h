@@ -30,6 +30,8 @@ int dvid_add_layernorm_launch(const float* x, const float* r, const float* g, co
                               int rows, int d, int relu, hipStream_t s, int nsplit = 1, long split_stride = 0,
                               const float* xbias = nullptr);
 int dvid_f32_to_f16_launch(const float* x, half_t* y, long n, hipStream_t s);
+int dvid_resize_u8_launch(const unsigned char* src, int h, int w, unsigned char* tmp, float* out, int oh, int ow, int ph, int pw,
+                          const int* xbounds, const int* xk, int xksize, const int* ybounds, const int* yk, int yksize, hipStream_t s);
 // fc = x * (scale[frame] + 1) + shift  (shift per frame [B,D] or per row [R,D])
 int dvid_modulate_launch(const float* x, const float* scale, int scale_ld, const float* shift, int shift_per_row, int shift_ld,
                          half_t* y16, int rows, int rows_per_frame, int d, hipStream_t s);

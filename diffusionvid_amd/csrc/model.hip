@@ -1181,6 +1181,17 @@ int dvid_f32_to_f16(const float* x, void* y, int64_t n, void* stream) {
     return DVID_OK;
 }
 
+int dvid_resize_u8_to_f32(const void* src_hwc, int h, int w, void* tmp, float* out_chw, int oh, int ow, int ph, int pw,
+                          const int* xbounds, const int* xk, int xksize, const int* ybounds, const int* yk, int yksize, void* stream) {
+    g_err[0] = 0;
+    if (!src_hwc || !out_chw) FAIL(DVID_ERR_ARG, "null image");
+    const int rc = dvid_resize_u8_launch(reinterpret_cast<const unsigned char*>(src_hwc), h, w, reinterpret_cast<unsigned char*>(tmp),
+                                         out_chw, oh, ow, ph, pw, xbounds, xk, xksize, ybounds, yk, yksize,
+                                         reinterpret_cast<hipStream_t>(stream));
+    if (rc != DVID_OK) FAIL(rc, "resize %dx%d -> %dx%d (padded %dx%d): bad sizes or missing tables / scratch", h, w, oh, ow, ph, pw);
+    return DVID_OK;
+}
+
 // ---- measurement -------------------------------------------------------------------------------
 int dvid_profile_enable(int on) {
     g_prof_on = on != 0;

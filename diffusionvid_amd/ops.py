@@ -128,6 +128,21 @@ def add_layernorm(x, r, g, b, relu=False):
     return y
 
 
+def resize_u8_to_f32(src_hwc, oh, ow, ph, pw, xtab, ytab):
+    """uint8 [H, W, 3] (device) -> fp32 [1, 3, ph, pw] in [0, 1]: Pillow-identical bilinear resize to (oh, ow), zero padding to
+    (ph, pw).  xtab / ytab: (bounds, weights) int32 device tensors of data/transforms.resample_tables, None for an axis
+    that keeps its size."""
+    src = _cuda(src_hwc, torch.uint8)
+    h, w = src.shape[:2]
+    out = torch.empty((1, 3, ph, pw), dtype=torch.float32, device=src.device)
+    tmp = torch.empty((h, ow, 3), dtype=torch.uint8, device=src.device) if xtab is not None else None
+    xb, xk = xtab if xtab is not None else (None, None)
+    yb, yk = ytab if ytab is not None else (None, None)
+    call("dvid_resize_u8_to_f32", ptr(src), h, w, ptr(tmp), ptr(out), oh, ow, ph, pw, ptr(xb), ptr(xk), 0 if xk is None else xk.shape[1],
+         ptr(yb), ptr(yk), 0 if yk is None else yk.shape[1], stream_ptr())
+    return out
+
+
 def noise_to_boxes(x, snr_scale, img_w, img_h):
     x = _cuda(x, torch.float32)
     out = torch.empty_like(x)

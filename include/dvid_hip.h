@@ -158,6 +158,15 @@ int dvid_nhwc_from_nchw(const float* in, void* out_f16, int n, int h, int w, int
 int dvid_nchw_from_nhwc(const void* in_f16, float* out, int n, int h, int w, int c, void* stream);
 int dvid_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
 
+/* Test-time Resize + ToTensor + padding on the device (mega_core/data/transforms/build.py:89-97, transforms.py:31-70:
+ * PIL.Image.resize(BILINEAR) through torchvision; structures/image_list.py:54-61): src uint8 [h][w][3] RGB ->
+ * out fp32 [3][ph][pw] in [0,1], rows >= oh / columns >= ow zero.  Bit-identical to Pillow: two integer passes with the
+ * 22-bit weight tables of diffusionvid_amd/data/transforms.py:resample_tables (bounds int32 [n][2] = first source sample,
+ * count; weights int32 [n][ksize]); a table pointer is NULL exactly when that axis keeps its size.  tmp: >= h*ow*3 bytes
+ * (unused when ow == w). */
+int dvid_resize_u8_to_f32(const void* src_hwc, int h, int w, void* tmp, float* out_chw, int oh, int ow, int ph, int pw,
+                          const int* xbounds, const int* xk, int xksize, const int* ybounds, const int* yk, int yksize, void* stream);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Tile configurations of the implicit-GEMM kernel (all bit-identical in their results): the per-shape tuner picks one;
  * dvid_igemm_set_config(k) forces table entry k wherever it is valid (k = -1: back to the tuner). */

@@ -343,6 +343,69 @@ def g13_checkpoint_matching():
     save("g13_checkpoint_matching", **arrs)
 
 
+def g14_vid_dataset_protocol():
+    """The reference's REAL dataset class at test time -- VIDMEGADataset._get_test (vid_mega.py:164-250) over VIDDataset's
+    frame-list parser (vid.py:56-66) -- on a tiny on-disk set (3 videos of 21 / 9 / 1 frames; every image stores its
+    (video, frame) in pixel (0, 0), so the files each item loaded are read back from the pixels), for the shipped
+    protocol and for the streaming one (one global frame per call); and Resize.get_size (transforms.py:31-59) on a table
+    of source sizes."""
+    import pickle
+    import tempfile
+    from PIL import Image
+    from mega_core.config import cfg as RC
+    from mega_core.data.datasets.vid_mega import VIDMEGADataset
+    from mega_core.data.transforms import transforms as T
+    root = tempfile.mkdtemp()
+    lens = [21, 9, 1]
+    os.makedirs(os.path.join(root, "ImageSets"))
+    lines, annos = [], []
+    n = 0
+    for v, L in enumerate(lens):
+        d = os.path.join(root, "Data", "VID", "val", "vid%02d" % v)
+        os.makedirs(d)
+        for f in range(L):
+            n += 1
+            img = np.zeros((12, 16, 3), np.uint8)
+            img[0, 0] = (v, f, 7)
+            Image.fromarray(img).save(os.path.join(d, "%06d.JPEG" % f), format="PNG")        # lossless content under the name the class opens
+            lines.append("val/vid%02d %d %d %d" % (v, n, f, L))
+            annos.append({"boxes": torch.zeros((0, 4)), "labels": torch.zeros((0,), dtype=torch.int64), "im_info": (12, 16)})
+    index = os.path.join(root, "ImageSets", "VID_val_videos.txt")
+    open(index, "w").write("\n".join(lines) + "\n")
+    os.makedirs(os.path.join(root, "cache"))
+    pickle.dump(annos, open(os.path.join(root, "cache", "VID_val_videos_anno.pkl"), "wb"))
+    arrs = {"lens": np.array(lens), "index_lines": np.array(lines)}
+    for tag, stop in (("shipped", True), ("streaming", False)):
+        M = RC.MODEL.VID.MEGA
+        M.MAX_OFFSET, M.MIN_OFFSET, M.ALL_FRAME_INTERVAL, M.KEY_FRAME_LOCATION = (7, -0, 8, 0) if stop else (0, 0, 1, 0)
+        M.GLOBAL.ENABLE, M.GLOBAL.SIZE, M.GLOBAL.SHUFFLE, M.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST = True, 24, False, stop
+        M.SHUFFLED_CUR_TEST = False
+        RC.INPUT.INFER_BATCH = 8 if stop else 1
+        ds = VIDMEGADataset("VID_val_videos", root, os.path.join(root, "Data", "VID"), os.path.join(root, "Annotations", "VID"), index,
+                            None, is_train=False)
+        rows, ref_l, ref_g, ids_all = [], [], [], []
+        for idx in range(len(ds)):
+            images, target, ids = ds[idx]
+            px = lambda im: tuple(int(x) for x in np.asarray(im)[0, 0][:2])       # noqa: E731
+            assert px(images["cur"]) == (ds.frame_seg_len.index(ds.frame_seg_len[idx]) * 0 + px(images["cur"])[0], ds.frame_seg_id[idx])
+            rows.append([images["frame_category"], images["frame_id"], images["start_id"], images["end_id"], images["seg_len"],
+                         images["last_queue_id"], px(images["cur"])[0], len(images["ref_l"]), len(images["ref_g"])])
+            ref_l += [px(im)[1] for im in images["ref_l"]]
+            ref_g += [px(im)[1] for im in images["ref_g"]]
+            ids_all.append(ids)
+        arrs[tag + ".rows"] = np.array(rows, dtype=np.int64)
+        arrs[tag + ".ref_l"] = np.array(ref_l, dtype=np.int64)
+        arrs[tag + ".ref_g"] = np.array(ref_g, dtype=np.int64)
+        arrs[tag + ".ids"] = np.array(ids_all, dtype=np.int64)
+        arrs[tag + ".start_index"] = np.array(ds.start_index, dtype=np.int64)
+    rs = T.Resize(600, 1000)
+    sizes = [(1280, 720), (720, 1280), (640, 480), (500, 375), (1000, 600), (600, 1000), (1920, 1080), (320, 240), (1001, 599),
+             (2000, 500), (600, 600), (333, 500), (176, 144), (1280, 960), (853, 480)]
+    arrs["resize.wh"] = np.array(sizes, dtype=np.int64)
+    arrs["resize.out_hw"] = np.array([rs.get_size(wh) for wh in sizes], dtype=np.int64)
+    save("g14_vid_dataset_protocol", **arrs)
+
+
 if __name__ == "__main__":
     # The reference targets torch 1.8 (INSTALL.md:3-13) where nn.MultiheadAttention.forward IS
     # F.multi_head_attention_forward; keep torch 2.x's fused inference fast path out of the goldens.
@@ -361,3 +424,4 @@ if __name__ == "__main__":
     g10_sampler()
     g12_nms_known_answers()
     g13_checkpoint_matching()
+    g14_vid_dataset_protocol()

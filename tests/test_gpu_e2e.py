@@ -639,3 +639,50 @@ def test_streaming_mode_online_memory_update():
     # free-running memories drift apart as a point set (every call re-picks 900 of 975 rows from slightly different features:
     # measured 0.87 -> 0.73 of the oracle's rows with a GPU row within 0.5 over 30 calls) while the detections stay matched
     assert min(mem_close) > 0.5
+
+
+def test_real_dataset_front_end_device_transform_equals_host_transform(tmp_path):
+    """SURVEY.md 8f row 2 end to end: image files on disk in the reference's layout -> VIDMEGATestDataset (frame list, item
+    protocol, look-ahead hand-over) -> Resize + ToTensor -> detector.  The device transform (uint8 upload, HIP resize) must
+    give exactly the detections of the host transform (Pillow, the reference's path), on frames whose size differs from
+    the network's (so the resize really happens) -- and a second video of another aspect ratio follows in the same run
+    (mixed frame sizes through one model)."""
+    from PIL import Image
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data import transforms as T
+    from diffusionvid_amd.data.datasets import VIDMEGATestDataset
+    from diffusionvid_amd.engine import inference as eng
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    lens, sizes = [19, 9], [(90, 160), (120, 96)]
+    lines, n = [], 0
+    for v, (L, hw) in enumerate(zip(lens, sizes)):
+        d = tmp_path / "Data" / "VID" / "val" / ("vid%02d" % v)
+        d.mkdir(parents=True)
+        for f in range(L):
+            n += 1
+            img = (synthetic.synthetic_frame(f, hw[0], hw[1], video=v, smooth=True) * 255).round().byte().permute(1, 2, 0).numpy()
+            Image.fromarray(img).save(str(d / ("%06d.JPEG" % f)), format="PNG")
+            lines.append("val/vid%02d %d %d %d" % (v, n, f, L))
+    (tmp_path / "ImageSets").mkdir()
+    index = tmp_path / "ImageSets" / "VID_val_videos.txt"
+    index.write_text("\n".join(lines) + "\n")
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.VID.MEGA.GLOBAL.SHUFFLE", False, "INPUT.LOOKAHEAD_BATCHES", 2],
+                  "configs/BASE_RCNN_1gpu.yaml")
+    cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+    model = model.to("cuda").eval()
+    model.noise_fn = synthetic.noise_fn
+    dev = torch.device("cuda")
+    img_dir = str(tmp_path / "Data" / "VID")
+    host = VIDMEGATestDataset(cfg, img_dir, str(index), transform=T.ResizeToTensor(120, 200))
+    devi = VIDMEGATestDataset(cfg, img_dir, str(index), transform=T.ResizeToTensorDevice("cuda", 120, 200, 32))
+    a = eng.compute_on_dataset(model, host, range(len(host)), dev)
+    b = eng.compute_on_dataset(model, devi, range(len(devi)), dev)
+    assert sorted(a) == sorted(b) == list(range(sum(lens)))
+    assert a[0].size == (199, 112) and a[lens[0]].size == (120, 150)          # (w, h) of the resized frames of the two videos
+    for i in a:
+        assert torch.equal(a[i].bbox, b[i].bbox) and torch.equal(a[i].get_field("scores"), b[i].get_field("scores"))
+    assert sum(len(x) for x in a.values()) > 0

@@ -513,3 +513,26 @@ def test_swin_backbone_specialised_paths_bit_identical():
     for a, b in zip(fast, slow):
         assert torch.isfinite(a.float()).all() and torch.equal(a, b)
     m.close()
+
+
+@pytest.mark.parametrize("hw,mn,mx", [((720, 1280), 600, 1000), ((1280, 720), 600, 1000), ((480, 640), 600, 1000), ((600, 1000), 600, 1000),
+                                      ((375, 500), 600, 1000), ((97, 161), 60, 100), ((53, 37), 84, 120)])
+def test_resize_u8_matches_pillow(dv, hw, mn, mx):
+    """csrc/resize.hip: uint8 frame at native size -> Resize(min, max) + ToTensor + /32 zero padding on the device, against
+    Pillow's BILINEAR resize (what torchvision's F.resize runs on the reference's PIL images, transforms.py:61-70) --
+    byte work, so bit-exact; covers down- and up-scaling, portrait frames, an axis that keeps its size, full VID sizes."""
+    from PIL import Image
+    from diffusionvid_amd.data import transforms as T
+    rng = np.random.RandomState(hw[0])
+    img = rng.randint(0, 256, size=hw + (3,)).astype(np.uint8)
+    tf = T.ResizeToTensorDevice("cuda", mn, mx, 32)
+    out = tf(img, True)
+    oh, ow = T.get_size((hw[1], hw[0]), mn, mx)
+    assert out.image_size == (oh, ow) and out.shape == (1, 3, -(-oh // 32) * 32, -(-ow // 32) * 32)
+    ref = torch.from_numpy(np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR)).copy()).permute(2, 0, 1).float().div(255)
+    got = out.cpu()[0]
+    assert torch.equal(got[:, :oh, :ow], ref)
+    assert got[:, oh:].abs().sum() == 0 and got[:, :, ow:].abs().sum() == 0
+    # a reference frame re-uses the current frame's size (transforms.py:63-65)
+    other = rng.randint(0, 256, size=hw + (3,)).astype(np.uint8)
+    assert tf(other, False).image_size == (oh, ow)

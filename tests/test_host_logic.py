@@ -306,3 +306,108 @@ def test_detectron_checkpointer_round_trip(tmp_path):
     with pytest.raises(NotImplementedError):
         DetectronCheckpointer(get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.BACKBONE.CONV_BODY", "R-101-FPN", "MODEL.DEVICE", "cpu"],
                                       "configs/BASE_RCNN_1gpu.yaml"), model).load(str(p))
+
+
+def _tiny_vid_set(tmp_path, lens, hw=(12, 16)):
+    """on-disk set in the reference's layout; every image stores (video, frame) in pixel (0, 0)"""
+    from PIL import Image
+    lines, n = [], 0
+    for v, L in enumerate(lens):
+        d = tmp_path / "Data" / "VID" / "val" / ("vid%02d" % v)
+        d.mkdir(parents=True)
+        for f in range(L):
+            n += 1
+            img = np.zeros(hw + (3,), np.uint8)
+            img[0, 0] = (v, f, 7)
+            Image.fromarray(img).save(str(d / ("%06d.JPEG" % f)), format="PNG")
+            lines.append("val/vid%02d %d %d %d" % (v, n, f, L))
+    (tmp_path / "ImageSets").mkdir()
+    index = tmp_path / "ImageSets" / "VID_val_videos.txt"
+    index.write_text("\n".join(lines) + "\n")
+    return str(tmp_path / "Data" / "VID"), str(index), lines
+
+
+@pytest.mark.parametrize("tag", ["shipped", "streaming"])
+def test_real_vid_dataset_protocol_matches_reference_class(tmp_path, tag):
+    """data/datasets/vid.py against the reference's REAL VIDMEGADataset._get_test run on the same on-disk layout (golden
+    g14): bookkeeping ints, the files loaded as local / global reference frames (read back from the pixels), image ids;
+    the synthetic bench dataset must produce the same protocol for the same video lengths."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.datasets import VIDFrameList, VIDMEGATestDataset
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    z = golden("g14_vid_dataset_protocol")
+    lens = [int(x) for x in z["lens"]]
+    img_dir, index, lines = _tiny_vid_set(tmp_path, lens)
+    assert lines == [str(x) for x in z["index_lines"]]
+    opts = [] if tag == "shipped" else ["INPUT.INFER_BATCH", 1, "MODEL.VID.MEGA.MAX_OFFSET", 0, "MODEL.VID.MEGA.MIN_OFFSET", 0,
+                                        "MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 1, "MODEL.VID.MEGA.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST", False]
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", opts + ["MODEL.VID.MEGA.GLOBAL.SHUFFLE", False], "configs/BASE_RCNN_1gpu.yaml")
+    fl = VIDFrameList(index)
+    assert len(fl) == sum(lens) and fl.frame_seg_len[0] == lens[0] and fl.image_set_index[22] == "val/vid01/000001"
+    ds = VIDMEGATestDataset(cfg, img_dir, index)
+    syn = SyntheticVIDDataset(lens, cfg, height=12, width=16)
+    assert ds.start_index == [int(x) for x in z[tag + ".start_index"]] == syn.start_index
+    rows, ref_l, ref_g = z[tag + ".rows"], list(z[tag + ".ref_l"]), list(z[tag + ".ref_g"])
+    pl = pg = 0
+    for idx in range(len(ds)):
+        images, target, ids = ds[idx]
+        px = lambda im: (int(im[0, 0, 0]), int(im[0, 0, 1]))       # noqa: E731
+        got = [images["frame_category"], images["frame_id"], images["start_id"], images["end_id"], images["seg_len"],
+               images["last_queue_id"], px(images["cur"])[0], len(images["ref_l"]), len(images["ref_g"])]
+        assert got == [int(x) for x in rows[idx]], (idx, got, rows[idx])
+        assert px(images["cur"])[1] == images["frame_id"]
+        nl, ng = len(images["ref_l"]), len(images["ref_g"])
+        assert [px(im)[1] for im in images["ref_l"]] == [int(x) for x in ref_l[pl:pl + nl]]
+        assert [px(im)[1] for im in images["ref_g"]] == [int(x) for x in ref_g[pg:pg + ng]]
+        assert ids == [int(x) for x in z[tag + ".ids"][idx]]
+        # the synthetic driver emits the same protocol
+        s_l, s_g, s_last = syn.ref_ids(idx)
+        assert s_l == [int(x) for x in ref_l[pl:pl + nl]] and s_g == [int(x) for x in ref_g[pg:pg + ng]] and s_last == images["last_queue_id"]
+        pl, pg = pl + nl, pg + ng
+    assert pl == len(ref_l) and pg == len(ref_g)
+
+
+def test_real_vid_dataset_lookahead_handover(tmp_path):
+    """INPUT.LOOKAHEAD_BATCHES: `ref_ahead` of the real dataset holds, per later batch of the group, exactly the frames its own
+    calls would deliver through `ref_l` (same files, same order), like the synthetic dataset's."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.datasets import VIDMEGATestDataset
+    img_dir, index, _ = _tiny_vid_set(tmp_path, [37, 8])
+    base = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.VID.MEGA.GLOBAL.SHUFFLE", False], "configs/BASE_RCNN_1gpu.yaml")
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.VID.MEGA.GLOBAL.SHUFFLE", False, "INPUT.LOOKAHEAD_BATCHES", 3],
+                  "configs/BASE_RCNN_1gpu.yaml")
+    plain, ahead = VIDMEGATestDataset(base, img_dir, index), VIDMEGATestDataset(cfg, img_dir, index)
+    px = lambda im: int(im[0, 0, 1])       # noqa: E731
+    delivered = {}
+    for idx in range(37):
+        it = plain[idx][0]
+        fb = -(-it["frame_id"] // 8) * 8
+        delivered.setdefault(fb, []).extend(px(im) for im in it["ref_l"])
+    for idx in range(45):
+        it = ahead[idx][0]
+        assert ("ref_ahead" in it) == (it["frame_id"] % 24 == 0)
+        if it["seg_len"] <= it["frame_id"] + 8:
+            assert not it.get("ref_ahead")
+        if idx < 37 and "ref_ahead" in it:
+            for fb, frames in it["ref_ahead"].items():
+                assert [px(im) for im in frames] == delivered[fb], fb
+
+
+def test_resize_matches_pillow_and_reference_size_rule():
+    """data/transforms.py: get_size against the reference's Resize.get_size table (golden g14, transforms.py:39-59); the
+    integer two-pass resample (the tables the HIP kernels consume) against Pillow's own BILINEAR resize, bit for bit,
+    including an axis that keeps its size and an up-scaling case."""
+    from PIL import Image
+    from diffusionvid_amd.data import transforms as T
+    z = golden("g14_vid_dataset_protocol")
+    for wh, want in zip(z["resize.wh"], z["resize.out_hw"]):
+        assert tuple(T.get_size((int(wh[0]), int(wh[1])))) == (int(want[0]), int(want[1]))
+    rng = np.random.RandomState(1)
+    for (h, w), (mn, mx) in [((72, 128), (60, 100)), ((128, 72), (60, 100)), ((37, 53), (84, 120)), ((60, 100), (60, 100)),
+                             ((200, 50), (40, 90)), ((90, 161), (60, 100))]:
+        img = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        oh, ow = T.get_size((w, h), mn, mx)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        np.testing.assert_array_equal(T.resize_u8_numpy(img, (oh, ow)), ref)
+        t = T.ResizeToTensor(mn, mx)(img, True)
+        assert t.shape == (3, oh, ow) and torch.equal(t, torch.from_numpy(ref.copy()).permute(2, 0, 1).float().div(255))
