@@ -186,6 +186,10 @@ struct dvid_model {
 
     // sub-batch chains (see dvid_backbone_resnet_fpn)
     int nchain = 2;
+    // software pipeline of the ResNet backbone (see dvid_backbone_resnet_fpn): sub-batches, and the (stage, block) at which
+    // a sub-batch moves from the front stream to the back stream; pipe_parts <= 1: off
+    int pipe_parts = 0, pipe_stage = 2, pipe_block = 0;
+    std::vector<hipEvent_t> ev_mid;
     hipStream_t cs[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool streams_ready = false;
@@ -566,6 +570,14 @@ int dvid_model_create(const dvid_config* cfg, dvid_model** out) {
     dvid_model* m = new dvid_model();
     m->cfg = *cfg;
     if (const char* e = getenv("DVID_CHAINS")) m->nchain = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
+    if (const char* e = getenv("DVID_PIPE")) m->pipe_parts = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
+    if (const char* e = getenv("DVID_PIPE_SPLIT")) {
+        int st = 2, b = 0;
+        if (sscanf(e, "%d:%d", &st, &b) >= 1 && st >= 0 && st <= 3 && b >= 0) {
+            m->pipe_stage = st;
+            m->pipe_block = b;
+        }
+    }
     *out = m;
     return DVID_OK;
 }
@@ -578,6 +590,7 @@ int dvid_model_destroy(dvid_model* m) {
                       &m->f32d, &m->h16a, &m->h16b, &m->hid16, &m->ss, &m->deltas, &m->kvproj, &m->mem16, &m->splitk, &m->vt};
     for (DevBuf* b : bufs) b->release();
     for (auto& kv : m->ss_tables) kv.second.release();
+    for (hipEvent_t e : m->ev_mid) (void)hipEventDestroy(e);
     delete m;
     return DVID_OK;
 }
@@ -712,6 +725,16 @@ int dvid_set_chains(dvid_model* m, int nchain) {
     return DVID_OK;
 }
 
+int dvid_set_pipeline(dvid_model* m, int parts, int split_stage, int split_block) {
+    g_err[0] = 0;
+    if (!m || parts < 0 || parts > 64 || split_stage < 0 || split_stage > 3 || split_block < 0)
+        FAIL(DVID_ERR_ARG, "parts 0..64, split stage 0..3 (res2..res5), block >= 0");
+    m->pipe_parts = parts;
+    m->pipe_stage = split_stage;
+    m->pipe_block = split_block;
+    return DVID_OK;
+}
+
 int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width, int boxes_per_frame) {
     g_err[0] = 0;
     if (!m || max_frames <= 0 || boxes_per_frame <= 0) FAIL(DVID_ERR_ARG, "bad argument");
@@ -788,18 +811,33 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
     // Frames are independent through the backbone.  They are processed as `nchain` sub-batches on separate HIP
     // streams: a layer of one sub-batch rarely fills 256 CUs evenly (e.g. res4: 304-608 tiles), and with two chains
     // in flight the blocks of one chain's next kernel start on the CUs the other chain's tail leaves idle.
-    const int nchain = (m->nchain > 1 && n >= 2 * m->nchain) ? m->nchain : 1;
+    //
+    // Software pipeline (pipe_parts = P > 1, takes precedence): the first layers (stem, res2, res3: short-K 1x1 convolutions
+    // on large maps) are bound by HBM traffic, the later ones (res4, res5, FPN: long-K 3x3 convolutions on small maps) by the
+    // MFMA / operand-staging rate.  The n frames are cut into P sub-batches; a FRONT stream runs the first part of every
+    // sub-batch back to back, a BACK stream the second part, sub-batch p's back part waiting for its front part by an
+    // event -- so the front of sub-batch p + 1 (memory system) runs beside the back of sub-batch p (matrix cores) on the
+    // same chip.  Same kernels, same per-frame arithmetic: results are bit-identical to the sequential schedule.
+    const bool piped = m->pipe_parts > 1 && n >= 2 * m->pipe_parts;
+    const int nchain = piped ? m->pipe_parts : ((m->nchain > 1 && n >= 2 * m->nchain) ? m->nchain : 1);
     if (nchain > 1) TRY(m->ensure_streams());
     const int per = (n + nchain - 1) / nchain;
     const size_t px = (size_t)height * width, px4 = px / 16;
+    if (piped) {
+        while ((int)m->ev_mid.size() < nchain) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->ev_mid.push_back(e);
+        }
+    }
     if (nchain > 1) {
         HIP_TRY(hipEventRecord(m->ev_fork, s));
-        for (int c = 0; c < nchain; ++c) HIP_TRY(hipStreamWaitEvent(m->cs[c], m->ev_fork, 0));
+        for (int c = 0; c < (piped ? 2 : nchain); ++c) HIP_TRY(hipStreamWaitEvent(m->cs[c], m->ev_fork, 0));
     }
     for (int c = 0; c < nchain; ++c) {
         const int f0 = c * per, nf = (f0 + per <= n) ? per : n - f0;
         if (nf <= 0) continue;
-        hipStream_t cs = nchain > 1 ? m->cs[c] : s;
+        hipStream_t cs = piped ? m->cs[0] : (nchain > 1 ? m->cs[c] : s);
         // this chain's slice of every workspace buffer starts at its first frame (f0 + nf <= n <= ws_frames for any
         // chain count, so no slice can run past the end)
         const size_t fo = (size_t)f0;
@@ -829,6 +867,11 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
             for (int b = 0; b < nb; ++b) {
                 const Block& blk = m->blocks[st][b];
                 int h2 = h, w2 = w;
+                if (piped && st == m->pipe_stage && b == (m->pipe_block < nb ? m->pipe_block : nb - 1)) {
+                    HIP_TRY(hipEventRecord(m->ev_mid[c], cs));           // front part of this sub-batch done
+                    cs = m->cs[1];
+                    HIP_TRY(hipStreamWaitEvent(cs, m->ev_mid[c], 0));
+                }
                 TRY(conv_run(blk.c1, cur, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs));
                 TRY(conv_run(blk.c2, t1, nf, h, w, t2, 1, 0, nullptr, 0, 0, cs, &h2, &w2));
                 const half_t* res = cur;
@@ -855,8 +898,14 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
             TRY(conv_run(m->lateral[l], stage_out[l + 1], nf, sh[l + 1], sw[l + 1], lat[l], 0, 0, res, res ? 2 : 0, 0, cs));
             TRY(conv_run(m->output[l], lat[l], nf, sh[l + 1], sw[l + 1], pout[l], 0, 0, nullptr, 0, 0, cs));
         }
-        if (nchain > 1) {
+        if (nchain > 1 && !piped) {
             HIP_TRY(hipEventRecord(m->ev_join[c], cs));
+            HIP_TRY(hipStreamWaitEvent(s, m->ev_join[c], 0));
+        }
+    }
+    if (piped) {
+        for (int c = 0; c < 2; ++c) {
+            HIP_TRY(hipEventRecord(m->ev_join[c], m->cs[c]));
             HIP_TRY(hipStreamWaitEvent(s, m->ev_join[c], 0));
         }
     }

@@ -272,6 +272,10 @@ class Model:
         """concurrent sub-batch chains inside the library (1 = sequential kernels, for per-kernel profiling)"""
         call("dvid_set_chains", self.handle, int(n))
 
+    def set_pipeline(self, parts, split_stage=2, split_block=0):
+        """ResNet backbone as a two-stream software pipeline over `parts` sub-batches (0 / 1: off); see dvid_set_pipeline"""
+        call("dvid_set_pipeline", self.handle, int(parts), int(split_stage), int(split_block))
+
     def reserve(self, max_frames, height, width, boxes_per_frame):
         """Workspace for up to max_frames frames of height x width with boxes_per_frame boxes; only ever grows."""
         key = (max_frames, height, width, boxes_per_frame)

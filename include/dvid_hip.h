@@ -87,6 +87,12 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
  * stream before returning) used by the backbone and the heads; 1 = strictly sequential kernels (profiling). */
 int dvid_set_chains(dvid_model* m, int nchain);
 
+/* Software pipeline of the ResNet backbone: `parts` sub-batches; the layers before block `split_block` of stage
+ * `split_stage` (0..3 = res2..res5) of every sub-batch run on a front stream, the rest on a back stream one sub-batch
+ * behind, so HBM-bound early layers overlap MFMA-bound late layers.  parts <= 1: off (dvid_set_chains applies).  Results
+ * do not depend on the schedule. */
+int dvid_set_pipeline(dvid_model* m, int parts, int split_stage, int split_block);
+
 /* ---- stages -------------------------------------------------------------------------------- */
 /* images: fp32 NCHW [n,3,height,width] in [0,1] (zero padded, un-normalised).  Outputs fp16 NHWC
  * p3 [n,h/8,w/8,256], p4 [n,h/16,w/16,256], p5 [n,h/32,w/32,256]. */

@@ -536,3 +536,24 @@ def test_resize_u8_matches_pillow(dv, hw, mn, mx):
     # a reference frame re-uses the current frame's size (transforms.py:63-65)
     other = rng.randint(0, 256, size=hw + (3,)).astype(np.uint8)
     assert tf(other, False).image_size == (oh, ow)
+
+
+def test_backbone_pipeline_schedule_bit_identical(dv):
+    """dvid_set_pipeline: the two-stream front/back software pipeline of the ResNet backbone (sub-batches, split point inside
+    res4 and at a stage boundary, ragged last sub-batch) must return exactly the sequential schedule's feature maps."""
+    from diffusionvid_amd.utils import synthetic
+    blocks = (1, 2, 3, 1)
+    sd = synthetic.make_state_dict(0, blocks=blocks)
+    g = torch.Generator().manual_seed(21)
+    imgs = torch.rand(11, 3, 96, 160, generator=g).cuda()
+    model = dv.Model(sd, res_blocks=blocks)
+    model.reserve(11, 96, 160, 300)
+    model.set_chains(1)
+    ref = [t.clone() for t in model.backbone(imgs)]
+    for parts, st, blk in ((2, 2, 0), (3, 2, 1), (4, 1, 0), (5, 3, 0), (2, 2, 7)):
+        model.set_pipeline(parts, st, blk)
+        got = model.backbone(imgs)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), (parts, st, blk)
+    model.set_pipeline(0)
+    model.close()
