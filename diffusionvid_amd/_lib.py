@@ -34,6 +34,7 @@ SIGNATURES = {
     "dvid_model_set_tensor": (c_int, [c_void_p, C.c_char_p, c_void_p, C.POINTER(c_int64), c_int]),
     "dvid_model_finalize": (c_int, [c_void_p]),
     "dvid_set_chains": (c_int, [c_void_p, c_int]),
+    "dvid_set_fusion": (c_int, [c_void_p, c_int]),
     "dvid_set_pipeline": (c_int, [c_void_p, c_int, c_int, c_int]),
     "dvid_workspace_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "dvid_backbone_resnet_fpn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "dvid_profile_reset": (c_int, []),
     "dvid_profile_dump": (c_int, [C.c_char_p]),
     "dvid_profile_read": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int64)]),
+    "dvid_profile_read_fused": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int64)]),
     "dvid_profile_read_bytes": (c_int, [C.POINTER(C.c_double)]),
 }
 

@@ -18,6 +18,22 @@ struct IgemmParams {
 };
 int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);   // igemm2.hip: per-shape tuned tile configuration
 
+// c3c1.hip: conv3 (+ residual + ReLU) of one bottleneck fused with conv1 (+ ReLU) of the next; w3f / w1f are the two weight
+// matrices in MFMA B-fragment order (pack_frag_order in model.hip)
+struct C3C1Params {
+    const half_t* a;      // [M][K1]   conv2 output of the block
+    const half_t* w3f;    // conv3 weights [N1][K1], fragment order
+    const float* b3;      // [N1]
+    const half_t* r;      // [M][N1]   residual (block input or shortcut output)
+    half_t* y;            // [M][N1]   block output
+    const half_t* w1f;    // next conv1 weights [N2][N1], fragment order
+    const float* b1;      // [N2]
+    half_t* z;            // [M][N2]   next block's conv1 output
+    long M;
+};
+bool dvid_c3c1_supported(int k1, int n1, int n2);
+int dvid_c3c1_launch(const C3C1Params& p, int k1, int n1, int n2, hipStream_t s);
+
 // elementwise.hip
 int dvid_prep_images_launch(const float* nchw, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
                             hipStream_t s);

@@ -43,6 +43,7 @@ struct ProfRec {
     hipEvent_t a, b;
     double flop, bytes;
     int M, N, K, taps, stride, res_mode;
+    int kind = 0;              // 0: igemm2 launch, 1: fused conv3 -> conv1 launch (c3c1.hip)
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -58,6 +59,7 @@ int igemm(const IgemmParams& p, hipStream_t s) {
         HIP_TRY(hipEventCreate(&r.a));
         HIP_TRY(hipEventCreate(&r.b));
     }
+    r.kind = 0;
     r.flop = 2.0 * p.M * (double)p.Cout * (double)p.alg_k;
     // algorithmic HBM bytes: every operand touched once (input pixels, packed weights, output, residual)
     const double in_px = (double)p.M * (p.ntaps > 1 ? p.stride * p.stride : 1);
@@ -72,6 +74,33 @@ int igemm(const IgemmParams& p, hipStream_t s) {
     r.res_mode = p.res_mode;
     HIP_TRY(hipEventRecord(r.a, s));
     const int rc = dvid_igemm_launch(p, s);
+    HIP_TRY(hipEventRecord(r.b, s));
+    g_prof.push_back(r);
+    return rc;
+}
+
+int c3c1(const C3C1Params& q, int k1, int n1, int n2, hipStream_t s) {
+    if (!g_prof_on) return dvid_c3c1_launch(q, k1, n1, n2, s);
+    ProfRec r;
+    if (!g_prof_pool.empty()) {
+        r = g_prof_pool.back();
+        g_prof_pool.pop_back();
+    } else {
+        HIP_TRY(hipEventCreate(&r.a));
+        HIP_TRY(hipEventCreate(&r.b));
+    }
+    r.kind = 1;
+    r.flop = 2.0 * q.M * ((double)k1 * n1 + (double)n1 * n2);
+    // algorithmic HBM bytes: A + residual + Y + Z + both weight matrices, each once (Y is not re-read: that is the point)
+    r.bytes = (double)q.M * (k1 + 2.0 * n1 + n2) * 2.0 + ((double)k1 * n1 + (double)n1 * n2) * 2.0;
+    r.M = (int)q.M;
+    r.N = n1;
+    r.K = k1;
+    r.taps = 1;
+    r.stride = n2;
+    r.res_mode = 1;
+    HIP_TRY(hipEventRecord(r.a, s));
+    const int rc = dvid_c3c1_launch(q, k1, n1, n2, s);
     HIP_TRY(hipEventRecord(r.b, s));
     g_prof.push_back(r);
     return rc;
@@ -114,6 +143,7 @@ struct ConvW {   // conv or linear weights in MFMA-operand layout
     float* bias = nullptr;
     int cin = 0, cout = 0, kh = 1, kw = 1, stride = 1, pad = 0, kpad = 0;
     int cin_real = 0;  // un-padded input channels (algorithmic FLOP count)
+    half_t* wfrag = nullptr;   // 1x1 layers of the bottlenecks: the same matrix in MFMA B-fragment order (csrc/c3c1.hip)
 };
 struct LNW {
     float* g = nullptr;
@@ -182,6 +212,7 @@ struct dvid_model {
     std::map<std::pair<int, std::vector<int64_t>>, DevBuf> ss_tables;   // (head slot, t vector) -> device scale/shift table
     std::map<std::pair<int, int64_t>, std::vector<float>> ss_rows;     // (head slot, t) -> host row [bt_out]
 
+    bool fuse_c3c1 = true;   // conv3 (+ residual) of a bottleneck fused with the next bottleneck's conv1 (DVID_FUSE_C3C1=0: off)
     int mem_lk = 0;       // rows of the global memory whose K/V projections sit in kvproj (0: none)
 
     // sub-batch chains (see dvid_backbone_resnet_fpn)
@@ -278,6 +309,21 @@ int make_conv_bn(dvid_model* m, const std::string& name, int stride, int pad, in
         bb[o] = b->v[o] - mu->v[o] * s[o];
     }
     return make_conv(m, *w, s, bb, stride, pad, cin_pad, nullptr, out);
+}
+
+// [cout][kpad] (K contiguous) -> MFMA B-fragment order for v_mfma_f32_32x32x16_f16: block (n-tile of 32 rows, k-step of 16) is
+// 64 lanes x 8 halves, lane l = row (l & 31), k = 8 * (l >> 5) .. + 8 -- one contiguous 1-KiB wave load per fragment.
+int pack_frag_order(dvid_model* m, ConvW* w) {
+    if (w->kh != 1 || w->kw != 1 || w->cout % 32 || w->kpad % 16 || w->kpad != w->cin) return DVID_OK;
+    std::vector<half_t> src((size_t)w->cout * w->kpad), dst(src.size());
+    HIP_TRY(hipMemcpy(src.data(), w->w, src.size() * sizeof(half_t), hipMemcpyDeviceToHost));
+    const int ks_n = w->kpad / 16;
+    for (int nt = 0; nt < w->cout / 32; ++nt)
+        for (int ks = 0; ks < ks_n; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e)
+                    dst[(((size_t)nt * ks_n + ks) * 64 + l) * 8 + e] = src[(size_t)(nt * 32 + (l & 31)) * w->kpad + ks * 16 + (l >> 5) * 8 + e];
+    return m->upload(dst.data(), dst.size() * sizeof(half_t), reinterpret_cast<void**>(&w->wfrag));
 }
 
 int make_linear(dvid_model* m, const std::string& name, bool has_bias, ConvW* out, const std::vector<int>* perm = nullptr,
@@ -570,6 +616,7 @@ int dvid_model_create(const dvid_config* cfg, dvid_model** out) {
     dvid_model* m = new dvid_model();
     m->cfg = *cfg;
     if (const char* e = getenv("DVID_CHAINS")) m->nchain = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
+    if (const char* e = getenv("DVID_FUSE_C3C1")) m->fuse_c3c1 = atoi(e) != 0;
     if (const char* e = getenv("DVID_PIPE")) m->pipe_parts = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
     if (const char* e = getenv("DVID_PIPE_SPLIT")) {
         int st = 2, b = 0;
@@ -626,6 +673,8 @@ int dvid_model_finalize(dvid_model* m) {
                 TRY(make_conv_bn(m, p + ".conv3", 1, 0, 0, &blk.c3));
                 blk.has_sc = (b == 0);
                 if (blk.has_sc) TRY(make_conv_bn(m, p + ".shortcut", stride, 0, 0, &blk.sc));
+                TRY(pack_frag_order(m, &blk.c1));
+                TRY(pack_frag_order(m, &blk.c3));
             }
         }
     }
@@ -722,6 +771,13 @@ int dvid_set_chains(dvid_model* m, int nchain) {
     g_err[0] = 0;
     if (!m || nchain < 1 || nchain > 4) FAIL(DVID_ERR_ARG, "nchain must be 1..4");
     m->nchain = nchain;
+    return DVID_OK;
+}
+
+int dvid_set_fusion(dvid_model* m, int conv3_conv1) {
+    g_err[0] = 0;
+    if (!m) FAIL(DVID_ERR_ARG, "null model");
+    m->fuse_c3c1 = conv3_conv1 != 0;
     return DVID_OK;
 }
 
@@ -862,6 +918,7 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
         w = (w + 2 - 3) / 2 + 1;
         half_t* cur = bx;  // block input
         int sh[4], sw[4];
+        bool c1_done = false;   // this block's conv1 output already sits in t1 (written by the previous block's fused launch)
         for (int st = 0; st < 4; ++st) {
             const int nb = (int)m->blocks[st].size();
             for (int b = 0; b < nb; ++b) {
@@ -872,7 +929,7 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
                     cs = m->cs[1];
                     HIP_TRY(hipStreamWaitEvent(cs, m->ev_mid[c], 0));
                 }
-                TRY(conv_run(blk.c1, cur, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs));
+                if (!c1_done) TRY(conv_run(blk.c1, cur, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs));
                 TRY(conv_run(blk.c2, t1, nf, h, w, t2, 1, 0, nullptr, 0, 0, cs, &h2, &w2));
                 const half_t* res = cur;
                 if (blk.has_sc) {
@@ -881,7 +938,29 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
                 }
                 // res3..res5 outputs persist for the FPN; everything else ping-pongs between bufX/bufY
                 half_t* dst = (b == nb - 1 && stage_out[st]) ? stage_out[st] : (cur == bx ? by : bx);
-                TRY(conv_run(blk.c3, t2, nf, h2, w2, dst, 1, 0, res, 1, 0, cs));
+                // the block that consumes this one's output: its conv1 is a 1x1 / stride-1 layer on exactly the rows written
+                // here, so it rides in the same launch (csrc/c3c1.hip) -- unless a pipeline hand-over sits between the two
+                const Block* nxt = (b + 1 < nb) ? &m->blocks[st][b + 1] : ((st < 3 && !m->blocks[st + 1].empty()) ? &m->blocks[st + 1][0] : nullptr);
+                const bool handover = piped && nxt && ((b + 1 < nb) ? (st == m->pipe_stage && b + 1 == (m->pipe_block < nb ? m->pipe_block : nb - 1))
+                                                                     : (st + 1 == m->pipe_stage && m->pipe_block == 0));
+                const bool fuse = m->fuse_c3c1 && nxt && !handover && blk.c3.wfrag && nxt->c1.wfrag && nxt->c1.cin == blk.c3.cout &&
+                                  dvid_c3c1_supported(blk.c3.cin, blk.c3.cout, nxt->c1.cout);
+                if (fuse) {
+                    C3C1Params q;
+                    q.a = t2;
+                    q.w3f = blk.c3.wfrag;
+                    q.b3 = blk.c3.bias;
+                    q.r = res;
+                    q.y = dst;
+                    q.w1f = nxt->c1.wfrag;
+                    q.b1 = nxt->c1.bias;
+                    q.z = t1;
+                    q.M = (long)nf * h2 * w2;
+                    TRY(c3c1(q, blk.c3.cin, blk.c3.cout, nxt->c1.cout, cs));
+                } else {
+                    TRY(conv_run(blk.c3, t2, nf, h2, w2, dst, 1, 0, res, 1, 0, cs));
+                }
+                c1_done = fuse;
                 h = h2;
                 w = w2;
                 cur = dst;
@@ -1254,25 +1333,40 @@ int dvid_profile_reset(void) {
 int dvid_profile_read_bytes(double* igemm_alg_bytes) {
     g_err[0] = 0;
     double b = 0;
-    for (auto& r : g_prof) b += r.bytes;
+    for (auto& r : g_prof)
+        if (r.kind == 0) b += r.bytes;
     if (igemm_alg_bytes) *igemm_alg_bytes = b;
     return DVID_OK;
 }
 
-int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches) {
-    g_err[0] = 0;
-    double ms = 0, fl = 0;
+static int profile_sum(int kind, double* ms_out, double* flop_out, double* bytes_out, int64_t* n_out) {
+    double ms = 0, fl = 0, by = 0;
+    int64_t n = 0;
     for (auto& r : g_prof) {
+        if (r.kind != kind) continue;
         HIP_TRY(hipEventSynchronize(r.b));
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
         ms += t;
         fl += r.flop;
+        by += r.bytes;
+        ++n;
     }
-    if (igemm_ms) *igemm_ms = ms;
-    if (igemm_flop) *igemm_flop = fl;
-    if (igemm_launches) *igemm_launches = (int64_t)g_prof.size();
+    if (ms_out) *ms_out = ms;
+    if (flop_out) *flop_out = fl;
+    if (bytes_out) *bytes_out = by;
+    if (n_out) *n_out = n;
     return DVID_OK;
+}
+
+int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches) {
+    g_err[0] = 0;
+    return profile_sum(0, igemm_ms, igemm_flop, nullptr, igemm_launches);
+}
+
+int dvid_profile_read_fused(double* ms, double* flop, double* alg_bytes, int64_t* launches) {
+    g_err[0] = 0;
+    return profile_sum(1, ms, flop, alg_bytes, launches);
 }
 
 // one CSV line per recorded igemm launch: M,N,K,taps,stride,res_mode,ms,tflops
@@ -1280,12 +1374,12 @@ int dvid_profile_dump(const char* path) {
     g_err[0] = 0;
     FILE* f = fopen(path, "w");
     if (!f) FAIL(DVID_ERR_ARG, "cannot open %s", path);
-    fprintf(f, "M,N,K,taps,stride,res_mode,ms,tflops\n");
+    fprintf(f, "M,N,K,taps,stride,res_mode,ms,tflops,kind\n");
     for (auto& r : g_prof) {
         HIP_TRY(hipEventSynchronize(r.b));
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
-        fprintf(f, "%d,%d,%d,%d,%d,%d,%.5f,%.2f\n", r.M, r.N, r.K, r.taps, r.stride, r.res_mode, t, r.flop / (t * 1e-3) / 1e12);
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%.5f,%.2f,%d\n", r.M, r.N, r.K, r.taps, r.stride, r.res_mode, t, r.flop / (t * 1e-3) / 1e12, r.kind);
     }
     fclose(f);
     return DVID_OK;

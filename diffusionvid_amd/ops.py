@@ -272,6 +272,10 @@ class Model:
         """concurrent sub-batch chains inside the library (1 = sequential kernels, for per-kernel profiling)"""
         call("dvid_set_chains", self.handle, int(n))
 
+    def set_fusion(self, conv3_conv1=True):
+        """ResNet backbone: conv3 (+ residual) -> next conv1 in one launch (csrc/c3c1.hip); same results either way"""
+        call("dvid_set_fusion", self.handle, int(bool(conv3_conv1)))
+
     def set_pipeline(self, parts, split_stage=2, split_block=0):
         """ResNet backbone as a two-stream software pipeline over `parts` sub-batches (0 / 1: off); see dvid_set_pipeline"""
         call("dvid_set_pipeline", self.handle, int(parts), int(split_stage), int(split_block))

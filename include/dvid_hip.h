@@ -87,6 +87,11 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
  * stream before returning) used by the backbone and the heads; 1 = strictly sequential kernels (profiling). */
 int dvid_set_chains(dvid_model* m, int nchain);
 
+/* ResNet backbone: fuse every bottleneck's conv3 (+ residual + ReLU) with the next bottleneck's conv1 (+ ReLU) into one
+ * launch that keeps the block output's fp16 tile in LDS as the second product's operand (csrc/c3c1.hip); on by default,
+ * results are bit-identical either way. */
+int dvid_set_fusion(dvid_model* m, int conv3_conv1);
+
 /* Software pipeline of the ResNet backbone: `parts` sub-batches; the layers before block `split_block` of stage
  * `split_stage` (0..3 = res2..res5) of every sub-batch run on a front stream, the rest on a back stream one sub-batch
  * behind, so HBM-bound early layers overlap MFMA-bound late layers.  parts <= 1: off (dvid_set_chains applies).  Results
@@ -184,6 +189,8 @@ int dvid_igemm_set_config(int cfg);
 int dvid_profile_enable(int on);
 int dvid_profile_reset(void);
 int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches);
+/* the fused conv3 -> conv1 launches of the same pass (not included in the igemm figures above) */
+int dvid_profile_read_fused(double* ms, double* flop, double* alg_bytes, int64_t* launches);
 /* sum over the recorded launches of the algorithmic HBM bytes (input + weights + output + residual, each touched once) */
 int dvid_profile_read_bytes(double* igemm_alg_bytes);
 /* CSV (M,N,K,taps,stride,res_mode,ms,tflops), one line per recorded igemm launch */

@@ -557,3 +557,30 @@ def test_backbone_pipeline_schedule_bit_identical(dv):
         assert all(torch.equal(a, b) for a, b in zip(got, ref)), (parts, st, blk)
     model.set_pipeline(0)
     model.close()
+
+
+@pytest.mark.parametrize("blocks,hw,n", [((2, 2, 3, 2), (96, 160), 3), ((3, 4, 5, 3), (64, 96), 5)])
+def test_backbone_conv3_conv1_fusion_bit_identical(dv, blocks, hw, n):
+    """csrc/c3c1.hip: conv3 (+ residual + ReLU) fused with the next bottleneck's conv1 must reproduce the two separate
+    igemm launches bit for bit (same K order, same single fp16 rounding) -- checked on the feature maps of a backbone whose
+    every fusable pair is present (inside res2 / res3 / res4, across the res2->res3 and res3->res4 boundaries, block 0 with
+    its shortcut as the residual), with a row count that is not a multiple of the 64-row tile."""
+    from diffusionvid_amd.utils import synthetic
+    sd = synthetic.make_state_dict(0, blocks=blocks)
+    g = torch.Generator().manual_seed(31)
+    imgs = torch.rand(n, 3, hw[0], hw[1], generator=g).cuda()
+    model = dv.Model(sd, res_blocks=blocks)
+    model.reserve(n, hw[0], hw[1], 300)
+    model.set_chains(1)
+    model.set_fusion(False)
+    ref = [t.clone() for t in model.backbone(imgs)]
+    model.set_fusion(True)
+    got = model.backbone(imgs)
+    torch.cuda.synchronize()
+    for name, a, b in zip(("p3", "p4", "p5"), got, ref):
+        assert torch.equal(a, b), f"{name}: {(a.float() - b.float()).abs().max().item():.3e} max abs difference"
+    model.set_chains(2)
+    got2 = model.backbone(imgs)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got2, ref))
+    model.close()
