@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256, 2) void c3c1_kernel(C3C1Params p) {
     constexpr int NC = Cfg::NC, NCH = Cfg::NCH, TN1 = Cfg::TN1, TM2 = Cfg::TM2, TN2 = Cfg::TN2;
     constexpr int AP = Cfg::A_PITCH, YP = Cfg::Y_PITCH;
     constexpr int KS1 = K1 / 16, KS2 = NC / 16;
-    constexpr int PF = (N2 >= 256) ? 2 : 4;              // prefetch depth of the weight fragments (register budget: 256 / lane)
-    static_assert(NC % 128 == 0 && N1 % NC == 0 && K1 % 16 == 0 && N2 % 64 == 0, "shape");
+    constexpr int PF = 4;              // prefetch depth of the weight fragments (register budget: 256 / lane)
+    static_assert(NC % 128 == 0 && N1 % NC == 0 && K1 % 64 == 0 && N2 % 64 == 0, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* As = reinterpret_cast<half_t*>(smem);
     half_t* Ys = As + BM * AP;
@@ -78,8 +78,13 @@ __global__ __launch_bounds__(256, 2) void c3c1_kernel(C3C1Params p) {
             for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
     __syncthreads();
 
-    const half8* w3f = reinterpret_cast<const half8*>(p.w3f);
-    const half8* w1f = reinterpret_cast<const half8*>(p.w1f);
+    const half8* __restrict__ w3f = reinterpret_cast<const half8*>(p.w3f);
+    const half8* __restrict__ w1f = reinterpret_cast<const half8*>(p.w1f);
+    const half_t* __restrict__ rg = p.r;
+    half_t* __restrict__ yg = p.y;
+    half_t* __restrict__ zg = p.z;
+    const float* __restrict__ b3g = p.b3;
+    const int rows_here = (p.M - m0) < BM ? (int)(p.M - m0) : BM;       // valid rows of this tile (>= 1)
 
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
@@ -99,45 +104,72 @@ __global__ __launch_bounds__(256, 2) void c3c1_kernel(C3C1Params p) {
             for (int d = 0; d < D; ++d)
 #pragma unroll
                 for (int j = 0; j < TN1; ++j) bq[d][j] = w3f[((long)(nt1 + j) * KS1 + d) * 64 + lane];
+#pragma unroll 1
+            for (int kg = 0; kg < KS1; kg += D) {         // rolled: bounds the scheduler's look-ahead (registers) and the code size
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                half8 fa[2], fb[TN1];
+                for (int d = 0; d < D; ++d) {
+                    const int ks = kg + d;
+                    half8 fa[2], fb[TN1];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const half8*>(As + (i * 32 + l31) * AP + ks * 16 + lhi * 8);
+                    for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const half8*>(As + (i * 32 + l31) * AP + ks * 16 + lhi * 8);
 #pragma unroll
-                for (int j = 0; j < TN1; ++j) fb[j] = bq[ks % D][j];
-                if (ks + D < KS1) {
+                    for (int j = 0; j < TN1; ++j) fb[j] = bq[d][j];
+                    if (ks + D < KS1) {
 #pragma unroll
-                    for (int j = 0; j < TN1; ++j) bq[ks % D][j] = w3f[((long)(nt1 + j) * KS1 + ks + D) * 64 + lane];
+                        for (int j = 0; j < TN1; ++j) bq[d][j] = w3f[((long)(nt1 + j) * KS1 + ks + D) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN1; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc1[i][j], 0, 0, 0);
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN1; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc1[i][j], 0, 0, 0);
             }
         }
         if (c > 0) __syncthreads();                       // every wave is done reading the previous chunk from Ys
         // ---- epilogue 1: + bias + residual, one fp16 rounding, ReLU; -> Y (global) and Ys (LDS) ----
+        // The 16 residual loads of a 32 x 32 tile are issued before its first store (the loads are independent; behind a
+        // store the compiler would have to assume aliasing and serialise them, one HBM latency each).  Addresses are a
+        // wave-uniform base + a 32-bit lane offset, so they cost one VGPR each instead of a 64-bit pair.
+        const half_t* rbase = p.r + m0 * N1 + c * NC;
+        half_t* ybase = p.y + m0 * N1 + c * NC;
 #pragma unroll
         for (int j = 0; j < TN1; ++j) {
             const int coln = wave * (TN1 * 32) + j * 32 + l31;       // column inside the chunk
-            const int n = c * NC + coln;
-            const float bias = p.b3[n];
+            const float bias = b3g[c * NC + coln];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                // lane offsets are re-derived per tile from a value the optimiser cannot see through: otherwise it hoists all
+                // 128 element offsets of the epilogue out of the chunk loop and spills the accumulators to make room
+                unsigned lane_off = (unsigned)((i * 32 + 4 * lhi) * N1 + coln);
+                int row0 = i * 32 + 4 * lhi;
+                asm volatile("" : "+v"(lane_off), "+v"(row0));
+                half_t rv[16];
+                bool ok[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const long m = m0 + row;
-                    half_t y = (half_t)0.f;
-                    if (m < p.M) {
-                        const float v = (acc1[i][j][r] + bias) + (float)p.r[m * N1 + n];
-                        y = (half_t)v;
-                        y = y > (half_t)0.f ? y : (half_t)0.f;
-                        p.y[m * N1 + n] = y;
-                    }
-                    Ys[row * YP + coln] = y;
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    ok[r] = row0 + dr < rows_here;
+#ifdef T_NOLOAD
+                    rv[r] = (half_t)0.f;
+#else
+                    rv[r] = ok[r] ? rbase[lane_off + (unsigned)(dr * N1)] : (half_t)0.f;
+#endif
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    const float v = (acc1[i][j][r] + bias) + (float)rv[r];
+                    half_t y = (half_t)v;
+                    y = y > (half_t)0.f ? y : (half_t)0.f;
+#ifndef T_NOSTORE
+                    if (ok[r]) ybase[lane_off + (unsigned)(dr * N1)] = y;
+#endif
+                    Ys[(i * 32 + 4 * lhi + dr) * YP + coln] = y;
+                }
+                __builtin_amdgcn_sched_barrier(0);       // keep the next tile's loads from being hoisted over this one (registers)
+            }
         }
         // first weight fragments of the second product: in flight across the barrier
         constexpr int D2 = KS2 < PF ? KS2 : PF;
@@ -148,24 +180,29 @@ __global__ __launch_bounds__(256, 2) void c3c1_kernel(C3C1Params p) {
             for (int j = 0; j < TN2; ++j) bq2[d][j] = w1f[((long)(nt2_0 + j) * (N1 / 16) + c * KS2 + d) * 64 + lane];
         __syncthreads();
         // ================= second product: K slice = this chunk =================
+#pragma unroll 1
+        for (int kg = 0; kg < KS2; kg += D2) {
 #pragma unroll
-        for (int ks = 0; ks < KS2; ++ks) {
-            half8 fa[TM2], fb[TN2];
+            for (int d = 0; d < D2; ++d) {
+                const int ks = kg + d;
+                half8 fa[TM2], fb[TN2];
 #pragma unroll
-            for (int i = 0; i < TM2; ++i) fa[i] = *reinterpret_cast<const half8*>(Ys + ((mt2_0 + i) * 32 + l31) * YP + ks * 16 + lhi * 8);
+                for (int i = 0; i < TM2; ++i) fa[i] = *reinterpret_cast<const half8*>(Ys + ((mt2_0 + i) * 32 + l31) * YP + ks * 16 + lhi * 8);
 #pragma unroll
-            for (int j = 0; j < TN2; ++j) fb[j] = bq2[ks % D2][j];
-            if (ks + D2 < KS2) {
+                for (int j = 0; j < TN2; ++j) fb[j] = bq2[d][j];
+                if (ks + D2 < KS2) {
 #pragma unroll
-                for (int j = 0; j < TN2; ++j) bq2[ks % D2][j] = w1f[((long)(nt2_0 + j) * (N1 / 16) + c * KS2 + ks + D2) * 64 + lane];
+                    for (int j = 0; j < TN2; ++j) bq2[d][j] = w1f[((long)(nt2_0 + j) * (N1 / 16) + c * KS2 + ks + D2) * 64 + lane];
+                }
+#pragma unroll
+                for (int i = 0; i < TM2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc2[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < TM2; ++i)
-#pragma unroll
-                for (int j = 0; j < TN2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc2[i][j], 0, 0, 0);
         }
     }
     // ---- epilogue 2: + bias, fp16, ReLU -> Z ----
+    half_t* __restrict__ zbase = zg + m0 * N2;
 #pragma unroll
     for (int j = 0; j < TN2; ++j) {
         const int n = (nt2_0 + j) * 32 + l31;
@@ -174,10 +211,10 @@ __global__ __launch_bounds__(256, 2) void c3c1_kernel(C3C1Params p) {
         for (int i = 0; i < TM2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long m = m0 + (mt2_0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < p.M) {
+                const int row = (mt2_0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row < rows_here) {
                     half_t z = (half_t)(acc2[i][j][r] + bias);
-                    p.z[m * N2 + n] = z > (half_t)0.f ? z : (half_t)0.f;
+                    zbase[(unsigned)(row * N2 + n)] = z > (half_t)0.f ? z : (half_t)0.f;
                 }
             }
     }
