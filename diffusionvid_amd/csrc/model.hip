@@ -212,7 +212,11 @@ struct dvid_model {
     std::map<std::pair<int, std::vector<int64_t>>, DevBuf> ss_tables;   // (head slot, t vector) -> device scale/shift table
     std::map<std::pair<int, int64_t>, std::vector<float>> ss_rows;     // (head slot, t) -> host row [bt_out]
 
-    bool fuse_c3c1 = true;   // conv3 (+ residual) of a bottleneck fused with the next bottleneck's conv1 (DVID_FUSE_C3C1=0: off)
+    // conv3 (+ residual) of a bottleneck fused with the next bottleneck's conv1 (csrc/c3c1.hip).  Bit-identical, and OFF by
+    // default: measured at 104 frames it is a wash (38.9 vs 38.1 ms per backbone pass, profiles/r02_c3c1_fusion.txt) -- the
+    // fused launch saves the re-read of the block output but fetches the weights once per 128 rows instead of once per
+    // 256, and its phases are barrier-locked inside one workgroup per CU.  DVID_FUSE_C3C1=1 / dvid_set_fusion turn it on.
+    bool fuse_c3c1 = false;
     int mem_lk = 0;       // rows of the global memory whose K/V projections sit in kvproj (0: none)
 
     // sub-batch chains (see dvid_backbone_resnet_fpn)

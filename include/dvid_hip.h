@@ -88,8 +88,8 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
 int dvid_set_chains(dvid_model* m, int nchain);
 
 /* ResNet backbone: fuse every bottleneck's conv3 (+ residual + ReLU) with the next bottleneck's conv1 (+ ReLU) into one
- * launch that keeps the block output's fp16 tile in LDS as the second product's operand (csrc/c3c1.hip); on by default,
- * results are bit-identical either way. */
+ * launch that keeps the block output's fp16 tile in LDS as the second product's operand (csrc/c3c1.hip).  Results are
+ * bit-identical either way; off by default (measured no faster than the two tuned launches, profiles/r02_c3c1_fusion.txt). */
 int dvid_set_fusion(dvid_model* m, int conv3_conv1);
 
 /* Software pipeline of the ResNet backbone: `parts` sub-batches; the layers before block `split_block` of stage
