@@ -50,7 +50,7 @@ from diffusionvid_amd.engine import inference as engine  # noqa: E402
 from diffusionvid_amd.modeling.detector import build_detection_model  # noqa: E402
 from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
-TRAFFIC_FILE = "r01h_pmc_igemm_traffic.json"
+TRAFFIC_FILE = "r02_pmc_igemm_traffic.json"
 PEAK_FP16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 # algorithmic work per output frame: backbone + heads + global attention, faithful pass counts

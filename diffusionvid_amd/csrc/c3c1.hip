@@ -89,8 +89,6 @@ __global__ __launch_bounds__(64 * NW * MH, 4) void c3c1_kernel(C3C1Params p) {
 
     const half8* __restrict__ w3f = reinterpret_cast<const half8*>(p.w3f);
     const half8* __restrict__ w1f = reinterpret_cast<const half8*>(p.w1f);
-    const half_t* __restrict__ rg = p.r;
-    half_t* __restrict__ yg = p.y;
     half_t* __restrict__ zg = p.z;
     const float* __restrict__ b3g = p.b3;
     const int rows_here = (p.M - m0) < BM ? (int)(p.M - m0) : BM;       // valid rows of this tile (>= 1)

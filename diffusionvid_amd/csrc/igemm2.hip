@@ -611,16 +611,30 @@ void tune_cache_append(const ShapeKey& k, int cfg, int n) {
     }
 }
 
+// Tuning scratch: the timing launches write to a buffer that only ever grows (no hipMalloc / hipFree per shape); it is
+// needed because a layer may accumulate in place (Swin's residual stream: out == res), where repeating the launch on the
+// real output would add twice.
+void* g_tune_scratch = nullptr;
+size_t g_tune_scratch_bytes = 0;
+
 int tune_shape(const IgemmParams& p, hipStream_t s, const TileCfg* cfgs, int ncfg, int fallback, int* best_out) {
     const size_t out_bytes = (size_t)p.M * p.ldc * (p.out_f32 ? 4 : 2) * (p.splitk > 1 ? p.splitk : 1);
-    void* scratch = nullptr;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMalloc(&scratch, out_bytes));
-    hipEvent_t a, b;
-    HIP_TRY(hipEventCreate(&a));
-    HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipStreamSynchronize(s));           // a quiet stream for the timings; other streams keep running
+    if (out_bytes > g_tune_scratch_bytes) {
+        if (g_tune_scratch) HIP_TRY(hipFree(g_tune_scratch));
+        g_tune_scratch = nullptr;
+        g_tune_scratch_bytes = 0;
+        const size_t want = out_bytes + out_bytes / 4;
+        HIP_TRY(hipMalloc(&g_tune_scratch, want));
+        g_tune_scratch_bytes = want;
+    }
+    static hipEvent_t a = nullptr, b = nullptr;
+    if (!a) {
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+    }
     IgemmParams q = p;
-    q.out = scratch;
+    q.out = g_tune_scratch;
     static const bool log = getenv("DVID_IGEMM_TUNE_LOG") != nullptr;
     int best = fallback;
     float best_ms = 1e30f;
@@ -644,15 +658,23 @@ int tune_shape(const IgemmParams& p, hipStream_t s, const TileCfg* cfgs, int ncf
             best = c;
         }
     }
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    HIP_TRY(hipFree(scratch));
     if (log)
         fprintf(stderr, "[igemm tune] M %d N %d K %d -> %dx%dx%d/%d (%.2f us, %.0f TFLOP/s)\n", p.M, p.Cout, p.Kpad, cfgs[best].bm,
                 cfgs[best].bn, cfgs[best].bkt, cfgs[best].nstage, best_ms * 1e3f, 2.0 * p.M * p.Cout * (double)p.alg_k / best_ms / 1e9);
     *best_out = best;
     return DVID_OK;
 }
+
+// Row counts are bucketed for the tuner's key (8 steps per octave above 1024 rows, multiples of 64 below): a stream of
+// videos ends in ragged groups, so exact M values keep appearing for ever, while the best tile only depends on how many
+// tiles the launch has to the nearest ~10 %.
+int bucket_rows(int M) {
+    if (M <= 1024) return (M + 63) / 64 * 64;
+    const int sh = 31 - __builtin_clz((unsigned)M) - 3;
+    return ((M + (1 << sh) - 1) >> sh) << sh;
+}
+
+int g_tune_mode = -1;            // -1: follow DVID_IGEMM_TUNE (default on); 0: never time on the serving path; 1: time new shape buckets
 
 }  // namespace
 
@@ -661,6 +683,12 @@ int dvid_igemm_num_configs(void) { return kNumCfg; }
 int dvid_igemm_set_config(int cfg) {
     if (cfg < -1 || cfg >= kNumCfg) return DVID_ERR_ARG;
     g_forced_cfg = cfg;
+    return DVID_OK;
+}
+
+int dvid_igemm_set_tuning(int mode) {
+    if (mode < -1 || mode > 1) return DVID_ERR_ARG;
+    g_tune_mode = mode;
     return DVID_OK;
 }
 
@@ -677,12 +705,13 @@ int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
     // valid for (parity tests compare configurations bit for bit; experiments)
     static const int cfg_env0 = getenv("DVID_IGEMM_CFG") ? atoi(getenv("DVID_IGEMM_CFG")) : -1;
     const int cfg_env = g_forced_cfg >= -1 ? g_forced_cfg : cfg_env0;
-    static const bool tune = !(getenv("DVID_IGEMM_TUNE") && atoi(getenv("DVID_IGEMM_TUNE")) == 0);
+    static const bool tune_env = !(getenv("DVID_IGEMM_TUNE") && atoi(getenv("DVID_IGEMM_TUNE")) == 0);
+    const bool tune = g_tune_mode < 0 ? tune_env : true;         // mode 0 still uses cached / preloaded winners
     int fallback = smallc ? (p.Kpad >= 512 ? 1 : 0) : heuristic_cfg(p);
     if (!cfg_valid(cfgs[fallback], p)) fallback = smallc ? 0 : (p.Kpad >= 512 ? 3 : 0);
     if (cfg_env >= 0 && cfg_env < ncfg && cfg_valid(cfgs[cfg_env], p)) return cfgs[cfg_env].launch(p, s);
     if (!tune) return cfgs[fallback].launch(p, s);
-    const ShapeKey key{p.M, p.Cout, p.Kpad, p.Cin, p.ntaps, p.stride, p.res_mode,
+    const ShapeKey key{bucket_rows(p.M), p.Cout, p.Kpad, p.Cin, p.ntaps, p.stride, p.res_mode,
                        (p.out_f32 ? 1 : 0) | (p.res_f32 ? 2 : 0) | (smallc ? 4 : 0) | (p.splitk << 4) | (p.relu << 12)};
     int cfg = -1;
     {
@@ -695,6 +724,8 @@ int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
         auto it = g_tuned.find(key);
         if (it != g_tuned.end()) {
             cfg = it->second;
+        } else if (g_tune_mode == 0) {
+            cfg = fallback;                     // serving mode: no timing launches; the hand rule for unseen buckets
         } else {
             const int rc = tune_shape(p, s, cfgs, ncfg, fallback, &cfg);
             if (rc != DVID_OK) return rc;
@@ -702,5 +733,6 @@ int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
             tune_cache_append(key, cfg, ncfg);
         }
     }
+    if (!cfg_valid(cfgs[cfg], p)) cfg = fallback;      // a bucket's winner may not fit its smallest member
     return cfgs[cfg].launch(p, s);
 }

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -46,19 +47,30 @@ struct ProfRec {
     int kind = 0;              // 0: igemm2 launch, 1: fused conv3 -> conv1 launch (c3c1.hip)
 };
 bool g_prof_on = false;
+std::mutex g_prof_mu;                 // models on different host threads may launch concurrently
 std::vector<ProfRec> g_prof;
 std::vector<ProfRec> g_prof_pool;
+
+int prof_take(ProfRec* r) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (!g_prof_pool.empty()) {
+        *r = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return DVID_OK;
+    }
+    HIP_TRY(hipEventCreate(&r->a));
+    HIP_TRY(hipEventCreate(&r->b));
+    return DVID_OK;
+}
+void prof_push(const ProfRec& r) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_prof.push_back(r);
+}
 
 int igemm(const IgemmParams& p, hipStream_t s) {
     if (!g_prof_on) return dvid_igemm_launch(p, s);
     ProfRec r;
-    if (!g_prof_pool.empty()) {
-        r = g_prof_pool.back();
-        g_prof_pool.pop_back();
-    } else {
-        HIP_TRY(hipEventCreate(&r.a));
-        HIP_TRY(hipEventCreate(&r.b));
-    }
+    if (prof_take(&r) != DVID_OK) return DVID_ERR_HIP;
     r.kind = 0;
     r.flop = 2.0 * p.M * (double)p.Cout * (double)p.alg_k;
     // algorithmic HBM bytes: every operand touched once (input pixels, packed weights, output, residual)
@@ -75,20 +87,14 @@ int igemm(const IgemmParams& p, hipStream_t s) {
     HIP_TRY(hipEventRecord(r.a, s));
     const int rc = dvid_igemm_launch(p, s);
     HIP_TRY(hipEventRecord(r.b, s));
-    g_prof.push_back(r);
+    prof_push(r);
     return rc;
 }
 
 int c3c1(const C3C1Params& q, int k1, int n1, int n2, hipStream_t s) {
     if (!g_prof_on) return dvid_c3c1_launch(q, k1, n1, n2, s);
     ProfRec r;
-    if (!g_prof_pool.empty()) {
-        r = g_prof_pool.back();
-        g_prof_pool.pop_back();
-    } else {
-        HIP_TRY(hipEventCreate(&r.a));
-        HIP_TRY(hipEventCreate(&r.b));
-    }
+    if (prof_take(&r) != DVID_OK) return DVID_ERR_HIP;
     r.kind = 1;
     r.flop = 2.0 * q.M * ((double)k1 * n1 + (double)n1 * n2);
     // algorithmic HBM bytes: A + residual + Y + Z + both weight matrices, each once (Y is not re-read: that is the point)
@@ -102,7 +108,7 @@ int c3c1(const C3C1Params& q, int k1, int n1, int n2, hipStream_t s) {
     HIP_TRY(hipEventRecord(r.a, s));
     const int rc = dvid_c3c1_launch(q, k1, n1, n2, s);
     HIP_TRY(hipEventRecord(r.b, s));
-    g_prof.push_back(r);
+    prof_push(r);
     return rc;
 }
 
@@ -1330,6 +1336,7 @@ int dvid_profile_enable(int on) {
     return DVID_OK;
 }
 int dvid_profile_reset(void) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof) g_prof_pool.push_back(r);
     g_prof.clear();
     return DVID_OK;

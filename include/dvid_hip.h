@@ -183,6 +183,11 @@ int dvid_resize_u8_to_f32(const void* src_hwc, int h, int w, void* tmp, float* o
  * dvid_igemm_set_config(k) forces table entry k wherever it is valid (k = -1: back to the tuner). */
 int dvid_igemm_num_configs(void);
 int dvid_igemm_set_config(int cfg);
+/* Per-shape tile tuning: 1 = the first launch of a new (row bucket, N, K, ...) key times every valid configuration on the
+ * launch's own stream (stream sync + ~80 launches once per key; keys bucket the row count 8 steps per octave, so ragged
+ * video tails do not create new ones); 0 = never time on the calling path: cached winners (DVID_IGEMM_TUNE_CACHE, earlier
+ * launches) or the hand rule; -1 = follow the environment (DVID_IGEMM_TUNE, default on). */
+int dvid_igemm_set_tuning(int mode);
 
 /* When enabled, every igemm launch is bracketed by HIP events on its stream; dvid_profile_read
  * synchronises those events and returns totals since the last reset. */

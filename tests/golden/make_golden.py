@@ -271,6 +271,41 @@ def g11_vid_eval():
     save("g11_vid_eval", nframes=np.array(12), ap=res[0]["ap"], map=np.array(res[0]["map"]), **flat)
 
 
+def g15_vid_eval_motion():
+    """Motion-specific AP (vid_eval.py:39-50, :164-299): calc_detection_vid_prec_rec + calc_detection_vid_ap per motion range
+    on a toy set whose ground-truth boxes carry motion IoUs (the real values live in the data set's .mat file)."""
+    from mega_core.data.datasets.evaluation.vid import vid_eval as VE
+    g = torch.Generator().manual_seed(150)
+    preds, gts, motion, flat = [], [], [], {}
+    for f in range(16):
+        ng = int(torch.randint(0, 4, (1,), generator=g))
+        gb = torch.rand(ng, 2, generator=g) * 300
+        gwh = torch.rand(ng, 2, generator=g) * 120 + 20
+        gt = BoxList(torch.cat([gb, gb + gwh], 1).round(), (500, 400))
+        gt.add_field("labels", torch.randint(1, 4, (ng,), generator=g))
+        motion.append([float(x) for x in torch.rand(ng, generator=g)])
+        npred = int(torch.randint(0, 7, (1,), generator=g))
+        pb = torch.rand(npred, 2, generator=g) * 300
+        pwh = torch.rand(npred, 2, generator=g) * 120 + 20
+        boxes = torch.cat([pb, pb + pwh], 1)
+        for k in range(min(ng, npred)):            # some detections sit on ground truth (jittered)
+            boxes[k] = gt.bbox[k] + torch.randn(4, generator=g) * 4
+        pr = BoxList(boxes, (500, 400))
+        pr.add_field("labels", torch.cat([gt.get_field("labels")[:min(ng, npred)], torch.randint(1, 5, (npred - min(ng, npred),), generator=g)]))
+        pr.add_field("scores", torch.rand(npred, generator=g))
+        preds.append(pr)
+        gts.append(gt)
+        flat.update({f"gt_boxes{f}": gt.bbox, f"gt_labels{f}": gt.get_field("labels"), f"motion{f}": np.array(motion[-1]),
+                     f"pr_boxes{f}": pr.bbox, f"pr_labels{f}": pr.get_field("labels"), f"pr_scores{f}": pr.get_field("scores")})
+    ranges = [[0.0, 1.0], [0.0, 0.7], [0.7, 0.9], [0.9, 1.0]]
+    for i, rng in enumerate(ranges):
+        prec, rec = VE.calc_detection_vid_prec_rec(gt_boxlists=gts, pred_boxlists=preds, motion_ious=motion, iou_thresh=0.5, motion_range=rng)
+        ap = VE.calc_detection_vid_ap(prec, rec, use_07_metric=False)
+        flat[f"ap{i}"] = np.asarray(ap, dtype=np.float64)
+        flat[f"map{i}"] = np.array(np.nanmean(ap))
+    save("g15_vid_eval_motion", n_frames=np.array(16), ranges=np.array(ranges), **flat)
+
+
 def g12_nms_known_answers():
     """The known-answer vectors of the reference's own NMS tests (tests/test_nms.py:11-58 `test_nms_cpu`, :60-230
     `test_nms1_cpu`, themselves caffe2's UtilsNMSTest vectors), captured as data by running those two test methods with
@@ -424,4 +459,5 @@ if __name__ == "__main__":
     g10_sampler()
     g12_nms_known_answers()
     g13_checkpoint_matching()
+    g15_vid_eval_motion()
     g14_vid_dataset_protocol()

@@ -411,3 +411,46 @@ def test_resize_matches_pillow_and_reference_size_rule():
         np.testing.assert_array_equal(T.resize_u8_numpy(img, (oh, ow)), ref)
         t = T.ResizeToTensor(mn, mx)(img, True)
         assert t.shape == (3, oh, ow) and torch.equal(t, torch.from_numpy(ref.copy()).permute(2, 0, 1).float().div(255))
+
+
+def test_motion_specific_ap_matches_reference_golden(tmp_path):
+    """Motion-specific AP50 (all / fast / medium / slow; vid_eval.py:39-50, :164-299) against the reference's
+    calc_detection_vid_prec_rec + calc_detection_vid_ap on the same toy set (golden g15), and tools/test_prediction.py on a
+    predictions.pth + ground-truth file written from it."""
+    import subprocess
+    import sys
+    from diffusionvid_amd.data.evaluation import vid_eval
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    z = golden("g15_vid_eval_motion")
+    preds, gts, motion = [], [], []
+    for f in range(int(z["n_frames"])):
+        gt = BoxList(torch.from_numpy(z[f"gt_boxes{f}"]).reshape(-1, 4), (500, 400))
+        gt.add_field("labels", torch.from_numpy(z[f"gt_labels{f}"]))
+        pr = BoxList(torch.from_numpy(z[f"pr_boxes{f}"]).reshape(-1, 4), (500, 400))
+        pr.add_field("labels", torch.from_numpy(z[f"pr_labels{f}"]))
+        pr.add_field("scores", torch.from_numpy(z[f"pr_scores{f}"]))
+        preds.append(pr)
+        gts.append(gt)
+        motion.append([float(x) for x in z[f"motion{f}"]])
+    res = vid_eval.eval_detection_vid(preds, gts, motion_ious=motion)
+    assert len(res) == 4
+    for i, r in enumerate(res):
+        np.testing.assert_allclose(r["ap"], z[f"ap{i}"], rtol=0, atol=1e-12, equal_nan=True)
+        assert abs(r["map"] - float(z[f"map{i}"])) < 1e-12
+    assert len({round(r["map"], 6) for r in res}) > 1                       # the ranges really differ on this set
+    # the all-motion range equals the plain evaluator
+    plain = vid_eval.eval_detection_vid(preds, gts)
+    np.testing.assert_allclose(res[0]["ap"], plain["ap"], rtol=0, atol=1e-12, equal_nan=True)
+    # tools/test_prediction.py: predictions.pth + ground truth + motion file -> result.txt
+    folder = tmp_path / "inference" / "VID_val_videos"
+    folder.mkdir(parents=True)
+    vid_eval.save_predictions(preds, str(folder / "predictions.pth"))
+    torch.save({"gt": gts, "motion_ious": motion}, str(tmp_path / "gt.pth"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "test_prediction.py"), "--prediction-folder", str(tmp_path),
+                          "--dataset", "VID_val_videos", "--ground-truth", str(tmp_path / "gt.pth"), "--motion-specific"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]
+    text = (folder / "result.txt").read_text()
+    assert "AP50 | motion=   all = %.4f" % res[0]["map"] in text and "AP50 | motion=  slow = %.4f" % res[3]["map"] in text
+    assert "Category AP:" in text

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export DVID_CHAINS=1            # sequential launches: per-kernel durations are not inflated by overlap
-CMD="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-fed --no-side-configs"
 # tile-tuner timing launches would pollute the statistics: fill the tuning cache in an unprofiled run first
 export DVID_IGEMM_TUNE_CACHE=/tmp/dvid_tune_cache.txt
 rm -f $DVID_IGEMM_TUNE_CACHE
@@ -25,7 +25,7 @@ f = glob.glob("/tmp/prof_stats/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(f"{out}/{tag}_kernel_stats.txt", "w") as o:
-    o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline  (DVID_CHAINS=1; 5 videos of 304 frames:\n")
+    o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-fed --no-side-configs  (DVID_CHAINS=1; 5 videos of 304 frames:\n")
     o.write("# set-up, warm-up, timed step, chains=1 pass and instrumented pass)\n")
     o.write("total kernel time %.1f ms\n" % (tot / 1e6))
     ig = [r for r in rows if "igemm2_kernel" in r["Name"]]
@@ -65,8 +65,8 @@ if res["FETCH_SIZE"][1] and res["WRITE_SIZE"][1]:
                "mfma_busy_method": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs over sum(GRBM_GUI_ACTIVE) / 8 XCDs, igemm2 launches only",
                "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 "
-                         "--warmup 0 --no-cpu-baseline (the bench workload itself, 304-frame videos), DVID_CHAINS=1; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md "
-                         "(gfx950 counts 128-B requests at 64 B); WRITE_SIZE uncorrected", "round": 1},
+                         "--warmup 0 --no-cpu-baseline --no-host-fed --no-side-configs (the bench workload itself, 304-frame videos), DVID_CHAINS=1; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                         "(gfx950 counts 128-B requests at 64 B); WRITE_SIZE uncorrected", "round": int(tag[1:3]) if tag[1:3].isdigit() else None},
               open(f"{out}/{tag}_pmc_igemm_traffic.json", "w"), indent=1)
 else:
     open(f"{out}/{tag}_pmc_error.txt", "w").write(repr(res) + "\n" + open("/tmp/prof_FETCH_SIZE.log").read()[-3000:])
