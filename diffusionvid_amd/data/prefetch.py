@@ -33,12 +33,18 @@ class HostFedVideo:
         return len(self.ds)
 
     def pin(self):
-        """materialise every frame of the host dataset in pinned memory (outside any timed region: this stands for the
-        DataLoader workers' output queue)"""
-        for idx in range(len(self.ds)):
-            v, f = self.ds.video_of[idx], self.ds.frame_seg_id[idx]
-            if (v, f) not in self._host:
-                self._host[(v, f)] = self.ds.frame(v, f).tensors.pin_memory()
+        """materialise every video of the host dataset as ONE pinned tensor [frames, 3, H, W] (outside any timed region: this
+        stands for the DataLoader workers' collated output queue); a group's window is then a single contiguous copy"""
+        for v, first in enumerate(self.ds.start_index):
+            n = self.ds.frame_seg_len[first]
+            if v in self._host:
+                continue
+            sample = self.ds.frame(v, 0).tensors
+            buf = torch.empty((n,) + tuple(sample.shape[1:]), dtype=sample.dtype).pin_memory()
+            for f in range(n):
+                buf[f].copy_(self.ds.frame(v, f).tensors[0])
+            self._host[v] = buf
+            self.ds._cache.clear()                   # the pageable copies are not needed any more
         return self
 
     def reset(self):
@@ -59,16 +65,25 @@ class HostFedVideo:
         frames = self._window(v, g)
         if not frames:
             return
-        sample = self._host[(v, frames[0])]
-        if self._buf[slot] is None or self._buf[slot].shape[1:] != sample.shape[1:] or self._buf[slot].shape[0] < self.span:
-            self._buf[slot] = torch.empty((self.span,) + tuple(sample.shape[1:]), dtype=sample.dtype, device=self.device)
+        host = self._host[v]
+        if self._buf[slot] is None or self._buf[slot].shape[1:] != host.shape[1:] or self._buf[slot].shape[0] < self.span:
+            self._buf[slot] = torch.empty((self.span,) + tuple(host.shape[1:]), dtype=host.dtype, device=self.device)
         cur = torch.cuda.current_stream(self.device)
         self.copy_stream.wait_stream(cur)            # kernels queued so far may still read this buffer (two groups back)
         with torch.cuda.stream(self.copy_stream):
-            for j, f in enumerate(frames):
-                src = self._host[(v, f)]
-                self._buf[slot][j:j + 1].copy_(src, non_blocking=True)
+            # runs of consecutive frames -> one async copy each (a window is one run; group 0 of a short video may add the
+            # global frames as a second one)
+            j = 0
+            a = 0
+            while a < len(frames):
+                b = a
+                while b + 1 < len(frames) and frames[b + 1] == frames[b] + 1:
+                    b += 1
+                src = host[frames[a]:frames[b] + 1]
+                self._buf[slot][j:j + (b - a + 1)].copy_(src, non_blocking=True)
                 self.h2d_bytes += src.numel() * src.element_size()
+                j += b - a + 1
+                a = b + 1
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self._ready[slot] = ((v, g), ev, {f: j for j, f in enumerate(frames)})

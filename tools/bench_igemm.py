@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--only", type=str, default="", help="substring filter on layer names")
+    ap.add_argument("--vendor", action="store_true",
+                    help="also time torch.matmul (hipBLASLt / rocBLAS) on the same [M,K] x [N,K]^T fp16 problem for every 1x1 stride-1 "
+                         "layer -- the vendor library as a yardstick (plain GEMM: no bias / residual / ReLU epilogue, so it does less)")
     args = ap.parse_args()
     dev = "cuda"
     tot_ms = tot_fl = 0.0
@@ -91,7 +94,14 @@ def main():
         mult = int(name.split(" x")[1]) if " x" in name else 1
         tot_ms += ms * mult
         tot_fl += fl * mult
-        print(f"{name:28s} {M:8d} {cout:6d} {k*k*cin:6d} {ms:8.4f} {fl/ms/1e9:8.1f} {by/ms/1e6:8.0f} {by/1e6:8.1f}")
+        extra = ""
+        if args.vendor and k == 1 and stride == 1:
+            a2 = x.view(-1, cin)
+            w2 = (torch.randn(cout, cin, device=dev) * 0.05).half()
+            o2 = torch.empty(a2.shape[0], cout, dtype=torch.float16, device=dev)
+            vms = timeit(lambda: torch.matmul(a2, w2.t(), out=o2), args.iters)
+            extra = f"   vendor GEMM {vms:8.4f} ms {fl/vms/1e9:8.1f} TFLOP/s  (igemm2 / vendor time {ms/vms:5.2f})"
+        print(f"{name:28s} {M:8d} {cout:6d} {k*k*cin:6d} {ms:8.4f} {fl/ms/1e9:8.1f} {by/ms/1e6:8.0f} {by/1e6:8.1f}{extra}")
     if tot_ms:
         print(f"backbone total (weighted): {tot_ms:.3f} ms per {args.batch} frames, {tot_fl/tot_ms/1e9:.1f} TFLOP/s")
     rows = args.batch * 300
@@ -106,7 +116,13 @@ def main():
         ms = timeit(lambda: ops.linear(x, wp, kpad, bias, out_f32=f32), args.iters)
         fl = 2.0 * m * k * nout
         by = x.numel() * 2 + wp.numel() * 2 + m * nout * (4 if f32 else 2)
-        print(f"{'head.'+name:28s} {m:8d} {nout:6d} {k:6d} {ms:8.4f} {fl/ms/1e9:8.1f} {by/ms/1e6:8.0f} {by/1e6:8.1f}")
+        extra = ""
+        if args.vendor:
+            w2 = (torch.randn(nout, k, device=dev) * 0.05).half()
+            o2 = torch.empty(m, nout, dtype=torch.float16, device=dev)
+            vms = timeit(lambda: torch.matmul(x, w2.t(), out=o2), args.iters)
+            extra = f"   vendor GEMM {vms:8.4f} ms {fl/vms/1e9:8.1f} TFLOP/s  (igemm2 / vendor time {ms/vms:5.2f})"
+        print(f"{'head.'+name:28s} {m:8d} {nout:6d} {k:6d} {ms:8.4f} {fl/ms/1e9:8.1f} {by/ms/1e6:8.0f} {by/1e6:8.1f}{extra}")
 
 
 if __name__ == "__main__":
