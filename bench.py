@@ -58,9 +58,10 @@ ALG_GFLOP_PER_FRAME = {("r101", 1): 249.3, ("r101", 4): 385.0, ("swinb", 1): 459
 
 
 def run_video(model, ds, device):
+    """the reference's per-item loop (mega_core/engine/inference.py:22-94); the dataset emits the reference's unchanged item
+    dict, the look-ahead hand-over is built by the engine from the items it reads ahead (engine.lookahead_items)"""
     results = {}
-    for idx in range(len(ds)):
-        images, _, ids = ds[idx]
+    for idx, (images, _, ids) in engine.lookahead_items(ds, range(len(ds)), model.infer_batch, model.lookahead):
         out = model(images)
         if out:
             results.update({i: o for i, o in zip(ids, out)})
@@ -257,7 +258,7 @@ def main():
         torch.cuda.empty_cache()
 
     cfg, model = build(args.arch, args.sample_step, args.lookahead)
-    ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank)
+    ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
     ds.preload()
     with torch.no_grad():
         # set-up, outside the step accounting: weight repack / upload and the per-shape tile tuner (it times every
@@ -270,7 +271,7 @@ def main():
     host_fed = None
     if not args.no_host_fed:
         from diffusionvid_amd.data.prefetch import HostFedVideo
-        hds = SyntheticVIDDataset([L], cfg, height=H, width=W, device="cpu", video_base=rank)
+        hds = SyntheticVIDDataset([L], cfg, height=H, width=W, device="cpu", video_base=rank, emit_ref_ahead=False)
         # cyclic: the pass after the last group is the same video again, as in a stream of videos -- its first group is
         # staged under the previous pass's last group; every pass still copies every frame
         hf = HostFedVideo(hds, device, cfg.INPUT.INFER_BATCH * args.lookahead, cyclic=True).pin()
@@ -352,10 +353,8 @@ def main():
     def side(name, arch, sample_step, lookahead, steps):
         try:
             c2, m2 = build(arch, sample_step, lookahead)
-            d2 = ds if arch == args.arch else SyntheticVIDDataset([L], c2, height=H, width=W, device=device, video_base=rank)
-            if lookahead != args.lookahead or arch != args.arch:
-                d2 = SyntheticVIDDataset([L], c2, height=H, width=W, device=device, video_base=rank)
-                d2._cache = ds._cache              # same frames, already resident
+            d2 = SyntheticVIDDataset([L], c2, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
+            d2._cache = ds._cache                  # same frames, already resident
             with torch.no_grad():
                 run_video(m2, d2, device)
             t2, f2 = timed(m2, d2, steps, 1)
@@ -382,9 +381,10 @@ def main():
                                    % ("ResNet-101" if args.arch == "r101" else "Swin-Base", args.sample_step, args.sample_step, L, L,
                                       -(-L // infer_batch), infer_batch),
                        "frames_per_step_per_gpu": L, "infer_batch": infer_batch, "lookahead_batches": args.lookahead,
-                       "lookahead_note": "INPUT.LOOKAHEAD_BATCHES > 1 is an extension of the caller protocol (the dataset hands the next "
-                                         "batches' frames over early); the reference's unchanged protocol is the "
-                                         "reference_protocol_lookahead_1 entry of other_configs",
+                       "lookahead_note": "the dataset emits the reference's unchanged item dict (vid_mega.py:236-248); the engine loop reads the "
+                                         "group's later items ahead and hands their frames to the detector with the group's first call "
+                                         "(engine.lookahead_items).  other_configs.reference_protocol_lookahead_1 is the same loop without "
+                                         "reading ahead",
                        "parallelism": "videos sharded across ranks (one process per GPU, %s)"
                                       % ("RCCL group of %d ranks: one gather of the predictions to rank 0" % dist.get_world_size()
                                          if world > 1 else "single rank, no collective"),

@@ -16,7 +16,8 @@ from ..utils import synthetic
 
 
 class SyntheticVIDDataset:
-    def __init__(self, video_lengths, cfg, height=600, width=1000, device="cpu", shuffle_seed=None, video_base=0, smooth=False):
+    def __init__(self, video_lengths, cfg, height=600, width=1000, device="cpu", shuffle_seed=None, video_base=0, smooth=False,
+                 emit_ref_ahead=True):
         mega = cfg.MODEL.VID.MEGA
         self.max_offset = mega.MAX_OFFSET
         self.all_frame_interval = mega.ALL_FRAME_INTERVAL
@@ -30,6 +31,7 @@ class SyntheticVIDDataset:
         self.height, self.width, self.device = height, width, torch.device(device)
         self.video_base = video_base
         self.smooth = smooth
+        self.emit_ref_ahead = emit_ref_ahead      # False: the reference's unchanged item dict (the engine builds the look-ahead)
         self.frame_seg_len, self.frame_seg_id, self.video_of = [], [], []
         self.start_index, self.start_id, self.shuffled_index = [], [], {}
         rng = np.random.RandomState(shuffle_seed) if shuffle_seed is not None else None
@@ -99,7 +101,7 @@ class SyntheticVIDDataset:
             "seg_len": seg_len,
             "last_queue_id": ref_id_final,
         }
-        if self.lookahead > 1 and frame_id % (self.infer_batch * self.lookahead) == 0:
+        if self.emit_ref_ahead and self.lookahead > 1 and frame_id % (self.infer_batch * self.lookahead) == 0:
             # INPUT.LOOKAHEAD_BATCHES extension: the 8 frame slots each of the next batches will be built from, i.e.
             # exactly what calls fb-7 .. fb will deliver through `ref_l` (last frame repeated past the end of the video)
             images["ref_ahead"] = {

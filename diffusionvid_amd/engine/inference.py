@@ -17,12 +17,63 @@ from ..structures.bounding_box import BoxList
 from ..utils import comm
 
 
+def lookahead_items(dataset, indices, infer_batch, lookahead):
+    """The look-ahead hand-over built by the ENGINE from an unchanged dataset: yields `dataset[idx]` for idx in `indices`, in
+    order, each item loaded exactly once; on the first call of every look-ahead group (frame_id a multiple of infer_batch *
+    lookahead) the items of the group's later calls are read ahead and their `ref_l` frames -- exactly what those calls
+    would deliver -- are attached as `ref_ahead = {batch start frame: [frames]}` (INPUT.LOOKAHEAD_BATCHES of the MI355X
+    schedule).  The reference's own VIDMEGADataset (vid_mega.py:164-250) therefore needs no change: the detector still
+    receives every call with its usual keys and returns the later batches' results from the group's first call's work.
+    Items that already carry `ref_ahead` (datasets that emit it themselves) pass through untouched."""
+    indices = list(indices)
+    unit = infer_batch * lookahead
+    cache = {}
+    pos_of = {idx: k for k, idx in enumerate(indices)}
+
+    def get(idx):
+        if idx not in cache:
+            cache[idx] = dataset[idx]
+        return cache[idx]
+
+    for idx in indices:
+        item = get(idx)
+        images = item[0]
+        if lookahead > 1 and "ref_ahead" not in images and images["frame_id"] % unit == 0:
+            f0, end = images["frame_id"], images["end_id"]
+            ahead = {}
+            k = pos_of[idx]
+            # batches of this group after the first: fb = f0 + infer_batch, ... ; batch fb is fed by the calls fb - infer_batch + 1 .. fb
+            for fb in range(f0 + infer_batch, min(f0 + unit, end + 1), infer_batch):
+                frames = []
+                for f in range(fb - infer_batch + 1, fb + 1):
+                    j = k + (f - f0)
+                    if j >= len(indices):
+                        frames = None
+                        break
+                    nxt = get(indices[j])[0]
+                    if nxt["frame_id"] != f or nxt["frame_category"] == 0:
+                        frames = None             # not the same video / not consecutive: leave this batch to its own call
+                        break
+                    frames += list(nxt["ref_l"])
+                if frames is None or len(frames) != infer_batch:
+                    break
+                ahead[fb] = frames
+            images = dict(images)
+            images["ref_ahead"] = ahead
+            item = (images,) + tuple(item[1:])
+        cache.pop(idx, None)
+        yield idx, item
+
+
 def compute_on_dataset(model, dataset, indices, device, timer=None):
+    """mega_core/engine/inference.py:22-94.  With INPUT.LOOKAHEAD_BATCHES > 1 on the model the hand-over is built here
+    (`lookahead_items`), so any dataset that follows the reference's item protocol gets the grouped schedule."""
     model.eval()
     results = {}
     cpu = torch.device("cpu")
-    for idx in indices:
-        images, _, image_ids = dataset[idx]
+    la = int(getattr(model, "lookahead", 1) or 1)
+    for idx, item in lookahead_items(dataset, indices, getattr(model, "infer_batch", 1), la):
+        images, _, image_ids = item
         with torch.no_grad():
             t0 = time.perf_counter()
             output = model(images)

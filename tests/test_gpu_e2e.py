@@ -686,3 +686,31 @@ def test_real_dataset_front_end_device_transform_equals_host_transform(tmp_path)
     for i in a:
         assert torch.equal(a[i].bbox, b[i].bbox) and torch.equal(a[i].get_field("scores"), b[i].get_field("scores"))
     assert sum(len(x) for x in a.values()) > 0
+
+
+def test_engine_built_lookahead_equals_reference_schedule():
+    """The dataset emits the reference's unchanged item dict; engine.compute_on_dataset reads ahead and hands the group's later
+    frames over itself (engine.lookahead_items).  Detections must equal the plain one-batch-per-call schedule (look-ahead 1)
+    -- two videos back to back, ragged tails."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.engine import inference as eng
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    outs = {}
+    for la in (1, 4):
+        cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["INPUT.LOOKAHEAD_BATCHES", la], "configs/BASE_RCNN_1gpu.yaml")
+        cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+        cfg.freeze()
+        model = build_detection_model(cfg)
+        model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+        model = model.to("cuda").eval()
+        model.noise_fn = synthetic.noise_fn
+        ds = SyntheticVIDDataset([20, 44], cfg, height=120, width=200, device="cuda", smooth=True, emit_ref_ahead=False)
+        assert "ref_ahead" not in ds[0][0]
+        outs[la] = eng.compute_on_dataset(model, ds, range(len(ds)), torch.device("cuda"))
+        assert sorted(outs[la]) == list(range(64))
+    for i in range(64):
+        a, b = outs[1][i], outs[4][i]
+        assert len(a) == len(b) and torch.equal(a.get_field("labels"), b.get_field("labels"))
+        assert torch.allclose(a.bbox, b.bbox, atol=1e-4, rtol=0) and torch.allclose(a.get_field("scores"), b.get_field("scores"), atol=1e-5, rtol=0)

@@ -454,3 +454,53 @@ def test_motion_specific_ap_matches_reference_golden(tmp_path):
     text = (folder / "result.txt").read_text()
     assert "AP50 | motion=   all = %.4f" % res[0]["map"] in text and "AP50 | motion=  slow = %.4f" % res[3]["map"] in text
     assert "Category AP:" in text
+
+
+def test_engine_builds_lookahead_from_unchanged_dataset(tmp_path):
+    """engine.lookahead_items: from a dataset that emits the reference's unchanged item dict the engine loop builds the same
+    `ref_ahead` hand-over the look-ahead-aware datasets emit themselves -- same batches, same frames in the same order --
+    for the synthetic driver (frame objects compared by identity) and for the real dataset class on image files (frames
+    identified by their pixels), across video boundaries and ragged tails; every item is loaded exactly once."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.datasets import VIDMEGATestDataset
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.engine import inference as eng
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.VID.MEGA.GLOBAL.SHUFFLE", False, "INPUT.LOOKAHEAD_BATCHES", 3],
+                  "configs/BASE_RCNN_1gpu.yaml")
+    lens = [37, 8, 50]
+    own = SyntheticVIDDataset(lens, cfg, height=16, width=16)
+    plain = SyntheticVIDDataset(lens, cfg, height=16, width=16, emit_ref_ahead=False)
+    plain._cache = own._cache
+    loads = []
+    real_get = plain.__class__.__getitem__
+
+    class Counting:
+        def __len__(self):
+            return len(plain)
+
+        def __getitem__(self, i):
+            loads.append(i)
+            return real_get(plain, i)
+    seen = 0
+    for idx, (images, _, ids) in eng.lookahead_items(Counting(), range(len(plain)), 8, 3):
+        want = own[idx][0]
+        assert ("ref_ahead" in images) == ("ref_ahead" in want)
+        if "ref_ahead" in want:
+            assert sorted(images["ref_ahead"]) == sorted(want["ref_ahead"])
+            for fb in want["ref_ahead"]:
+                assert all(a is b for a, b in zip(images["ref_ahead"][fb], want["ref_ahead"][fb])), (idx, fb)
+                assert len(images["ref_ahead"][fb]) == 8
+            seen += len(want["ref_ahead"])
+        assert images["frame_id"] == want["frame_id"] and ids == own[idx][2]
+    assert seen > 6 and sorted(loads) == list(range(len(plain)))            # each item loaded once
+    # the real dataset class on files
+    img_dir, index, _ = _tiny_vid_set(tmp_path, [37, 8])
+    ds_own = VIDMEGATestDataset(cfg, img_dir, index)
+    base = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.VID.MEGA.GLOBAL.SHUFFLE", False], "configs/BASE_RCNN_1gpu.yaml")
+    ds_plain = VIDMEGATestDataset(base, img_dir, index)
+    px = lambda im: (int(im[0, 0, 0]), int(im[0, 0, 1]))       # noqa: E731
+    for idx, (images, _, ids) in eng.lookahead_items(ds_plain, range(len(ds_plain)), 8, 3):
+        want = ds_own[idx][0]
+        got = {fb: [px(im) for im in fr] for fb, fr in images.get("ref_ahead", {}).items()}
+        exp = {fb: [px(im) for im in fr] for fb, fr in want.get("ref_ahead", {}).items()}
+        assert got == exp, idx
