@@ -60,7 +60,7 @@ if res["FETCH_SIZE"][1] and res["WRITE_SIZE"][1]:
     write = res["WRITE_SIZE"][0] / res["WRITE_SIZE"][1] * 1024
     same = json.loads([l for l in open("/tmp/prof_FETCH_SIZE.log") if l.startswith('{"metric"')][-1])["roofline"]
     json.dump({"kernel": "igemm2_kernel (all instantiations)", "launches": int(res["FETCH_SIZE"][1]),
-               "alg_bytes_per_launch_same_run": same["alg_mbytes_per_launch"] * 1e6,
+               "alg_bytes_per_launch_same_run": same["layerwise_alg_mbytes_per_launch"] * 1e6,
                "mfma_busy_fraction": mfma_busy,
                "mfma_busy_method": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs over sum(GRBM_GUI_ACTIVE) / 8 XCDs, igemm2 launches only",
                "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
