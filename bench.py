@@ -113,6 +113,57 @@ def cpu_baseline(cfg, sd, frames, height, width):
                       "%d threads (fastest of a 16..%d probe on one backbone pass)" % (warm, dt, torch.get_num_threads(), os.cpu_count())}
 
 
+def vidval(args, build, timed, barrier, device, rank, world, H, W):
+    """BASELINE.json configs[4]: the VID-val-shaped set (555 videos, 176126 frames, lengths 24..3262) sharded over the ranks
+    by frame-count-balanced whole videos, every rank running the reference's per-item loop over its videos,
+    one gather of the predictions to rank 0 inside the timed region.  Strong scaling: the set is fixed, N ranks split it."""
+    from diffusionvid_amd.data.samplers import balanced_video_partition, vid_val_shaped_lengths
+    from diffusionvid_amd.data.synthetic_video import PooledVIDDataset
+    lens = vid_val_shaped_lengths()
+    if args.videos > 0:
+        lens = lens[:args.videos]
+    mine = balanced_video_partition(lens, world)[rank]
+    cfg, model = build(args.arch, args.sample_step, args.lookahead)
+    ds = PooledVIDDataset([lens[v] for v in mine], cfg, pool=128, height=H, width=W, device=device, emit_ref_ahead=False)
+    for v in range(128):
+        ds.frame(0, v)
+    warm = PooledVIDDataset([min(lens), 304], cfg, pool=128, height=H, width=W, device=device, emit_ref_ahead=False)
+    warm._cache = ds._cache
+    with torch.no_grad():
+        run_video(model, warm, device)             # repack + tuner (row buckets make the ragged tails hit cached winners)
+    barrier()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        res = run_video(model, ds, device)
+    nfr = len(res)
+    merged = engine.gather_predictions({(rank << 32) + k: v.to("cpu") for k, v in res.items()}, device=device) if world > 1 else res
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    ff = torch.tensor([nfr], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        total = int(sum(lens))
+        assert int(ff.item()) == total and (world == 1 or len(merged) == total)
+        print(json.dumps({
+            "metric": "frames/sec (1000x600) DiffusionVID-%s x%d, VID-val-shaped set" % ("R101" if args.arch == "r101" else "SwinB", args.sample_step),
+            "value": round(total / float(tt.item()), 2), "unit": "frames/sec", "n_gpus": world, "steps": 1, "warmup": 0,
+            "ms_per_step": round(float(tt.item()) * 1e3, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "%d synthetic videos / %d frames shaped like ImageNet-VID val (lengths %d..%d), 1000x600, 300 boxes, "
+                                   "frame-count-balanced whole videos per rank; frames drawn from a pool of 128 resident frames"
+                                   % (len(lens), total, min(lens), max(lens)),
+                       "lookahead_batches": args.lookahead, "ranks": world,
+                       "frames_of_heaviest_rank_over_mean": round(max(sum(lens[v] for v in p) for p in balanced_video_partition(lens, world))
+                                                                  / (total / world), 5)}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N ...` -> N ranks of this same command line under torch.distributed.run (127.0.0.1
     rendezvous on a free port); returns the launcher's exit code."""
@@ -173,6 +224,11 @@ def main():
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned frames, H2D in the timed region) measurement")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the reference-protocol (look-ahead 1), x4 and Swin-B measurements reported inside the line")
+    ap.add_argument("--workload", choices=("video", "vidval"), default="video",
+                    help="video (default): one synthetic video per GPU per step, weak scaling (the BASELINE headline).  vidval: "
+                         "BASELINE.json configs[4] -- a 555-video / 176126-frame VID-val-shaped set (data/samplers.vid_val_shaped_lengths) "
+                         "sharded over the ranks by balanced_video_partition, strong scaling; one step = the whole set (or --videos K of it)")
+    ap.add_argument("--videos", type=int, default=0, help="vidval: use only the first K videos of the set (0 = all 555)")
     ap.add_argument("--dry", action="store_true",
                     help="launcher / collective check without a GPU: every rank fabricates its shard's predictions, the gather to "
                          "rank 0 runs over gloo, and the JSON line reports the ranks seen (tests/test_dist_gloo.py)")
@@ -257,6 +313,8 @@ def main():
             model._engine = None
         torch.cuda.empty_cache()
 
+    if args.workload == "vidval":
+        return vidval(args, build, timed, barrier, device, rank, world, H, W)
     cfg, model = build(args.arch, args.sample_step, args.lookahead)
     ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
     ds.preload()

@@ -108,3 +108,16 @@ class SyntheticVIDDataset:
                 fb: [self.frame(v, min(fb - self.infer_batch + 1 + i + self.max_offset, seg_len - 1)) for i in range(self.infer_batch)]
                 for fb in range(frame_id + self.infer_batch, min(frame_id + self.infer_batch * self.lookahead, seg_len), self.infer_batch)}
         return images, None, [idx + i for i in range(self.infer_batch)]
+
+
+class PooledVIDDataset(SyntheticVIDDataset):
+    """A VID-val-shaped synthetic set (hundreds of videos, 10^5 frames) does not fit in HBM as distinct fp32 frames (176126 x
+    7.5 MB = 1.3 TB): frame f of video v is drawn from a pool of `pool` distinct seeded frames.  Protocol, video lengths
+    and per-video state are those of the full set; only the pixel content repeats."""
+
+    def __init__(self, video_lengths, cfg, pool=128, **kw):
+        super().__init__(video_lengths, cfg, **kw)
+        self.pool = int(pool)
+
+    def frame(self, video, f):
+        return super().frame(0, (video * 31 + f) % self.pool)
