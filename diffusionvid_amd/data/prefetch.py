@@ -27,6 +27,8 @@ class HostFedVideo:
         self._ready = [None, None]          # (video, group) staged in each buffer, event of its last copy
         self._slot_of = {}
         self.h2d_bytes = 0
+        self._model = None
+        self._pending = None
         self.cyclic = cyclic            # after the last video the first one follows (a bench pass repeated back to back)
 
     def __len__(self):
@@ -97,10 +99,29 @@ class HostFedVideo:
         torch.cuda.current_stream(self.device).wait_event(self._ready[slot][1])
         self._slot_of = {v: (g, slot), "slot": slot}
         n = self.ds.frame_seg_len[self.ds.start_index[v]]
+        nxt = None
         if (g + 1) * self.unit < n:
-            self._stage(v, g + 1, slot ^ 1)          # runs ahead, under this group's kernels
+            nxt = (v, g + 1, slot ^ 1)               # runs ahead, under this group's kernels
         elif v + 1 < len(self.ds.start_index) or self.cyclic:
-            self._stage((v + 1) % len(self.ds.start_index), 0, slot ^ 1)          # next video's first group
+            nxt = ((v + 1) % len(self.ds.start_index), 0, slot ^ 1)          # next video's first group
+        if nxt is not None:
+            if self._model is not None:
+                self._pending = nxt                  # issued by the detector once this group's own uploads and first kernels are queued
+            else:
+                self._stage(*nxt)
+
+    def attach(self, model):
+        """Let the detector trigger the next group's copies right after it has queued its own small uploads (noise draws) and
+        its first kernels: a pageable upload issued AFTER a 1-GB prefetch waits for that whole transfer (same DMA queue) while the
+        host blocks on it, which serialises copy and compute (measured: 219 ms per video against 179 resident)."""
+        self._model = model
+        model.after_first_launch = self._kick
+        return self
+
+    def _kick(self):
+        if self._pending is not None:
+            nxt, self._pending = self._pending, None
+            self._stage(*nxt)
 
     def _frame(self, v, f):
         g, slot = self._slot_of[v]

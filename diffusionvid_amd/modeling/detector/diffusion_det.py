@@ -154,6 +154,7 @@ class DiffusionDet(nn.Module):
         self._sr_host = torch.sqrt(1.0 / alphas_cumprod)
         self._srm1_host = torch.sqrt(1.0 / alphas_cumprod - 1)
         self.noise_fn = None
+        self.after_first_launch = None      # optional callable, run once the first backbone launch of a call is queued
         self.debug_taps = None      # dict -> receives intermediates (parity tests)
         # True: a batch's detections come back with ONE device->host copy and the BoxLists hold CPU tensors
         # (what engine/inference.py does next anyway, there with ~3 copies per frame); False: GPU tensors
@@ -395,6 +396,8 @@ class DiffusionDet(nn.Module):
         for ci, a in enumerate(range(0, total.shape[0], cap)):
             chunk = total[a:a + cap].contiguous()
             feats = eng.backbone(chunk)
+            if ci == 0 and self.after_first_launch is not None:
+                self.after_first_launch()          # e.g. the data layer's prefetch of the next group: behind this call's own uploads
             B = chunk.shape[0]
             t = torch.full((B,), 999, dtype=torch.long)
             (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init_all[a:a + B], t, box_extract=ci + 1)
