@@ -11,6 +11,7 @@
 // physical 16-byte chunk = logical chunk ^ ((row >> 2) & 3), conflict-free for ds_read_b128.
 // Two LDS stages of (BM+BN)*64 B and a half-tile fp32 epilogue buffer keep a workgroup at <= 33 KB,
 // so 4 workgroups (16 waves) share a CU and hide the DMA latency of each other's K steps.
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -35,7 +36,7 @@ struct Smem2 {
     static constexpr int kStage = (BM + BN) * BKT * 2;
     static constexpr int kCPitch = BN + 4;
     static constexpr int kCHalf = (BM / 2) * kCPitch * 4;
-    static constexpr int kRing = NSTAGE == 5 ? 4 : NSTAGE;        // NSTAGE 5 = the anti-phase schedule over a 4-stage ring
+    static constexpr int kRing = (NSTAGE == 5 || NSTAGE == 7) ? 4 : (NSTAGE == 6 ? 2 : NSTAGE);        // NSTAGE 5 = the anti-phase schedule over a 4-stage ring; 6 = register-staged, 2 stages
     static constexpr int kBytes = (kRing * kStage > kCHalf) ? kRing * kStage : kCHalf;
 };
 
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     constexpr int KEY_SHIFT = (BKT == 64) ? 1 : 2;  // swizzle key = (row >> KEY_SHIFT) & (CHUNKS - 1)
     constexpr int TM = BM / 64, TN = BN / (32 * WN);   // 32x32 MFMA tiles per wave (waves 2 x WN)
     constexpr int A_IT = BM / RPP / NW, B_IT = BN / RPP / NW;   // DMA pieces per wave per K tile
-    static_assert(NSTAGE >= 2 && NSTAGE <= 5, "ring depth");
-    static_assert(NSTAGE != 5 || (WN == 4 && AK != 1), "the anti-phase schedule is written for 8 waves");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 7, "ring depth / schedule code");
+    static_assert((NSTAGE != 5 && NSTAGE != 7) || (WN == 4 && AK != 1), "the anti-phase schedule is written for 8 waves");
     static_assert(A_IT >= 1 && B_IT >= 1 && A_IT * RPP * NW == BM && B_IT * RPP * NW == BN, "tile / wave-count mismatch");
     constexpr int A_BYTES = BM * ROW_BYTES;
     constexpr int STAGE = Smem2<BM, BN, BKT, NSTAGE>::kStage;
@@ -179,10 +180,9 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) b_ptr[i] += (long)kt0 * b_step[i];
 
-    // one DMA piece of K tile `kt` into `stage`: pieces [0, A_IT) are A rows, [A_IT, A_IT + B_IT) are B rows
-    auto issue_piece = [&](int kt, int stage, int i) {
-        char* sa = smem + stage * STAGE;
-        char* sb = sa + A_BYTES;
+    // source address of piece i of the NEXT K tile to be fetched (pieces [0, A_IT) are A rows, [A_IT, A_IT + B_IT) are B rows);
+    // advances that piece's own walk state
+    auto piece_src = [&](int i) -> const char* {
         if (i < A_IT) {
             if (SMALLC) {                                        // Cin == 8: one tap per 16-byte chunk
                 // this lane's tap (a_ty, a_tx) walks the filter CHUNKS taps per K step -- no division in the loop
@@ -190,26 +190,34 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
                 const int iy = a_iy[i] + tky, ix = a_ix[i] + tkx;
                 const bool ok = tky < p.KH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const char* src = ok ? a_ptr[i] + (long)((tky * p.W + tkx) * p.Cin) * 2 : zero;
-                glds16(src, sa + (wave + NW * i) * 1024);
                 a_tx[i] += CHUNKS;
                 while (a_tx[i] >= p.KW) {
                     a_tx[i] -= p.KW;
                     ++a_ty[i];
                 }
+                return src;
             } else if (FLAT) {
-                glds16(a_ptr[i], sa + (wave + NW * i) * 1024);
+                const char* src = a_ptr[i];
                 a_ptr[i] += a_mask[i];
+                return src;
             } else {
                 const long koff = (long)((ky * p.W + kx) * p.Cin + c0) * 2;      // wave-uniform byte offset of this K tile
-                const char* src = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + koff : zero;
-                glds16(src, sa + (wave + NW * i) * 1024);
+                return ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + koff : zero;
             }
         } else {
             const int j = i - A_IT;
-            glds16(b_ptr[j], sb + (wave + NW * j) * 1024);
+            const char* src = b_ptr[j];
             b_ptr[j] += b_step[j];
+            return src;
         }
     };
+    // LDS destination (wave base; the DMA and the register path both place lane l's 16 bytes at base + 16 l)
+    auto piece_dst = [&](int stage, int i) -> char* {
+        char* sa = smem + stage * STAGE;
+        return i < A_IT ? sa + (wave + NW * i) * 1024 : sa + A_BYTES + (wave + NW * (i - A_IT)) * 1024;
+    };
+    // one DMA piece of K tile `kt` into `stage`
+    auto issue_piece = [&](int kt, int stage, int i) { glds16(piece_src(i), piece_dst(stage, i)); };
     // advance the filter-tap walk to the next K tile (after the last piece of a tile has been issued)
     auto advance = [&]() {
         if (AK == 0) {
@@ -299,7 +307,63 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         }
     };
 
-    if constexpr (NSTAGE == 5) {
+    if constexpr (NSTAGE == 7) {
+        // The anti-phase schedule of NSTAGE 5 with register-staged operands: the global loads of tile t + 3 are issued between
+        // the MFMAs of M(t) (a few issue cycles each instead of ~100 per DMA piece) and their ds_write_b128 into stage
+        // (t + 3) & 3 happens in the next read slot R(t + 1), the slot that already belongs to LDS traffic; that stage held
+        // tile t - 1, whose last reads were retired two barriers earlier.  One 16-VGPR register set in flight.
+        constexpr int P = A_IT + B_IT, NM = TM * TN * KS;
+        static_assert(NSTAGE != 7 || NM % P == 0, "loads are spread evenly over the MFMAs of a tile");
+        half8 rg[P];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < nk) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) rg[i] = *reinterpret_cast<const half8*>(piece_src(i));
+                advance();
+#pragma unroll
+                for (int i = 0; i < P; ++i) *reinterpret_cast<half8*>(piece_dst(d, i) + lane * 16) = rg[i];
+            }
+        __syncthreads();
+        if (wm == 1) __builtin_amdgcn_s_barrier();                 // wave row 1 runs one slot behind row 0
+        bool pending = false;                                      // rg holds tile t + 2 (fetched in the previous M slot)
+        for (int t = 0; t < nk; ++t) {
+            // ---- R(t)
+            const char* st = smem + (t & 3) * STAGE;
+            half8 fa[TM][KS], fb[TN][KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i][ks] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * ROW_BYTES + choff[ks]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j][ks] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * ROW_BYTES + choff[ks]);
+            }
+            if (pending) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) *reinterpret_cast<half8*>(piece_dst((t + 2) & 3, i) + lane * 16) = rg[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- M(t)
+            const bool ld = t + 3 < nk;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                const int ks = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+                if (ld && q % (NM / P) == 1) rg[q / (NM / P)] = *reinterpret_cast<const half8*>(piece_src(q / (NM / P)));
+            }
+            if (ld) advance();
+            pending = ld;
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();                 // balances the extra barrier of row 1
+        __syncthreads();
+    } else if constexpr (NSTAGE == 5) {
         constexpr int P = A_IT + B_IT, NM = TM * TN * KS;
         static_assert(NSTAGE != 5 || NM % P == 0, "DMA pieces are spread evenly over the MFMAs of a tile");
 #pragma unroll
@@ -341,6 +405,39 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();                 // balances the extra barrier of row 1
         __syncthreads();
+    } else if constexpr (NSTAGE == 6) {
+        // Register-staged operands: global_load_dwordx4 -> VGPR -> ds_write_b128 into the same lane-linear, swizzled LDS image
+        // the DMA path builds.  A DMA piece costs its wave 100-185 issue cycles next to MFMAs and fragment reads
+        // (MI355X_MICROARCH.md; profiles/r01_lab_gemm_pingpong.txt), a load + a 16-byte LDS store about 20; the price is 4
+        // VGPRs per piece in flight.  Two register sets: tile kt + 2 is fetched while tile kt is computed, tile kt + 1
+        // (fetched an iteration earlier) is stored to the other stage first -- that stage was last read before the barrier
+        // that ended the previous iteration.  One barrier per K step.
+        constexpr int P = A_IT + B_IT;
+        half8 rg0[P], rg1[P];
+        auto fetch = [&](half8 (&r)[P]) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) r[i] = *reinterpret_cast<const half8*>(piece_src(i));
+            advance();
+        };
+        auto put = [&](const half8 (&r)[P], int stage) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) *reinterpret_cast<half8*>(piece_dst(stage, i) + lane * 16) = r[i];
+        };
+        fetch(rg0);
+        if (nk > 1) fetch(rg1);
+        put(rg0, 0);
+        __syncthreads();
+        auto step = [&](int kt, half8 (&r_next)[P], half8 (&r_free)[P]) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) put(r_next, cur ^ 1);
+            if (kt + 2 < nk) fetch(r_free);
+            compute(cur);
+            __syncthreads();
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, rg1, rg0);
+            if (kt + 1 < nk) step(kt + 1, rg0, rg1);
+        }
     } else if constexpr (NSTAGE == 2) {
         issue(kt0, 0);
         __syncthreads();
@@ -536,6 +633,10 @@ const TileCfg kCfgs[] = {
     {128, 256, 32, 3, &launch2<128, 256, 32, 3, false, 2>}, {128, 256, 64, 2, &launch2<128, 256, 64, 2, false, 2>},
     // nstage 5: the anti-phase schedule over a 4-stage ring (see igemm2_kernel)
     {256, 256, 32, 5, &launch2<256, 256, 32, 5, false, 4>},
+    // Schedules 6 (register-staged operands over 2 LDS stages) and 7 (the same inside the anti-phase schedule) are compiled on
+    // demand only: measured on the 104-frame shapes (profiles/r02_igemm_register_staging.txt) 256x256x32/6 beats its DMA twin
+    // /2 by 15 % (188 vs 222 us on 252928 x 256 x 1024) but loses to the ring (/3, 180) and the anti-phase DMA schedule (/5,
+    // 166); /7 loses to /5 on every shape (181 vs 166; 354 vs 310 on the 3x3) -- they never win, so they are not in the table.
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 const TileCfg kStemCfgs[] = {   // Cin == 8 stem (one filter tap per 16-byte chunk)
@@ -674,6 +775,26 @@ int bucket_rows(int M) {
     return ((M + (1 << sh) - 1) >> sh) << sh;
 }
 
+// A layer's best tile changes slowly with the row count: a bucket that has not been timed takes the winner of the nearest
+// timed bucket of the same layer within one octave, so a stream of ragged video tails costs one timing pass per layer and
+// octave, not one per bucket.
+int nearest_bucket_cfg(const ShapeKey& k) {
+    int best = -1;
+    double best_d = 1.0;            // |log2(M / M')| <= 1
+    for (const auto& kv : g_tuned) {
+        const ShapeKey& o = kv.first;
+        if (o.Cout != k.Cout || o.Kpad != k.Kpad || o.Cin != k.Cin || o.ntaps != k.ntaps || o.stride != k.stride || o.res_mode != k.res_mode ||
+            o.flags != k.flags || o.M <= 0)
+            continue;
+        const double d = fabs(log2((double)k.M / (double)o.M));
+        if (d <= best_d) {
+            best_d = d;
+            best = kv.second;
+        }
+    }
+    return best;
+}
+
 int g_tune_mode = -1;            // -1: follow DVID_IGEMM_TUNE (default on); 0: never time on the serving path; 1: time new shape buckets
 
 }  // namespace
@@ -724,6 +845,9 @@ int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
         auto it = g_tuned.find(key);
         if (it != g_tuned.end()) {
             cfg = it->second;
+        } else if (int near = nearest_bucket_cfg(key); near >= 0 && cfg_valid(cfgs[near], p)) {
+            cfg = near;                          // same layer, row count within a factor of two of a tuned bucket: inherit
+            g_tuned.emplace(key, cfg);
         } else if (g_tune_mode == 0) {
             cfg = fallback;                     // serving mode: no timing launches; the hand rule for unseen buckets
         } else {
