@@ -252,7 +252,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     constexpr int EROWS = (BM / 2) / ERPP;
     const int c8 = (tid % VPR) * 8;
     const int n = n0 + c8;
-    constexpr bool PRE = BM * BN <= 128 * 128;      // larger tiles need the registers for accumulators
+    constexpr bool PRE = BM * BN <= 128 * 128;      // larger tiles need the registers for accumulators (and lose anyway: 128x256 with the prefetch 453 vs 317 us on res4 conv3)
     const bool pre_ok = PRE && p.res_mode == 1 && !p.res_f32 && (p.Cout & 7) == 0;
     half8 rpre[2][PRE ? EROWS : 1];
     if (pre_ok) {

@@ -45,7 +45,7 @@ def remap_diffusiondet_heads(model_keys, state_dict, skip_names=None):
     counts = []
     for kwd in names:
         nums = [int(k.split(kwd + ".")[1][0]) for k in model_keys if kwd + "." in k]
-        counts.append(max(nums) + 1)
+        counts.append(max(nums) + 1 if nums else 0)       # (the reference assumes both lists exist; a head-less model has neither)
     lo, hi = list(accumulate(counts))
     change = ["head_series." + str(i) for i in range(lo, hi)]
     if skip_names is not None:        # training-time partial loads (checkpoint.py:62-65); inference passes None
