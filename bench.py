@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--arch", choices=("r101", "swinb"), default="r101",
                     help="r101 = the BASELINE.json headline configuration; swinb = configs/vid_Swin_B_DiffusionVID.yaml (INFER_BATCH 4)")
     ap.add_argument("--sample-step", type=int, default=1, help="MODEL.DiffusionDet.SAMPLE_STEP (4 = the x4 configuration)")
+    ap.add_argument("--skip-unobservable", action="store_true",
+                    help="MODEL.DiffusionDet.SKIP_UNOBSERVABLE for the main measurement (x4 only; SURVEY.md Appendix B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned frames, H2D in the timed region) measurement")
     ap.add_argument("--no-side-configs", action="store_true",
@@ -268,10 +270,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def build(arch, sample_step, lookahead):
+    def build(arch, sample_step, lookahead, skip_unobservable=False):
         yaml = "configs/vid_R_101_DiffusionVID.yaml" if arch == "r101" else "configs/vid_Swin_B_DiffusionVID.yaml"
         cfg = get_cfg(os.path.join(ROOT, yaml), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", lookahead,
-                                                 "MODEL.DiffusionDet.SAMPLE_STEP", sample_step],
+                                                 "MODEL.DiffusionDet.SAMPLE_STEP", sample_step,
+                                                 "MODEL.DiffusionDet.SKIP_UNOBSERVABLE", bool(skip_unobservable)],
                       os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
         cfg.freeze()
         model = build_detection_model(cfg).to(device).eval()
@@ -315,7 +318,7 @@ def main():
 
     if args.workload == "vidval":
         return vidval(args, build, timed, barrier, device, rank, world, H, W)
-    cfg, model = build(args.arch, args.sample_step, args.lookahead)
+    cfg, model = build(args.arch, args.sample_step, args.lookahead, args.skip_unobservable)
     ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
     ds.preload()
     with torch.no_grad():
@@ -411,9 +414,9 @@ def main():
     del model
     others = {}
 
-    def side(name, arch, sample_step, lookahead, steps):
+    def side(name, arch, sample_step, lookahead, steps, skip_unobservable=False):
         try:
-            c2, m2 = build(arch, sample_step, lookahead)
+            c2, m2 = build(arch, sample_step, lookahead, skip_unobservable)
             d2 = SyntheticVIDDataset([L], c2, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
             d2._cache = ds._cache                  # same frames, already resident
             with torch.no_grad():
@@ -429,6 +432,8 @@ def main():
         side("reference_protocol_lookahead_1", args.arch, args.sample_step, 1, 2)
         if headline and world == 1:
             side("r101_x4", "r101", 4, 13, 2)
+            # 12 observable head passes per frame instead of the faithful 19 (same detections)
+            side("r101_x4_observable_passes_only", "r101", 4, 13, 2, skip_unobservable=True)
             side("swinb_x1", "swinb", 1, 26, 2)
 
     if rank == 0:

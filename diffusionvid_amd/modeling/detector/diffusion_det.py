@@ -114,6 +114,7 @@ class DiffusionDet(nn.Module):
         alphas_cumprod_prev = torch.nn.functional.pad(alphas_cumprod[:-1], (1, 0), value=1.0)
         self.num_timesteps = timesteps
         self.sampling_timesteps = d.SAMPLE_STEP
+        self.skip_unobservable = bool(getattr(d, "SKIP_UNOBSERVABLE", False)) and d.SAMPLE_STEP > 1
         assert self.sampling_timesteps <= timesteps
         self.ddim_sampling_eta = 1.0
         self.scale = d.SNR_SCALE
@@ -399,6 +400,21 @@ class DiffusionDet(nn.Module):
             if ci == 0 and self.after_first_launch is not None:
                 self.after_first_launch()          # e.g. the data layer's prefetch of the next group: behind this call's own uploads
             B = chunk.shape[0]
+            if self.skip_unobservable:
+                # x4: of the extraction pass only the backbone features of every frame and the top-k
+                # object features of the GLOBAL frames are ever read -- the 3 heads run on the global frames of this chunk only
+                g0, g1 = max(len_l, a) - a, min(n_own, a + B) - a
+                dev, d = self.device, self.hidden_dim
+                res = {"feats": feats, "logits": torch.empty((B, M, self.num_classes), device=dev), "boxes": torch.empty((B, M, 4), device=dev),
+                       "obj": torch.empty((B, M, d), device=dev), "k1": torch.empty((B, self.top_k[0], d), device=dev),
+                       "k2": torch.empty((B, self.top_k[1], d), device=dev)}
+                if g1 > g0:
+                    t = torch.full((g1 - g0,), 999, dtype=torch.long)
+                    (cl, bx, pf), k1, k2 = self.model_predictions([f[g0:g1] for f in feats], whwh, box_init_all[a + g0:a + g1], t, box_extract=ci + 1)
+                    res["k1"][g0:g1] = k1.view(g1 - g0, self.top_k[0], d)
+                    res["k2"][g0:g1] = k2.view(g1 - g0, self.top_k[1], d)
+                per_frame += [(res, i) for i in range(B)]
+                continue
             t = torch.full((B,), 999, dtype=torch.long)
             (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init_all[a:a + B], t, box_extract=ci + 1)
             res = {"feats": feats, "logits": cl, "boxes": bx, "obj": pf[0].view(B, M, self.hidden_dim),
@@ -493,6 +509,8 @@ class DiffusionDet(nn.Module):
         coef = {t: (float(self._sr_host[t]), float(self._srm1_host[t])) for t, _ in pairs}
         ens_logits, ens_boxes = [], []
         for step, (time, time_next) in enumerate(pairs):
+            if time_next < 0 and self.skip_unobservable:
+                continue            # nothing reads the last step's outputs (diffusion_det.py:573-575, :607-627)
             t = torch.full((batch,), time, dtype=torch.long)
             outputs_class, outputs_coord = self.model_predictions(feats_cur, whwh, img, t)
             if self.debug_taps is not None:

@@ -714,3 +714,33 @@ def test_engine_built_lookahead_equals_reference_schedule():
         a, b = outs[1][i], outs[4][i]
         assert len(a) == len(b) and torch.equal(a.get_field("labels"), b.get_field("labels"))
         assert torch.allclose(a.bbox, b.bbox, atol=1e-4, rtol=0) and torch.allclose(a.get_field("scores"), b.get_field("scores"), atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize("lookahead", [1, 3])
+def test_x4_skip_unobservable_passes_keeps_detections(lookahead):
+    """with SAMPLE_STEP 4 nothing reads (a) the head passes of the last DDIM step and (b) the extraction
+    heads' outputs on local frames.  MODEL.DiffusionDet.SKIP_UNOBSERVABLE drops exactly those 7 of 19 head passes per frame;
+    the detections must be the very same tensors -- two videos, ragged tails, with and without look-ahead groups."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.engine import inference as eng
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    outs = {}
+    for skip in (False, True):
+        cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.DiffusionDet.SAMPLE_STEP", 4, "MODEL.DiffusionDet.SKIP_UNOBSERVABLE", skip,
+                                                              "INPUT.LOOKAHEAD_BATCHES", lookahead], "configs/BASE_RCNN_1gpu.yaml")
+        cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+        cfg.freeze()
+        model = build_detection_model(cfg)
+        model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+        model = model.to("cuda").eval()
+        model.noise_fn = synthetic.noise_fn
+        assert model.skip_unobservable == skip
+        ds = SyntheticVIDDataset([28, 13], cfg, height=120, width=200, device="cuda", smooth=True, emit_ref_ahead=False)
+        outs[skip] = eng.compute_on_dataset(model, ds, range(len(ds)), torch.device("cuda"))
+    assert sorted(outs[True]) == list(range(41)) and sum(len(v) for v in outs[True].values()) > 0
+    for i in range(41):
+        a, b = outs[False][i], outs[True][i]
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
+        assert torch.equal(a.get_field("labels"), b.get_field("labels"))
