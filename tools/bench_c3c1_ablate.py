@@ -9,6 +9,7 @@ n = 104
 m = ops.Model(synthetic.make_state_dict(0))
 m.reserve(n, 608, 1024, 300)
 m.set_chains(1)
+m.set_fusion(True)
 x = torch.rand(n, 3, 608, 1024, device="cuda")
 lib = _lib.load()
 m.backbone(x); m.backbone(x)
