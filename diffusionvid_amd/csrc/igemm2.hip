@@ -637,6 +637,8 @@ const TileCfg kCfgs[] = {
     // demand only: measured on the 104-frame shapes (profiles/r02_igemm_register_staging.txt) 256x256x32/6 beats its DMA twin
     // /2 by 15 % (188 vs 222 us on 252928 x 256 x 1024) but loses to the ring (/3, 180) and the anti-phase DMA schedule (/5,
     // 166); /7 loses to /5 on every shape (181 vs 166; 354 vs 310 on the 3x3) -- they never win, so they are not in the table.
+    // Nor are 4-wave 256x256 tiles (128x128 per wave, 256 accumulator AGPRs, one wave per SIMD -- the vendor library's shape,
+    // MT256x256x32/64 MIWT8_8): 191-206 us against 168 on 252928 x 256 x 1024, 343 against 311 on the 3x3.
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 const TileCfg kStemCfgs[] = {   // Cin == 8 stem (one filter tap per 16-byte chunk)
