@@ -744,3 +744,36 @@ def test_x4_skip_unobservable_passes_keeps_detections(lookahead):
         a, b = outs[False][i], outs[True][i]
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
         assert torch.equal(a.get_field("labels"), b.get_field("labels"))
+
+
+def test_host_fed_prefetch_equals_resident_frames():
+    """data/prefetch.HostFedVideo: frames in pinned host memory, one async copy per look-ahead group into two alternating HBM
+    staging buffers on a side stream (issued by the detector behind its own uploads), cyclic over two passes -- the
+    detections must be exactly those of the run on resident frames, for two videos with ragged tails (staging buffers are
+    re-used while earlier groups' kernels may still be reading: any missing stream dependency shows up as a difference)."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.prefetch import HostFedVideo
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.engine import inference as eng
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["INPUT.LOOKAHEAD_BATCHES", 2], "configs/BASE_RCNN_1gpu.yaml")
+    cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+    model = model.to("cuda").eval()
+    model.noise_fn = synthetic.noise_fn
+    dev = torch.device("cuda")
+    lens = [45, 30]
+    res_ds = SyntheticVIDDataset(lens, cfg, height=120, width=200, device="cuda", smooth=True, emit_ref_ahead=False)
+    ref = eng.compute_on_dataset(model, res_ds, range(len(res_ds)), dev)
+    host = SyntheticVIDDataset(lens, cfg, height=120, width=200, device="cpu", smooth=True, emit_ref_ahead=False)
+    hf = HostFedVideo(host, dev, 16, cyclic=True).pin().attach(model)
+    for _ in range(2):                                   # second pass: group 0 was staged under the previous pass's last group
+        got = eng.compute_on_dataset(model, hf, range(len(hf)), dev)
+        assert sorted(got) == sorted(ref) == list(range(75))
+        for i in ref:
+            assert torch.equal(ref[i].bbox, got[i].bbox) and torch.equal(ref[i].get_field("scores"), got[i].get_field("scores"))
+    assert hf.h2d_bytes >= 2 * 75 * 3 * 128 * 224 * 4
+    model.after_first_launch = None
