@@ -230,7 +230,8 @@ struct dvid_model {
     // software pipeline of the ResNet backbone (see dvid_backbone_resnet_fpn): sub-batches, and the (stage, block) at which
     // a sub-batch moves from the front stream to the back stream; pipe_parts <= 1: off
     int pipe_parts = 0, pipe_stage = 2, pipe_block = 0;
-    std::vector<hipEvent_t> ev_mid;
+    std::vector<hipEvent_t> ev_mid, ev_dyn;
+    int dyn_chunks = 1;       // DVID_DYN_CHUNKS: dynamic_layer GEMM / DynamicConv software pipeline over row chunks (1: off)
     hipStream_t cs[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool streams_ready = false;
@@ -528,8 +529,36 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
     float* x1 = f32c;
     TRY(dvid_add_layernorm_launch(pro, f32b, hw.norm1.g, hw.norm1.b, x1, h16a, R, d, 0, s));
     // --- DynamicConv ---
-    TRY(linear_run(hw.dynamic_layer, h16a, R, params16, 0, 0, s));
-    TRY(dvid_dynconv_launch(roi16, params16, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn16, R, s));
+    // dynamic_layer writes 64 KB of parameters per box that DynamicConv reads straight back (csrc/dynconv.hip).  With
+    // dyn_chunks > 1 the rows are cut into chunks: the GEMM of chunk i + 1 (MFMA / epilogue-bound) runs on this stream while
+    // DynamicConv of chunk i (HBM-bound) runs on a helper stream.  Measured (bench.py, one box, A/B): 1 chunk 1740 / 1734
+    // frames/s, 2 chunks 1729, 4 chunks 1717 / 1721, 8 chunks 1703 -- the two kernels do not overlap usefully; off by default.
+    const int nchunk = (m->dyn_chunks > 1 && nf >= 2 * m->dyn_chunks) ? m->dyn_chunks : 1;
+    if (nchunk == 1) {
+        TRY(linear_run(hw.dynamic_layer, h16a, R, params16, 0, 0, s));
+        TRY(dvid_dynconv_launch(roi16, params16, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn16, R, s));
+    } else {
+        TRY(m->ensure_streams());
+        hipStream_t hs = m->cs[3];
+        while ((int)m->ev_dyn.size() < nchunk + 1) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->ev_dyn.push_back(e);
+        }
+        const int fper = (nf + nchunk - 1) / nchunk;
+        for (int c = 0; c < nchunk; ++c) {
+            const int fa = c * fper, fb = (fa + fper < nf) ? fa + fper : nf;
+            if (fb <= fa) break;
+            const size_t r0c = (size_t)fa * M, rows = (size_t)(fb - fa) * M;
+            TRY(linear_run(hw.dynamic_layer, h16a + r0c * d, (int)rows, params16 + r0c * 2 * d * m->cfg.dim_dynamic, 0, 0, s));
+            HIP_TRY(hipEventRecord(m->ev_dyn[c], s));
+            HIP_TRY(hipStreamWaitEvent(hs, m->ev_dyn[c], 0));
+            TRY(dvid_dynconv_launch(roi16 + r0c * 49 * d, params16 + r0c * 2 * d * m->cfg.dim_dynamic, hw.dc_norm1.g, hw.dc_norm1.b,
+                                    hw.dc_norm2.g, hw.dc_norm2.b, dyn16 + r0c * 49 * d, (int)rows, hs));
+        }
+        HIP_TRY(hipEventRecord(m->ev_dyn[nchunk], hs));
+        HIP_TRY(hipStreamWaitEvent(s, m->ev_dyn[nchunk], 0));
+    }
     // out_layer: K = 49*d = 12544 on only R x d outputs -> split K over 7 workgroups per tile; the partial slabs
     // and the bias are summed inside the norm3 kernel that consumes them.
     const int osplit = ((hw.out_layer.kpad / 64) % 7 == 0) ? 7 : 1;
@@ -627,6 +656,7 @@ int dvid_model_create(const dvid_config* cfg, dvid_model** out) {
     m->cfg = *cfg;
     if (const char* e = getenv("DVID_CHAINS")) m->nchain = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
     if (const char* e = getenv("DVID_FUSE_C3C1")) m->fuse_c3c1 = atoi(e) != 0;
+    if (const char* e = getenv("DVID_DYN_CHUNKS")) m->dyn_chunks = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
     if (const char* e = getenv("DVID_PIPE")) m->pipe_parts = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
     if (const char* e = getenv("DVID_PIPE_SPLIT")) {
         int st = 2, b = 0;
@@ -648,6 +678,7 @@ int dvid_model_destroy(dvid_model* m) {
     for (DevBuf* b : bufs) b->release();
     for (auto& kv : m->ss_tables) kv.second.release();
     for (hipEvent_t e : m->ev_mid) (void)hipEventDestroy(e);
+    for (hipEvent_t e : m->ev_dyn) (void)hipEventDestroy(e);
     delete m;
     return DVID_OK;
 }
