@@ -9,16 +9,18 @@
 // Y chunk it has just produced is rounded to fp16 -- exactly what the unfused path stores -- kept in LDS, and used at once
 // as the A operand of the second product, so Y is written once and never re-read.
 //
-// Structure (256 threads = 4 waves, 2 workgroups per CU):
-//   * A[64, K1] is loaded into LDS once (pitch K1 + 8 halves: conflict-free ds_read_b128 fragments).
-//   * N1 is walked in chunks of up to 256 columns.  Per chunk every wave computes 64 rows x chunk/4 columns of the first
+// Structure (1024 threads = 16 waves = two independent 64-row halves of 8 waves, one workgroup per CU):
+//   * A[128, K1] is loaded into LDS once (pitch K1 + 8 halves: conflict-free ds_read_b128 fragments).
+//   * N1 is walked in chunks of up to 256 columns.  Per chunk every wave computes 64 rows x 32 columns of the first
 //     product, finishes them in registers (bias + residual + ReLU; the MFMA accumulator layout gives each lane one column
 //     and 16 rows per 32x32 tile, i.e. 64-byte runs per row across a half-wave for the residual loads and the Y stores),
 //     writes the fp16 values to global memory and into the LDS chunk buffer; after a barrier the chunk is one K slice of
 //     the second product, accumulated across chunks in K-ascending order.
 //   * The weights are never staged through LDS: they are re-packed at load time into MFMA B-fragment order (one
 //     contiguous 1-KiB block per 32 x 16 tile), so a wave fetches a fragment with one fully coalesced 16-byte-per-lane
-//     load from L2 (both matrices total <= 1 MB and are shared by every workgroup).  No barrier inside either K loop.
+//     load from L2; the two halves fetch the same fragments at about the same time, so the second fetch hits L1.
+//     No barrier inside either K loop.
+// Measured (profiles/r02_c3c1_fusion.txt): no faster than the two tuned igemm2 launches it replaces -- off by default.
 // Sums run in the same order as igemm2's (K ascending, 16 per MFMA, fp32 accumulate, one fp16 rounding after bias +
 // residual), so Y and Z are bit-identical to the two separate launches (tests/test_gpu_kernels.py).
 #include <stdlib.h>

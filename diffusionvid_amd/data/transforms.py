@@ -112,8 +112,8 @@ class ResizeToTensor:
         if is_current or self.size is None:
             self.size = get_size(image.size, self.min_size, self.max_size)
         oh, ow = self.size
-        out = np.asarray(image.convert("RGB").resize((ow, oh), Image.BILINEAR))
-        return torch.from_numpy(np.ascontiguousarray(out)).permute(2, 0, 1).to(torch.float32).div(255)
+        out = np.array(image.convert("RGB").resize((ow, oh), Image.BILINEAR))          # a writable copy
+        return torch.from_numpy(out).permute(2, 0, 1).to(torch.float32).div(255)
 
 
 class ResizeToTensorDevice:
