@@ -35,6 +35,7 @@ SIGNATURES = {
     "dvid_model_finalize": (c_int, [c_void_p]),
     "dvid_set_chains": (c_int, [c_void_p, c_int]),
     "dvid_set_fusion": (c_int, [c_void_p, c_int]),
+    "dvid_set_stem_layout": (c_int, [c_void_p, c_int]),
     "dvid_set_pipeline": (c_int, [c_void_p, c_int, c_int, c_int]),
     "dvid_workspace_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "dvid_backbone_resnet_fpn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

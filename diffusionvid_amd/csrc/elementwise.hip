@@ -20,6 +20,37 @@ __global__ void prep_images_kernel(const float* __restrict__ in, half_t* __restr
     *reinterpret_cast<half8*>(out + i * 8) = v;
 }
 
+// The same normaliser with a 2x2 space-to-depth layout: out[n][Y][X][(dy*2 + dx)*3 + c] (12 channels + 4 zero = 32 bytes per
+// 2x2 pixel block).  The 7x7 / stride-2 stem convolution over 3 channels is then a 4x4 / stride-1 convolution over these 16
+// channels (csrc/model.hip: make_stem_s2d): K = 256 instead of 448 padded columns and half the input bytes.
+__global__ void prep_images_s2d_kernel(const float* __restrict__ in, half_t* __restrict__ out, long nblk, int h2, int w2, float m0,
+                                       float m1, float m2, float s0, float s1, float s2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk) return;
+    const long per = (long)h2 * w2;
+    const long img = i / per, b = i - img * per;
+    const int Y = (int)(b / w2), X = (int)(b - (long)Y * w2);
+    const long w = 2L * w2, hw = 4 * per;
+    const float* p = in + img * 3 * hw + (2L * Y) * w + 2 * X;
+    half8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {0, 0, 0, 0, 0, 0, 0, 0};
+    half_t v[12];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const float* q = p + dy * w + dx;
+            v[(dy * 2 + dx) * 3 + 0] = (half_t)((q[0] - m0) * s0);
+            v[(dy * 2 + dx) * 3 + 1] = (half_t)((q[hw] - m1) * s1);
+            v[(dy * 2 + dx) * 3 + 2] = (half_t)((q[2 * hw] - m2) * s2);
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lo[e] = v[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hi[e] = v[8 + e];
+    *reinterpret_cast<half8*>(out + i * 16) = lo;
+    *reinterpret_cast<half8*>(out + i * 16 + 8) = hi;
+}
+
 // 3x3 stride-2 pad-1 max pool, NHWC fp16, one lane per 8-channel vector of an output pixel.
 __global__ void maxpool_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int n, int h, int w, int c, int ho, int wo) {
     const int cv = c >> 3;
@@ -253,6 +284,16 @@ int dvid_prep_images_launch(const float* nchw, half_t* nhwc8, int n, int h, int 
     const long hw = (long)h * w, npix = hw * n;
     hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, nchw, nhwc8, npix, hw, mean[0],
                        mean[1], mean[2], inv_std[0], inv_std[1], inv_std[2]);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_prep_images_s2d_launch(const float* nchw, half_t* s2d16, int n, int h, int w, const float* mean, const float* inv_std,
+                                hipStream_t s) {
+    if ((h | w) & 1) return DVID_ERR_ARG;
+    const long nblk = (long)n * (h / 2) * (w / 2);
+    hipLaunchKernelGGL(prep_images_s2d_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, nchw, s2d16, nblk, h / 2, w / 2,
+                       mean[0], mean[1], mean[2], inv_std[0], inv_std[1], inv_std[2]);
     LAUNCH_CHECK();
     return DVID_OK;
 }

@@ -119,8 +119,10 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         a_ptr[i] = zero;
         a_iy[i] = -(1 << 28);
         a_ix[i] = 0;
-        a_ty[i] = SMALLC ? a_lch[i] / p.KW : 0;
-        a_tx[i] = SMALLC ? a_lch[i] - a_ty[i] * p.KW : 0;
+        // SMALLC: Cin = 8 or 16 (one or two 16-byte chunks per filter tap); this lane's chunk belongs to tap lch / cpt
+        const int cpt = SMALLC ? (p.Cin >> 3) : 1;
+        a_ty[i] = SMALLC ? (a_lch[i] / cpt) / p.KW : 0;
+        a_tx[i] = SMALLC ? (a_lch[i] / cpt) - a_ty[i] * p.KW : 0;
         if (FLAT) {
             if (m < p.M) {
                 long pix = m;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
             const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
             a_iy[i] = iy0;
             a_ix[i] = ix0;
-            a_ptr[i] = reinterpret_cast<const char*>(p.in + ((long)(img * p.H + iy0) * p.W + ix0) * p.Cin + (SMALLC ? 0 : a_lch[i] * 8));
+            a_ptr[i] = reinterpret_cast<const char*>(p.in + ((long)(img * p.H + iy0) * p.W + ix0) * p.Cin + (SMALLC ? (a_lch[i] % cpt) * 8 : a_lch[i] * 8));
             if (!SMALLC) {
                 for (int t2 = 0; t2 < p.ntaps; ++t2) {
                     const int ty = t2 / p.KW, tx = t2 - ty * p.KW;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
                 const int iy = a_iy[i] + tky, ix = a_ix[i] + tkx;
                 const bool ok = tky < p.KH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const char* src = ok ? a_ptr[i] + (long)((tky * p.W + tkx) * p.Cin) * 2 : zero;
-                a_tx[i] += CHUNKS;
+                a_tx[i] += CHUNKS / (p.Cin >> 3);
                 while (a_tx[i] >= p.KW) {
                     a_tx[i] -= p.KW;
                     ++a_ty[i];
@@ -818,7 +820,7 @@ int dvid_igemm_set_tuning(int mode) {
 int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
     if (p.Kpad % 64 != 0 || p.Kpad < 64) return DVID_ERR_ARG;
-    const bool smallc = (p.Cin == 8 && p.KH * p.KW > 1);
+    const bool smallc = ((p.Cin == 8 || p.Cin == 16) && p.KH * p.KW > 1);
     if (!smallc && (p.Cin % 64 != 0)) return DVID_ERR_UNSUPPORTED;
     if (p.res_mode == 2 && ((p.Ho | p.Wo) & 1)) return DVID_ERR_ARG;
     if (p.splitk > 1 && (!p.out_f32 || p.bias || p.relu || p.res_mode || smallc || (p.Kpad / 64) % p.splitk)) return DVID_ERR_ARG;

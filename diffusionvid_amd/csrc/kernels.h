@@ -37,6 +37,8 @@ int dvid_c3c1_launch(const C3C1Params& p, int k1, int n1, int n2, hipStream_t s)
 // elementwise.hip
 int dvid_prep_images_launch(const float* nchw, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
                             hipStream_t s);
+int dvid_prep_images_s2d_launch(const float* nchw, half_t* s2d16, int n, int h, int w, const float* mean, const float* inv_std,
+                                hipStream_t s);
 int dvid_maxpool3x3s2_launch(const half_t* in, half_t* out, int n, int h, int w, int c, hipStream_t s);
 int dvid_nchw_from_nhwc_launch(const half_t* in, float* out, int n, int h, int w, int c, hipStream_t s);
 int dvid_nhwc_from_nchw_launch(const float* in, half_t* out, int n, int h, int w, int c, hipStream_t s);

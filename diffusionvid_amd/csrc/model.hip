@@ -149,6 +149,8 @@ struct ConvW {   // conv or linear weights in MFMA-operand layout
     float* bias = nullptr;
     int cin = 0, cout = 0, kh = 1, kw = 1, stride = 1, pad = 0, kpad = 0;
     int cin_real = 0;  // un-padded input channels (algorithmic FLOP count)
+    bool same_size = false;    // output spatial size = input size whatever (kh, pad) say (the space-to-depth stem: pad 2 before, 1 after)
+    int alg_k = 0;             // algorithmic K for the FLOP count when the packed layout carries structural zeros (0: kh*kw*cin_real)
     half_t* wfrag = nullptr;   // 1x1 layers of the bottlenecks: the same matrix in MFMA B-fragment order (csrc/c3c1.hip)
 };
 struct LNW {
@@ -196,7 +198,8 @@ struct dvid_model {
 
     // backbone
     bool has_backbone = false;
-    ConvW stem;
+    ConvW stem, stem_s2d;      // NHWC8 7x7/2 form and the 2x2 space-to-depth 4x4/1 form of the same layer
+    bool use_s2d = true;       // DVID_STEM_S2D=0: the NHWC8 form
     std::vector<Block> blocks[4];
     ConvW lateral[3], output[3];  // index 0 -> level 3
     // Swin backbone (backbone_type 1)
@@ -337,6 +340,46 @@ int pack_frag_order(dvid_model* m, ConvW* w) {
     return m->upload(dst.data(), dst.size() * sizeof(half_t), reinterpret_cast<void**>(&w->wfrag));
 }
 
+// The 7x7 / stride-2 / pad-3 stem over 3 channels as a 4x4 / stride-1 convolution over the 2x2 space-to-depth image (16 channels:
+// (dy*2 + dx)*3 + c, 4 zero): output pixel (oy, ox) reads input rows 2oy-3 .. 2oy+3 = s2d rows oy-2 .. oy+1 (pad 2 before; the row
+// after is inside or beyond the image), and original tap ky lives in s2d tap ty = (ky + 1) >> 1 at sub-row dy = (ky + 1) & 1.  FrozenBN
+// folded as in make_conv_bn.  K = 16 taps x 16 channels = 256 packed columns against 49 x 8 -> 448 of the NHWC8 form.
+int make_stem_s2d(dvid_model* m, const std::string& name, ConvW* out) {
+    NEED(w, name + ".weight");
+    NEED(g, name + ".norm.weight");
+    NEED(b, name + ".norm.bias");
+    NEED(mu, name + ".norm.running_mean");
+    NEED(var, name + ".norm.running_var");
+    const int cout = (int)w->shape[0];
+    if (w->shape.size() != 4 || w->shape[1] != 3 || w->shape[2] != 7 || w->shape[3] != 7) FAIL(DVID_ERR_UNSUPPORTED, "stem must be 3 -> C, 7x7");
+    const int kpad = 256;
+    std::vector<half_t> packed((size_t)cout * kpad, f2h(0.f));
+    std::vector<float> bias(cout);
+    for (int o = 0; o < cout; ++o) {
+        const float sc = g->v[o] / sqrtf(var->v[o] + 1e-5f);
+        bias[o] = b->v[o] - mu->v[o] * sc;
+        for (int c = 0; c < 3; ++c)
+            for (int ky = 0; ky < 7; ++ky)
+                for (int kx = 0; kx < 7; ++kx) {
+                    const int ty = (ky + 1) >> 1, dy = (ky + 1) & 1, tx = (kx + 1) >> 1, dx = (kx + 1) & 1;
+                    const float v = w->v[(((size_t)o * 3 + c) * 7 + ky) * 7 + kx] * sc;
+                    packed[(size_t)o * kpad + (size_t)(ty * 4 + tx) * 16 + (dy * 2 + dx) * 3 + c] = f2h(v);
+                }
+    }
+    TRY(m->upload(packed.data(), packed.size() * sizeof(half_t), reinterpret_cast<void**>(&out->w)));
+    TRY(upload_f32(m, bias, &out->bias));
+    out->cin = 16;
+    out->cin_real = 3;
+    out->cout = cout;
+    out->kh = out->kw = 4;
+    out->stride = 1;
+    out->pad = 2;
+    out->kpad = kpad;
+    out->same_size = true;
+    out->alg_k = 147;
+    return DVID_OK;
+}
+
 int make_linear(dvid_model* m, const std::string& name, bool has_bias, ConvW* out, const std::vector<int>* perm = nullptr,
                 int row0 = 0, int rows = -1) {
     NEED(w, name + (name.find("in_proj") != std::string::npos ? "_weight" : ".weight"));
@@ -435,13 +478,13 @@ int conv_run(const ConvW& w, const half_t* in, int n, int h, int wd, void* out, 
     p.KW = w.kw;
     p.stride = w.stride;
     p.pad = w.pad;
-    p.Ho = (h + 2 * w.pad - w.kh) / w.stride + 1;
-    p.Wo = (wd + 2 * w.pad - w.kw) / w.stride + 1;
+    p.Ho = w.same_size ? h : (h + 2 * w.pad - w.kh) / w.stride + 1;
+    p.Wo = w.same_size ? wd : (wd + 2 * w.pad - w.kw) / w.stride + 1;
     p.Cout = w.cout;
     p.M = n * p.Ho * p.Wo;
     p.Kpad = w.kpad;
     p.ntaps = w.kh * w.kw;
-    p.alg_k = w.kh * w.kw * (w.cin_real ? w.cin_real : w.cin);
+    p.alg_k = w.alg_k ? w.alg_k : w.kh * w.kw * (w.cin_real ? w.cin_real : w.cin);
     p.ldc = ldc ? ldc : w.cout;
     p.relu = relu;
     p.out_f32 = out_f32;
@@ -656,6 +699,7 @@ int dvid_model_create(const dvid_config* cfg, dvid_model** out) {
     m->cfg = *cfg;
     if (const char* e = getenv("DVID_CHAINS")) m->nchain = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
     if (const char* e = getenv("DVID_FUSE_C3C1")) m->fuse_c3c1 = atoi(e) != 0;
+    if (const char* e = getenv("DVID_STEM_S2D")) m->use_s2d = atoi(e) != 0;
     if (const char* e = getenv("DVID_DYN_CHUNKS")) m->dyn_chunks = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
     if (const char* e = getenv("DVID_PIPE")) m->pipe_parts = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
     if (const char* e = getenv("DVID_PIPE_SPLIT")) {
@@ -703,6 +747,7 @@ int dvid_model_finalize(dvid_model* m) {
     if (m->has_backbone && c.backbone_type == 0) {
         const std::string bu = "backbone.bottom_up.";
         TRY(make_conv_bn(m, bu + "stem.conv1", 2, 3, 8, &m->stem));
+        TRY(make_stem_s2d(m, bu + "stem.conv1", &m->stem_s2d));
         for (int s = 0; s < 4; ++s) {
             m->blocks[s].resize(c.res_blocks[s]);
             for (int b = 0; b < c.res_blocks[s]; ++b) {
@@ -812,6 +857,13 @@ int dvid_set_chains(dvid_model* m, int nchain) {
     g_err[0] = 0;
     if (!m || nchain < 1 || nchain > 4) FAIL(DVID_ERR_ARG, "nchain must be 1..4");
     m->nchain = nchain;
+    return DVID_OK;
+}
+
+int dvid_set_stem_layout(dvid_model* m, int space_to_depth) {
+    g_err[0] = 0;
+    if (!m) FAIL(DVID_ERR_ARG, "null model");
+    m->use_s2d = space_to_depth != 0;
     return DVID_OK;
 }
 
@@ -951,9 +1003,16 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
         half_t* lat[3];
         for (int l = 0; l < 3; ++l) lat[l] = m->lat[l].as<half_t>() + fo * (px4 / (4 << (2 * l))) * 256;
 
-        TRY(dvid_prep_images_launch(images + (size_t)f0 * 3 * px, img8, nf, height, width, mean, inv_std, cs));
         int h = height, w = width;
-        TRY(conv_run(m->stem, img8, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs, &h, &w));
+        if (m->use_s2d) {
+            // normalise + 2x2 space-to-depth (16 halves per block: the same bytes per frame as half an NHWC8 image), then the stem
+            // as a 4x4 / stride-1 convolution on the half-resolution grid
+            TRY(dvid_prep_images_s2d_launch(images + (size_t)f0 * 3 * px, img8, nf, height, width, mean, inv_std, cs));
+            TRY(conv_run(m->stem_s2d, img8, nf, h / 2, w / 2, t1, 1, 0, nullptr, 0, 0, cs, &h, &w));
+        } else {
+            TRY(dvid_prep_images_launch(images + (size_t)f0 * 3 * px, img8, nf, height, width, mean, inv_std, cs));
+            TRY(conv_run(m->stem, img8, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs, &h, &w));
+        }
         TRY(dvid_maxpool3x3s2_launch(t1, bx, nf, h, w, 64, cs));
         h = (h + 2 - 3) / 2 + 1;
         w = (w + 2 - 3) / 2 + 1;

@@ -272,6 +272,10 @@ class Model:
         """concurrent sub-batch chains inside the library (1 = sequential kernels, for per-kernel profiling)"""
         call("dvid_set_chains", self.handle, int(n))
 
+    def set_stem_layout(self, space_to_depth=True):
+        """ResNet stem over the 2x2 space-to-depth image (default) or the NHWC8 image; see dvid_set_stem_layout"""
+        call("dvid_set_stem_layout", self.handle, int(bool(space_to_depth)))
+
     def set_fusion(self, conv3_conv1=True):
         """ResNet backbone: conv3 (+ residual) -> next conv1 in one launch (csrc/c3c1.hip); same results either way"""
         call("dvid_set_fusion", self.handle, int(bool(conv3_conv1)))

@@ -87,6 +87,10 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
  * stream before returning) used by the backbone and the heads; 1 = strictly sequential kernels (profiling). */
 int dvid_set_chains(dvid_model* m, int nchain);
 
+/* ResNet stem: 1 (default) = the 7x7 / stride-2 convolution runs as a 4x4 / stride-1 convolution over the 2x2 space-to-depth image
+ * (16 channels per block, K = 256 packed columns); 0 = over the NHWC8 image (K = 448).  Same products, different summation order. */
+int dvid_set_stem_layout(dvid_model* m, int space_to_depth);
+
 /* ResNet backbone: fuse every bottleneck's conv3 (+ residual + ReLU) with the next bottleneck's conv1 (+ ReLU) into one
  * launch that keeps the block output's fp16 tile in LDS as the second product's operand (csrc/c3c1.hip).  Results are
  * bit-identical either way; off by default (measured no faster than the two tuned launches, profiles/r02_c3c1_fusion.txt). */

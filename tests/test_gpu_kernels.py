@@ -584,3 +584,47 @@ def test_backbone_conv3_conv1_fusion_bit_identical(dv, blocks, hw, n):
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(got2, ref))
     model.close()
+
+
+def test_igemm_smallc_16_channels(dv):
+    """The Cin = 16 form of the small-channel addressing (two 16-byte chunks per filter tap): a 4x4 / stride-1 / pad-2
+    convolution, the shape of the space-to-depth stem, against torch conv2d on the same fp16-rounded operands."""
+    g = torch.Generator().manual_seed(61)
+    n, h, w, cin, cout = 2, 19, 23, 16, 64
+    x = h16(torch.randn(n, cin, h, w, generator=g))
+    wt = h16(torch.randn(cout, cin, 4, 4, generator=g) * 0.1)
+    bias = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x, wt, bias, stride=1, padding=2))
+    wp, kpad = dv.pack_conv_weight(wt)
+    assert kpad == 256
+    got = dv.conv2d_nhwc(dv.nhwc_from_nchw(x.cuda()), wp.cuda(), kpad, bias.cuda(), cout, 4, 4, 1, 2, relu=True)
+    check("igemm_smallc16", dv.nchw_from_nhwc(got), ref, 2e-3, 2e-3)
+
+
+def test_stem_space_to_depth_equals_nhwc8_form(dv):
+    """The stem as a 4x4 convolution over the 2x2 space-to-depth image (default) against the 7x7 / stride-2 form over NHWC8:
+    the same fp16 products summed in another order -- last-bit flips at the fp16 stores propagate through the stages (about
+    half of the FPN values differ, by a few fp16 ulps at most), and both forms meet the oracle within the backbone tolerance (odd sizes of the padded border included: 96 x 160 and 64 x 96)."""
+    from diffusionvid_amd.utils import synthetic
+    blocks = (1, 1, 1, 1)
+    sd = synthetic.make_state_dict(0, blocks=blocks)
+    g = torch.Generator().manual_seed(62)
+    for hw in ((96, 160), (64, 96)):
+        imgs = torch.rand(3, 3, hw[0], hw[1], generator=g)
+        model = dv.Model(sd, res_blocks=blocks)
+        model.reserve(3, hw[0], hw[1], 300)
+        model.set_chains(1)
+        model.set_stem_layout(False)
+        a = [t.clone() for t in model.backbone(imgs.cuda())]
+        model.set_stem_layout(True)
+        b = model.backbone(imgs.cuda())
+        torch.cuda.synchronize()
+        mean, std = (123.675, 116.280, 103.530), (58.395, 57.120, 57.375)
+        ref = backbone_r101.backbone_r101_fpn(backbone_r101.normalizer(imgs, mean, std), sd, "backbone.", blocks)
+        for name, x, y in zip(("p3", "p4", "p5"), a, b):
+            same = (x == y).float().mean().item()
+            d = (x.float() - y.float()).abs().max().item()
+            print(f"stem layouts {hw} {name}: identical {same:.4f}, max |diff| {d:.3e}")
+            assert d < 0.05, (name, d)
+            check(f"backbone_s2d.{name}", dv.nchw_from_nhwc(y), ref[name], 3e-2, 3e-2)
+        model.close()
