@@ -1,0 +1,297 @@
+// 3x3 / stride-1 / pad-1 convolution (every bottleneck conv2 but the three strided ones, the FPN output convolutions) with the
+// A operand staged ONCE per input-channel chunk instead of once per filter tap.
+//
+// Why: in igemm2 the 256x256x32 step moves 32 KB through the global -> LDS DMA (16 KB of im2col rows + 16 KB of weights), and
+// that fill path, not the MFMA pipe, sets the pace of the long-K layers -- tools/lab/gemm_pingpong with half of the DMA pieces
+// removed runs at 1370 TFLOP/s against 866 with all of them (profiles/r02_lab_dma_ablation.txt).  A 3x3 convolution reads every
+// input pixel nine times, once per tap; here a workgroup owns an 8 x 32 patch of output pixels, stages the 10 x 34 halo of the
+// patch for 32 input channels (24 KB, pitch 36 pixels) and takes the A fragments of all nine taps from it by shifting the LDS
+// read address.  DMA per 256x256x32 step: 16 KB of weights + 24 / 9 KB of pixels = 18.7 KB instead of 32.
+//
+// Patch rows are rows of the batch laid end to end (row R = image * H + y), so a patch may straddle two images and no row of a
+// tile is wasted whatever H is (H = 38: 988 tiles per 104 frames instead of 1040 -- four rounds of the 256 CUs, not five).  One
+// 32-row MFMA block is one patch row, so "the row above / below belongs to another image (or lies outside)" is a per-fragment,
+// wave-uniform fact: such a fragment is read from a row of zeros in LDS.  Left / right borders are zero-filled by the DMA.
+//
+// K order: channel chunk outermost, then tap, then channel inside the chunk (igemm2: tap, then channel) -- the same fp16
+// products, another fp32 summation order; which of the two kernels a layer runs on is a function of its shape only (never of a
+// timing), so results stay reproducible.
+//
+// Schedule: the anti-phase schedule of igemm2 (NSTAGE 5): 8 waves, wave rows 0-3 / 4-7 alternate between a read slot R(s) (all
+// fragments of step s into registers) and an MFMA slot M(s) (the MFMAs of step s with the DMA pieces of step s + 3 between them),
+// one row a slot behind the other, one barrier per slot.  Weights: 4-stage ring of BN x 32 tiles.  Pixels: two halo buffers; the 3
+// pieces per wave of chunk c + 1 go out in the MFMA slots of taps 0, 1, 2 of chunk c.  In-order retirement makes one counted
+// s_waitcnt per read slot enough: B(s + 1) has landed when at most the pieces issued in M(s - 1) are outstanding.
+#include "common.h"
+#include "igemm_epilogue.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int TH = 8, TW = 32;                 // output patch: 8 rows of 32 pixels = 256 GEMM rows, one 32-row MFMA block per patch row
+constexpr int HH = TH + 2, HW = 36;            // halo rows / halo pitch in pixels (34 used; a multiple of 4 keeps the swizzle key a function of the column)
+constexpr int PX_BYTES = 64;                   // 32 channels of one pixel
+constexpr int A_PIECES = 24;                   // 1-KiB DMA pieces (16 pixels each) per halo chunk: 384 >= 360 pixels, 3 per wave
+constexpr int A_BUF = A_PIECES * 1024;
+constexpr int NB = 4;                          // weight ring depth
+
+template <int BN, int WN>
+struct Halo {
+    static constexpr int WM = 8 / WN;                       // waves along M
+    static constexpr int TM = 8 / WM, TN = BN / (32 * WN);  // 32x32 MFMA tiles per wave
+    static constexpr int B_STAGE = BN * PX_BYTES;
+    static constexpr int B_IT = BN / 16 / 8;                // weight pieces per wave per step
+    static constexpr int CP = BN + 4;                       // fp32 epilogue pitch
+    static constexpr int PASSES = BN > 128 ? 2 : 1;         // epilogue passes over the 256 rows
+    static constexpr int GR = 256 / PASSES;
+    static constexpr int kZRow = 2 * A_BUF + NB * B_STAGE;  // a halo row of zeros (fragments whose input row is another image's)
+    static constexpr int kRing = kZRow + HW * PX_BYTES;
+    static constexpr int kC = GR * CP * 4;
+    static constexpr int kBytes = kRing > kC ? kRing : kC;
+    static_assert(B_IT >= 1, "every wave stages at least one weight piece per step");
+};
+
+template <int BN, int WN>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(IgemmParams p, int tiles_x, int tiles_y) {
+    using C = Halo<BN, WN>;
+    constexpr int TM = C::TM, TN = C::TN, B_IT = C::B_IT, B_STAGE = C::B_STAGE, CP = C::CP;
+    constexpr int NM = TM * TN * 2;            // MFMAs per wave per step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                 // schedule phase: waves 0-3 lead, 4-7 run one slot behind (one wave of each per SIMD)
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int lid = igemm_xcd_remap((int)blockIdx.x, ntiles);
+    const int tile_n = lid % p.tiles_n;
+    const int tile_m = lid / p.tiles_n;
+    const int tx = tile_m % tiles_x, ty = tile_m / tiles_x;
+    const int r0 = ty * TH, x0 = tx * TW, n0 = tile_n * BN;          // r0: first batch row (image * H + y) of the patch
+    const int nrows = (p.M / (p.H * p.W)) * p.H;
+    const char* zero = reinterpret_cast<const char*>(g_zero16);
+    if (tid < HW * PX_BYTES / 16) *reinterpret_cast<float4v*>(smem + C::kZRow + tid * 16) = float4v{0.f, 0.f, 0.f, 0.f};   // published by the prologue barrier
+
+    // ---- halo DMA: piece q = wave + 8 i covers halo pixels [16 q, 16 q + 16); lane -> (pixel, 16-byte slot)
+    const char* a_ptr[3];
+    int a_step[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int pidx = 16 * (wave + 8 * i) + (lane >> 2);
+        const int hy = pidx / HW, hx = pidx - hy * HW;
+        const int gr = r0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = pidx < HH * HW && (unsigned)gr < (unsigned)nrows && (unsigned)gx < (unsigned)p.W;
+        const int lch = (lane & 3) ^ ((hx >> 2) & 3);          // logical channel group stored in this slot
+        a_ptr[i] = ok ? reinterpret_cast<const char*>(p.in + ((long)gr * p.W + gx) * p.Cin + lch * 8) : zero;
+        a_step[i] = ok ? PX_BYTES : 0;
+    }
+    const char* b_ptr[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = 16 * (wave + 8 * i) + (lane >> 2);
+        b_ptr[i] = reinterpret_cast<const char*>(p.w + (long)(n0 + row) * p.Kpad + ((lane & 3) ^ ((row >> 2) & 3)) * 8);
+    }
+    const int nch = p.Cin >> 5;                // channel chunks
+    char* const a_lds = smem;
+    char* const b_lds = smem + 2 * A_BUF;
+    // halo piece `i` of chunk `c` (the zero page past the last chunk: the wait counts stay the same for every step)
+    auto issue_a = [&](int c, int i) {
+        glds16(c < nch ? a_ptr[i] : zero, a_lds + (c & 1) * A_BUF + (wave + 8 * i) * 1024);
+        a_ptr[i] += a_step[i];
+    };
+    // weight pieces of step (c, tap) into ring slot (c + tap) & 3   [9 c + tap = c + tap mod 4]
+    auto issue_b = [&](int c, int tap, int i) {
+        const long koff = (long)(tap * p.Cin + c * 32) * 2;
+        glds16(c < nch ? b_ptr[i] + koff : zero, b_lds + ((c + tap) & 3) * B_STAGE + (wave + 8 * i) * 1024);
+    };
+
+    // ---- fragment addressing
+    const int frow = lane & 31;
+    int a_off[3][2];                           // [dx][ks]: halo column dx + frow inside a halo row
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int hx = dx + frow;
+            a_off[dx][ks] = hx * PX_BYTES + (((2 * ks + (lane >> 5)) ^ ((hx >> 2) & 3)) << 4);
+        }
+    // patch row wm * TM + i of this wave: is the input row above (dy = 0) / below (dy = 2) a row of the same image?
+    unsigned row_ok = 0;                       // bit 2 i: above, bit 2 i + 1: below (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int yimg = (r0 + wm * TM + i) % p.H;
+        row_ok |= (yimg > 0 ? 1u : 0u) << (2 * i) | (yimg < p.H - 1 ? 2u : 0u) << (2 * i);
+    }
+    const char* const zrow = smem + C::kZRow;
+    int b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_off[ks] = (wn * (BN / WN) + frow) * PX_BYTES + (((2 * ks + (lane >> 5)) ^ ((frow >> 2) & 3)) << 4);
+
+    float16v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: halo of chunk 0, weights of steps 0, 1, 2
+#pragma unroll
+    for (int i = 0; i < 3; ++i) issue_a(0, i);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) issue_b(0, s, i);
+    wait_vmcnt<2 * B_IT>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the zero row
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    for (int c = 0; c < nch; ++c) {
+        const char* abuf = a_lds + (c & 1) * A_BUF;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            // ---- R(s): fragments of step s = 9 c + tap
+            const char* bst = b_lds + ((c + tap) & 3) * B_STAGE;
+            half8 fa[TM][2], fb[TN][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const bool ok = dy == 1 || ((row_ok >> (2 * i + (dy >> 1))) & 1u);
+                    const char* hrow = ok ? abuf + (wm * TM + i + dy) * (HW * PX_BYTES) : zrow;
+                    fa[i][ks] = *reinterpret_cast<const half8*>(hrow + a_off[dx][ks]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j][ks] = *reinterpret_cast<const half8*>(bst + b_off[ks] + j * 32 * PX_BYTES);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // issued so far: everything up to M(s - 1); the weights of step s + 1 (and with them every older piece, the halo of
+            // the next chunk included) have landed once only the pieces of M(s - 1) are outstanding
+            if (tap >= 1 && tap <= 3) wait_vmcnt<B_IT + 1>(); else wait_vmcnt<B_IT>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- M(s): MFMAs of step s; weights of step s + 3 and, in taps 0-2, one halo piece of chunk c + 1 between them
+            const int c3 = tap < 6 ? c : c + 1, tap3 = tap < 6 ? tap + 3 : tap - 6;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                const int ks = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+                if ((q & 3) == 1) {
+                    const int k = q >> 2;
+                    if (k < B_IT) issue_b(c3, tap3, k);
+                    else if (k == B_IT && tap < 3) issue_a(c + 1, tap);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    wait_vmcnt<0>();                           // the look-ahead pieces past the last step target LDS the epilogue re-uses
+    __syncthreads();
+
+    // ---- epilogue: fp32 tile through LDS, + bias, ReLU, fp16 rows of 8 channels per thread
+    constexpr int VPR = BN / 8, ERPP = 512 / VPR, GR = C::GR, EROWS = GR / ERPP;
+    float* Cs = reinterpret_cast<float*>(smem);
+    const int c8 = (tid % VPR) * 8;
+    const int n = n0 + c8;
+    float4v b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        b_lo = *reinterpret_cast<const float4v*>(p.bias + n);
+        b_hi = *reinterpret_cast<const float4v*>(p.bias + n + 4);
+    }
+    half_t* const outp = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+    for (int pass = 0; pass < C::PASSES; ++pass) {
+        if (pass) __syncthreads();
+        if ((wm * TM * 32) / GR == pass) {
+            const int rbase = wm * TM * 32 - pass * GR;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int col = wn * (BN / WN) + j * 32 + (lane & 31);
+                        Cs[row * CP + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EROWS; ++e) {
+            const int rl = tid / VPR + e * ERPP;
+            const int r = pass * GR + rl;
+            const int gr = r0 + (r >> 5), gx = x0 + (r & 31);
+            if (gr < nrows && gx < p.W) {
+                const float* csp = Cs + rl * CP + c8;
+                float4v lo = *reinterpret_cast<const float4v*>(csp) + b_lo;
+                float4v hi = *reinterpret_cast<const float4v*>(csp + 4) + b_hi;
+                const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hi, half4);
+                half8 hv = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (p.relu) hv = __builtin_elementwise_max(hv, half8{0, 0, 0, 0, 0, 0, 0, 0});
+                *reinterpret_cast<half8*>(outp + ((long)gr * p.W + gx) * p.ldc + n) = hv;
+            }
+        }
+    }
+}
+
+template <int BN, int WN>
+int launch(IgemmParams p, hipStream_t s) {
+    using C = Halo<BN, WN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, C::kBytes));
+        attr_done = true;
+    }
+    const int tiles_x = ceil_div(p.W, TW), tiles_y = ceil_div((p.M / (p.H * p.W)) * p.H, TH);
+    p.tiles_m = tiles_x * tiles_y;
+    p.tiles_n = p.Cout / BN;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), C::kBytes, s, p, tiles_x, tiles_y);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+}  // namespace
+
+// Which launches take this kernel is decided by the layer and the image size alone -- never by a timing, and not by the number of
+// images in the launch either: the two kernels differ in fp32 summation order, and a frame's features must not depend on how many
+// frames share its launch (look-ahead groups, ragged video tails, streaming).  Rule: the layer type fits; the patch grid wastes
+// at most 1/8 of its columns (W against the next multiple of 32); the map has at least 2048 pixels.  Measured, frames of
+// 608 x 1024 (ms, this kernel vs igemm2; profiles/r02_conv3x3_halo.txt):
+//   res3 conv2 (76 x 128, 128 ch)   8 frames 0.038 / 0.044    24: 0.084 / 0.126    104: 0.336 / 0.419
+//   res4 conv2 (38 x 64, 256 ch)    8 frames 0.051 / 0.043    24: 0.069 / 0.080    104: 0.268 / 0.309     (22 layers)
+//   res5 conv2 (19 x 32, 512 ch)    8 frames 0.084 / 0.048    24: 0.098 / 0.088    104: 0.260 / 0.292     -> igemm2 (too few patches per CU
+//   FPN out p5 (19 x 32, 256 ch)    8 frames 0.046 / 0.021    24: 0.049 / 0.033    104: 0.071 / 0.095        below ~100 frames)
+//   FPN out p4 / p3                 as res4 / 8 frames 0.118 / 0.130, 104: 1.053 / 1.268
+bool dvid_conv3x3_halo_supported(const IgemmParams& p) {
+    return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.H && p.Wo == p.W && (p.Cin & 31) == 0 && p.Cin >= 64 &&
+           p.Kpad == 9 * p.Cin && (p.Cout & 127) == 0 && p.res_mode == 0 && !p.out_f32 && p.splitk <= 1 && p.relu <= 1 && (p.ldc & 7) == 0 &&
+           p.H > 0 && p.W > 0 && p.M == (p.M / (p.H * p.W)) * p.H * p.W;
+}
+
+bool dvid_conv3x3_halo_preferred(const IgemmParams& p) {
+    if (!dvid_conv3x3_halo_supported(p)) return false;
+    return ceil_div(p.W, TW) * TW * 7 <= p.W * 8 && p.H * p.W >= 2048;
+}
+
+int dvid_conv3x3_halo_launch(const IgemmParams& p, hipStream_t s) {
+    if (!dvid_conv3x3_halo_supported(p)) return DVID_ERR_UNSUPPORTED;
+    return (p.Cout & 255) == 0 ? launch<256, 4>(p, s) : launch<128, 2>(p, s);
+}

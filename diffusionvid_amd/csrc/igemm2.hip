@@ -817,9 +817,27 @@ int dvid_igemm_set_tuning(int mode) {
     return DVID_OK;
 }
 
+// 3x3 / stride-1 layers on the halo-staged kernel (conv3x3.hip): -1 = DVID_CONV3X3_HALO or on, 0 = off, 1 = on where the shape
+// rule prefers it, 2 = on wherever the layer type fits (tests)
+static int g_halo_mode = -1;
+int dvid_igemm_set_conv3x3(int mode) {
+    if (mode < -1 || mode > 2) return DVID_ERR_ARG;
+    g_halo_mode = mode;
+    return DVID_OK;
+}
+
 int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
     if (p.Kpad % 64 != 0 || p.Kpad < 64) return DVID_ERR_ARG;
+    {
+        // a function of the shape only -- never of a timing: the two kernels sum the same products in different orders.  A forced
+        // tile configuration (the bit-identity tests, experiments) means the igemm2 kernel.
+        static const int halo_env = getenv("DVID_CONV3X3_HALO") ? atoi(getenv("DVID_CONV3X3_HALO")) : 1;
+        static const int cfg_forced_env = getenv("DVID_IGEMM_CFG") ? atoi(getenv("DVID_IGEMM_CFG")) : -1;
+        const bool forced = g_forced_cfg >= 0 || (g_forced_cfg < -1 && cfg_forced_env >= 0);
+        const int halo = g_halo_mode >= 0 ? g_halo_mode : halo_env;
+        if (halo && !forced && (halo >= 2 ? dvid_conv3x3_halo_supported(p) : dvid_conv3x3_halo_preferred(p))) return dvid_conv3x3_halo_launch(p, s);
+    }
     const bool smallc = ((p.Cin == 8 || p.Cin == 16) && p.KH * p.KW > 1);
     if (!smallc && (p.Cin % 64 != 0)) return DVID_ERR_UNSUPPORTED;
     if (p.res_mode == 2 && ((p.Ho | p.Wo) & 1)) return DVID_ERR_ARG;

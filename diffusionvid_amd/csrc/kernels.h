@@ -18,6 +18,11 @@ struct IgemmParams {
 };
 int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);   // igemm2.hip: per-shape tuned tile configuration
 
+// conv3x3.hip: 3x3 / stride-1 / pad-1 layers with the input patch + halo staged once per channel chunk (all nine taps read it)
+bool dvid_conv3x3_halo_supported(const IgemmParams& p);   // the layer type fits the kernel
+bool dvid_conv3x3_halo_preferred(const IgemmParams& p);   // ... and the shape rule (patch grid waste, patches per CU) picks it
+int dvid_conv3x3_halo_launch(const IgemmParams& p, hipStream_t s);
+
 // c3c1.hip: conv3 (+ residual + ReLU) of one bottleneck fused with conv1 (+ ReLU) of the next; w3f / w1f are the two weight
 // matrices in MFMA B-fragment order (pack_frag_order in model.hip)
 struct C3C1Params {

@@ -628,3 +628,35 @@ def test_stem_space_to_depth_equals_nhwc8_form(dv):
             assert d < 0.05, (name, d)
             check(f"backbone_s2d.{name}", dv.nchw_from_nhwc(y), ref[name], 3e-2, 3e-2)
         model.close()
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 35, 64, 128, True), (3, 38, 64, 256, 256, True), (1, 8, 32, 128, 512, False),
+                                   (2, 5, 70, 192, 128, True), (1, 76, 128, 128, 128, True)])
+def test_conv3x3_halo(dv, shape):
+    """csrc/conv3x3.hip (3x3 / stride 1 / pad 1, the 8 x 32 patch's halo staged once per 32-channel chunk) against torch conv2d
+    on the same fp16-rounded operands and against the igemm2 kernel on the same launch (same products, another summation
+    order): ragged patch grids (19 x 35, 5 x 70), one-patch images, Cout of one or two 256-wide / 128-wide tiles, bias, ReLU."""
+    from diffusionvid_amd import _lib
+    lib = _lib.load()
+    n, h, w, cin, cout, relu = shape
+    g = torch.Generator().manual_seed(70 + h)
+    x = h16(torch.randn(n, cin, h, w, generator=g))
+    wt = h16(torch.randn(cout, cin, 3, 3, generator=g) * (1.5 / (9 * cin) ** 0.5))
+    bias = torch.randn(cout, generator=g) * 0.5
+    ref = F.conv2d(x, wt, bias, stride=1, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    wp, kpad = dv.pack_conv_weight(wt)
+    xn = dv.nhwc_from_nchw(x.cuda())
+    try:
+        _lib.check(lib.dvid_igemm_set_conv3x3(2), "set_conv3x3")       # 2: wherever the layer type fits, whatever the shape rule says
+        got = dv.conv2d_nhwc(xn, wp.cuda(), kpad, bias.cuda(), cout, 3, 3, 1, 1, relu=relu)
+        _lib.check(lib.dvid_igemm_set_conv3x3(0), "set_conv3x3")
+        base = dv.conv2d_nhwc(xn, wp.cuda(), kpad, bias.cuda(), cout, 3, 3, 1, 1, relu=relu)
+    finally:
+        lib.dvid_igemm_set_conv3x3(-1)
+    torch.cuda.synchronize()
+    check("conv3x3_halo", dv.nchw_from_nhwc(got), ref, 2e-3, 2e-3)
+    d = (got.float() - base.float()).abs().max().item()
+    print("halo vs igemm2: max |diff| %.3e, identical %.4f" % (d, (got == base).float().mean().item()))
+    assert d <= 4e-3 * max(1.0, ref.abs().max().item())

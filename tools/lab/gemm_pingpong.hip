@@ -55,7 +55,7 @@ constexpr int BM = 256, BN = 256, BK = 32, NSTAGE = 4;
 constexpr int STAGE = (BM + BN) * BK * 2;        // 32 KiB
 constexpr int A_BYTES = BM * BK * 2;
 
-template <bool STAGGER, bool PRIO, int RP, int ABL = 0>      // ABL (diagnostics): 1 no DMA in the loop, 2 no fragment reads; RP: DMA pieces (of 4 per tile) issued in the R slot; the rest go between the MFMAs
+template <bool STAGGER, bool PRIO, int RP, int ABL = 0>      // ABL (diagnostics): 1 no DMA in the loop, 2 no fragment reads, 4 no A pieces (B only), 8 no B pieces (A only), 16 one A piece of two; RP: DMA pieces (of 4 per tile) issued in the R slot; the rest go between the MFMAs
 __global__ __launch_bounds__(512) void gemm_pingpong(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C,
                                                      int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,15 +77,17 @@ __global__ __launch_bounds__(512) void gemm_pingpong(const half_t* __restrict__ 
         a_src[i] = reinterpret_cast<const char*>(A + (long)(m0 + row) * K + lch * 8);
         b_src[i] = reinterpret_cast<const char*>(B + (long)(n0 + row) * K + lch * 8);
     }
+    // which of the 4 pieces (0, 1: A; 2, 3: B) exist under the ablation
+    auto live = [](int pc) { return !((ABL & 4) && pc < 2) && !((ABL & 8) && pc >= 2) && !((ABL & 16) && pc == 1); };
     auto issue = [&](int t) {
         char* st = smem + (t % NSTAGE) * STAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            glds16(a_src[i] + (long)t * BK * 2, st + (wave + 8 * i) * 1024);
-            glds16(b_src[i] + (long)t * BK * 2, st + A_BYTES + (wave + 8 * i) * 1024);
+            if (live(i)) glds16(a_src[i] + (long)t * BK * 2, st + (wave + 8 * i) * 1024);
+            if (live(2 + i)) glds16(b_src[i] + (long)t * BK * 2, st + A_BYTES + (wave + 8 * i) * 1024);
         }
     };
-    constexpr int P = 4;      // DMA instructions per wave per tile
+    constexpr int P = 4 - ((ABL & 4) ? 2 : 0) - ((ABL & 8) ? 2 : 0) - ((ABL & 16) ? 1 : 0);      // DMA instructions per wave per tile
 
     // fragment addressing
     const int frow = lane & 31;
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(512) void gemm_pingpong(const half_t* __restrict__ 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
                 if (dma && (q & 3) == 1 && (q >> 2) >= RP) {          // remaining DMA pieces after MFMAs 1, 5, 9, 13
                     const int pc = q >> 2;          // 0, 1: A pieces; 2, 3: B pieces
+                    if (!live(pc)) continue;
                     if (pc < 2) glds16(a_src[pc] + (long)(t + 3) * BK * 2, dst + (wave + 8 * pc) * 1024);
                     else glds16(b_src[pc - 2] + (long)(t + 3) * BK * 2, dst + A_BYTES + (wave + 8 * (pc - 2)) * 1024);
                 }
@@ -449,10 +452,12 @@ __global__ void gemm_naive(const half_t* A, const half_t* B, float* C, int M, in
 int main() {
     const int smem = NSTAGE * STAGE;
     typedef void (*kern_t)(const half_t*, const half_t*, half_t*, int, int, int);
-    const kern_t kerns[3] = {gemm_pingpong<true, true, 0>, gemm_bdirect, gemm_pipe};
-    const char* names[3] = {"pingpong R0/M4", "bdirect", "pipe"};
-    for (int v = 0; v < 3; ++v) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    for (int v = 0; v < 3; ++v) {
+    constexpr int NV = 6;
+    const kern_t kerns[NV] = {gemm_pingpong<true, true, 0>, gemm_pingpong<true, true, 0, 16>, gemm_pingpong<true, true, 0, 4>, gemm_pingpong<true, true, 0, 8>,
+                              gemm_pingpong<true, true, 0, 1>, gemm_pingpong<true, true, 0, 3>};
+    const char* names[NV] = {"R0/M4", "3 of 4 pieces", "B pieces only", "A pieces only", "no DMA", "no DMA no reads"};
+    for (int v = 0; v < NV; ++v) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    for (int v = 0; v < NV; ++v) {
     const kern_t gemm_kernel = kerns[v];
     struct Shape { int M, N, K; };
     const Shape shapes[] = {{512, 512, 96}, {4096, 4096, 4096}, {58368, 256, 1024}, {58368, 256, 2304}, {126464, 256, 2304}};
