@@ -252,6 +252,164 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IgemmParams p, int ti
     }
 }
 
+
+// ---- 64 -> 64 channels (the res2 conv2 layers): all 64 input channels of the halo at once ----------------------------------------
+// K = 576 is too short for a channel-chunk loop, and 128 bytes per pixel make the whole 10 x 34 halo 44 KB: it is staged once, in the
+// prologue; the K loop is the nine taps (one 64-row x 64-channel weight tile each, 4-stage ring, counted vmcnt, one barrier per tap).
+// 4 waves, each 2 patch rows x 64 output channels; 76 KB of LDS, so two workgroups share a CU and cover each other's prologue and
+// epilogue.  DMA per 256-row tile: 44 + 72 KB against ~430 KB in igemm2 (im2col rows 9 x 32 KB + weights per 128 rows).  K order is
+// igemm2's (tap, then channel): results are bit-identical to it.
+constexpr int C64_HW = 34;                                  // halo pitch in pixels
+constexpr int C64_PX = 128;                                 // bytes per pixel (64 channels)
+constexpr int C64_A_PIECES = 44;                            // 8 pixels per 1-KiB piece: 352 >= 340 pixels, 11 per wave
+constexpr int C64_A = C64_A_PIECES * 1024;
+constexpr int C64_B_STAGE = 64 * C64_PX;                    // 64 output channels x 64 input channels of one tap
+constexpr int C64_CP = 68;
+constexpr int C64_BYTES = C64_A + NB * C64_B_STAGE;         // 77824 >= 256 * 68 * 4 (epilogue tile)
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(IgemmParams p, int tiles_x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = igemm_xcd_remap((int)blockIdx.x, p.tiles_m);
+    const int tx = lid % tiles_x, ty = lid / tiles_x;
+    const int r0 = ty * TH, x0 = tx * TW;
+    const int nrows = (p.M / (p.H * p.W)) * p.H;
+    const char* zero = reinterpret_cast<const char*>(g_zero16);
+    char* const a_lds = smem;
+    char* const b_lds = smem + C64_A;
+
+    // ---- prologue: the whole halo (11 pieces per wave), weights of taps 0, 1, 2 (2 pieces per wave each)
+#pragma unroll
+    for (int i = 0; i < C64_A_PIECES / 4; ++i) {
+        const int q = wave + 4 * i;
+        const int pidx = 8 * q + (lane >> 3);
+        const int hy = pidx / C64_HW, hx = pidx - hy * C64_HW;
+        const int gr = r0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = pidx < HH * C64_HW && (unsigned)gr < (unsigned)nrows && (unsigned)gx < (unsigned)p.W;
+        const int lch = (lane & 7) ^ ((hx >> 1) & 7);
+        glds16(ok ? reinterpret_cast<const char*>(p.in + ((long)gr * p.W + gx) * 64 + lch * 8) : zero, a_lds + q * 1024);
+    }
+    const char* b_ptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (wave + 4 * i) + (lane >> 3);
+        b_ptr[i] = reinterpret_cast<const char*>(p.w + (long)row * p.Kpad + ((lane & 7) ^ ((row >> 1) & 7)) * 8);
+    }
+    auto issue_b = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(b_ptr[i] + tap * 128, b_lds + (tap & 3) * C64_B_STAGE + (wave + 4 * i) * 1024);
+    };
+    issue_b(0);
+    issue_b(1);
+    issue_b(2);
+
+    // ---- fragment addressing: wave w owns patch rows 2 w, 2 w + 1 and all 64 output channels
+    const int frow = lane & 31;
+    int a_off[3][4];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int hx = dx + frow;
+            a_off[dx][ks] = hx * C64_PX + (((2 * ks + (lane >> 5)) ^ ((hx >> 1) & 7)) << 4);
+        }
+    int b_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b_off[ks] = frow * C64_PX + (((2 * ks + (lane >> 5)) ^ ((frow >> 1) & 7)) << 4);
+    unsigned row_ok = 0;                       // bit 2 i: the row above patch row 2 w + i is a row of the same image; bit 2 i + 1: the row below
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int yimg = (r0 + 2 * wave + i) % p.H;
+        row_ok |= (yimg > 0 ? 1u : 0u) << (2 * i) | (yimg < p.H - 1 ? 2u : 0u) << (2 * i);
+    }
+
+    float16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        // weights of this tap (and, at tap 0, the halo) landed; taps tap + 1, tap + 2 may stay in flight
+        if (tap <= 6) wait_vmcnt<4>(); else if (tap == 7) wait_vmcnt<2>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();            // ... for every wave; the stage of tap - 1 is no longer read
+        if (tap + 3 < 9) issue_b(tap + 3);
+        const char* bst = b_lds + (tap & 3) * C64_B_STAGE;
+        half8 fb[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j][ks] = *reinterpret_cast<const half8*>(bst + b_off[ks] + j * 32 * C64_PX);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // a row above / below that belongs to another image (or lies outside the batch) contributes nothing: wave-uniform skip
+            if (dy != 1 && !((row_ok >> (2 * i + (dy >> 1))) & 1u)) continue;
+            const char* hrow = a_lds + (2 * wave + i + dy) * (C64_HW * C64_PX);
+            half8 fa[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[ks] = *reinterpret_cast<const half8*>(hrow + a_off[dx][ks]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[j][ks], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: the 256 x 64 fp32 tile through LDS; 8 threads finish a row of 64 channels
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Cs[row * C64_CP + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+    __syncthreads();
+    const int c8 = (tid & 7) * 8;
+    float4v b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        b_lo = *reinterpret_cast<const float4v*>(p.bias + c8);
+        b_hi = *reinterpret_cast<const float4v*>(p.bias + c8 + 4);
+    }
+    half_t* const outp = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int r = (tid >> 3) + e * 32;
+        const int gr = r0 + (r >> 5), gx = x0 + (r & 31);
+        if (gr < nrows && gx < p.W) {
+            const float* csp = Cs + r * C64_CP + c8;
+            float4v lo = *reinterpret_cast<const float4v*>(csp) + b_lo;
+            float4v hi = *reinterpret_cast<const float4v*>(csp + 4) + b_hi;
+            const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hi, half4);
+            half8 hv = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+            if (p.relu) hv = __builtin_elementwise_max(hv, half8{0, 0, 0, 0, 0, 0, 0, 0});
+            *reinterpret_cast<half8*>(outp + ((long)gr * p.W + gx) * p.ldc + c8) = hv;
+        }
+    }
+}
+
+int launch_c64(IgemmParams p, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C64_BYTES));
+        attr_done = true;
+    }
+    const int tiles_x = ceil_div(p.W, TW);
+    p.tiles_m = tiles_x * ceil_div((p.M / (p.H * p.W)) * p.H, TH);
+    p.tiles_n = 1;
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(p.tiles_m), dim3(256), C64_BYTES, s, p, tiles_x);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
 template <int BN, int WN>
 int launch(IgemmParams p, hipStream_t s) {
     using C = Halo<BN, WN>;
@@ -282,7 +440,7 @@ int launch(IgemmParams p, hipStream_t s) {
 //   FPN out p4 / p3                 as res4 / 8 frames 0.118 / 0.130, 104: 1.053 / 1.268
 bool dvid_conv3x3_halo_supported(const IgemmParams& p) {
     return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.H && p.Wo == p.W && (p.Cin & 31) == 0 && p.Cin >= 64 &&
-           p.Kpad == 9 * p.Cin && (p.Cout & 127) == 0 && p.res_mode == 0 && !p.out_f32 && p.splitk <= 1 && p.relu <= 1 && (p.ldc & 7) == 0 &&
+           p.Kpad == 9 * p.Cin && ((p.Cout & 127) == 0 || (p.Cout == 64 && p.Cin == 64)) && p.res_mode == 0 && !p.out_f32 && p.splitk <= 1 && p.relu <= 1 && (p.ldc & 7) == 0 &&
            p.H > 0 && p.W > 0 && p.M == (p.M / (p.H * p.W)) * p.H * p.W;
 }
 
@@ -293,5 +451,6 @@ bool dvid_conv3x3_halo_preferred(const IgemmParams& p) {
 
 int dvid_conv3x3_halo_launch(const IgemmParams& p, hipStream_t s) {
     if (!dvid_conv3x3_halo_supported(p)) return DVID_ERR_UNSUPPORTED;
+    if (p.Cout == 64) return launch_c64(p, s);
     return (p.Cout & 255) == 0 ? launch<256, 4>(p, s) : launch<128, 2>(p, s);
 }

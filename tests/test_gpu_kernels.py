@@ -631,11 +631,13 @@ def test_stem_space_to_depth_equals_nhwc8_form(dv):
 
 
 @pytest.mark.parametrize("shape", [(2, 19, 35, 64, 128, True), (3, 38, 64, 256, 256, True), (1, 8, 32, 128, 512, False),
-                                   (2, 5, 70, 192, 128, True), (1, 76, 128, 128, 128, True)])
+                                   (2, 5, 70, 192, 128, True), (1, 76, 128, 128, 128, True),
+                                   (3, 19, 35, 64, 64, True), (1, 40, 64, 64, 64, False)])
 def test_conv3x3_halo(dv, shape):
     """csrc/conv3x3.hip (3x3 / stride 1 / pad 1, the 8 x 32 patch's halo staged once per 32-channel chunk) against torch conv2d
     on the same fp16-rounded operands and against the igemm2 kernel on the same launch (same products, another summation
-    order): ragged patch grids (19 x 35, 5 x 70), one-patch images, Cout of one or two 256-wide / 128-wide tiles, bias, ReLU."""
+    order): ragged patch grids (19 x 35, 5 x 70), one-patch images, Cout of one or two 256-wide / 128-wide tiles, bias, ReLU.
+    The 64 -> 64 channel variant (res2) keeps igemm2's K order and must equal it bit for bit."""
     from diffusionvid_amd import _lib
     lib = _lib.load()
     n, h, w, cin, cout, relu = shape
@@ -660,3 +662,5 @@ def test_conv3x3_halo(dv, shape):
     d = (got.float() - base.float()).abs().max().item()
     print("halo vs igemm2: max |diff| %.3e, identical %.4f" % (d, (got == base).float().mean().item()))
     assert d <= 4e-3 * max(1.0, ref.abs().max().item())
+    if cout == 64:
+        assert torch.equal(got, base)
