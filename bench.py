@@ -18,17 +18,18 @@ every stage is per-frame independent given the video's global memory, so the gro
 host sync; --lookahead 1 is the reference's schedule and gives the same detections (tests/test_gpu_e2e.py::test_lookahead_batches_do_not_change_results).
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel is the implicit-GEMM MFMA conv/linear kernel (igemm2_kernel<...>, ~80 % of the
-               GPU time, profiles/r01h_kernel_stats.txt).  An instrumented repeat of one step right after the timed
-               region brackets every launch with HIP events on its launch stream (sub-batch chains off, so launches
-               do not overlap) and sums durations, algorithmic FLOP (2*M*N*K) and algorithmic HBM bytes (input +
-               weights + output + residual, each once).  The bound is the lower roof at the measured intensity
-               (ridge = 2500 TFLOP/s / 8 TB/s = 312 FLOP/B, MI355X_MICROARCH.md): below the ridge
-               achieved/peak are GB/s against 8000, above it TFLOP/s against 2500; both fractions are always
-               printed (hbm_frac, mfma_frac).  traffic = measured HBM bytes per launch from the committed
-               rocprofv3 --pmc passes (tools/profile_round.sh).
-  cpu_baseline the CPU oracle (oracle/, PyTorch CPU fp32, a port of the reference path) timed on the host
-               cores of this box on ONE steady-state call of 4 frames at the same size.
+  roofline     the dominant kernels are the implicit-GEMM MFMA conv/linear kernels (igemm2_kernel<...>, and conv3x3_* for the
+               3x3 / stride-1 layers; ~80 % of the GPU time, profiles/r02_kernel_stats.txt).  An instrumented repeat of one
+               step right after the timed region brackets every such launch with HIP events on its launch stream (sub-batch
+               chains off, so launches do not overlap) and sums durations, algorithmic FLOP (2*M*N*K) and the layer-wise
+               byte model (input + weights + output + residual, each once).  bound = "mfma" (249.3 GFLOP
+               against 60-90 MB of ideal-fusion HBM traffic per frame); achieved = FLOP / summed durations against the
+               2500 TFLOP/s dense fp16 peak.  traffic = measured HBM bytes per launch from the committed rocprofv3 --pmc
+               passes (tools/profile_round.sh), labelled as coming from that profile.
+  host_fed     the same workload with the frames in pinned host memory, H2D inside the timed region.
+  other_configs  the reference call protocol without look-ahead, R101 x4, Swin-B x1 (each its own model, timed the same way).
+  cpu_baseline the CPU oracle (oracle/, PyTorch CPU fp32, a port of the reference path) timed on the host cores of this
+               box: one steady-state 8-frame call after a warm-up call, thread count chosen by a probe.
 """
 import argparse
 import ctypes
@@ -389,7 +390,7 @@ def main():
         # kFLOP/B); `achieved` = algorithmic FLOP of the launches / their summed durations.  The layer-by-layer byte model
         # (every layer's input + weights + output + residual once) and the measured traffic are printed next to it: their
         # ratio to the ideal-fusion figure is the activation round-trip traffic that fusion has yet to remove.
-        roofline = {"bound": "mfma", "kernel": "igemm2_kernel (implicit-GEMM conv/linear, fp16 MFMA)",
+        roofline = {"bound": "mfma", "kernel": "implicit-GEMM conv/linear kernels, fp16 MFMA (igemm2_kernel; conv3x3_* for the 3x3 / stride-1 layers)",
                     "achieved": round(tflops, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP16_TFLOPS, 4),
                     "traffic": traffic,
                     "traffic_source": "profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh on this "
