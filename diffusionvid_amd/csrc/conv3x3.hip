@@ -410,6 +410,138 @@ int launch_c64(IgemmParams p, hipStream_t s) {
     return DVID_OK;
 }
 
+// ---- the space-to-depth stem: 4x4 taps / stride 1 over 16 channels (32 bytes per pixel), 64 output channels -------------------------
+// (model.hip make_stem_s2d: the 7x7 / stride-2 stem over the 2x2 space-to-depth image; window rows y - 2 .. y + 1, columns x - 2 .. x + 1.)
+// One MFMA K step (16 halves) is one tap.  Per 8 x 32 patch: the 11 x 35 halo (12 KB) and all 16 taps' weights (32 KB, tap-major) are
+// staged in the prologue -- 44 KB of DMA per 256 rows against 192 KB in igemm2 -- and 48 KB of LDS put three workgroups on a CU, which
+// cover each other's prologue and epilogue.  32-byte rows: two 16-byte slots per pixel / weight row, slot = half ^ bit 3 of the
+// column (rows p and p + 8 would meet in the same banks).  K order is igemm2's (tap by tap): bit-identical.
+constexpr int S2D_HW = 35, S2D_HH = 11, S2D_PX = 32;
+constexpr int S2D_A = 16 * 1024;                            // 13 pieces of 32 pixels cover the 385 halo pixels; 16 issued (4 per wave)
+constexpr int S2D_B = 16 * 64 * S2D_PX;                     // [tap][n][32 B]
+constexpr int S2D_CP = 68;
+constexpr int S2D_BYTES = S2D_A + S2D_B;                    // 49152 >= 128 * 68 * 4 (epilogue half tile)
+
+__global__ __launch_bounds__(256) void conv4x4_s2d_kernel(IgemmParams p, int tiles_x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = igemm_xcd_remap((int)blockIdx.x, p.tiles_m);
+    const int tx0 = lid % tiles_x, ty0 = lid / tiles_x;
+    const int r0 = ty0 * TH, x0 = tx0 * TW;
+    const int nrows = (p.M / (p.H * p.W)) * p.H;
+    const char* zero = reinterpret_cast<const char*>(g_zero16);
+    char* const a_lds = smem;
+    char* const b_lds = smem + S2D_A;
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave + 4 * i;
+        const int pidx = 32 * q + (lane >> 1);
+        const int hy = pidx / S2D_HW, hx = pidx - hy * S2D_HW;
+        const int gr = r0 - 2 + hy, gx = x0 - 2 + hx;
+        const bool ok = pidx < S2D_HH * S2D_HW && (unsigned)gr < (unsigned)nrows && (unsigned)gx < (unsigned)p.W;
+        const int half = (lane & 1) ^ ((hx >> 3) & 1);
+        glds16(ok ? reinterpret_cast<const char*>(p.in + ((long)gr * p.W + gx) * 16 + half * 8) : zero, a_lds + q * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = wave + 4 * i;                         // piece: tap q >> 1, output channels 32 (q & 1) ..
+        const int n = 32 * (q & 1) + (lane >> 1);
+        const int half = (lane & 1) ^ ((n >> 3) & 1);
+        glds16(reinterpret_cast<const char*>(p.w + (long)n * p.Kpad + (q >> 1) * 16 + half * 8), b_lds + q * 1024);
+    }
+
+    const int frow = lane & 31, hsel = lane >> 5;
+    int a_off[4];
+#pragma unroll
+    for (int tx = 0; tx < 4; ++tx) a_off[tx] = (frow + tx) * S2D_PX + ((hsel ^ (((frow + tx) >> 3) & 1)) << 4);
+    const int b_off = frow * S2D_PX + ((hsel ^ ((frow >> 3) & 1)) << 4);
+    // taps ty = 0, 1 reach 2 / 1 rows up, ty = 3 one row down: rows of another image (or outside the batch) contribute nothing
+    unsigned row_ok = 0;                       // bits 4 i + ty
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int yimg = (r0 + 2 * wave + i) % p.H;
+        row_ok |= ((yimg >= 2 ? 1u : 0u) | (yimg >= 1 ? 2u : 0u) | 4u | (yimg < p.H - 1 ? 8u : 0u)) << (4 * i);
+    }
+
+    float16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    wait_vmcnt<0>();
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+        const int ty = tap >> 2, tx = tap & 3;
+        half8 fb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const half8*>(b_lds + tap * (64 * S2D_PX) + j * 32 * S2D_PX + b_off);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!((row_ok >> (4 * i + ty)) & 1u)) continue;
+            const half8 fa = *reinterpret_cast<const half8*>(a_lds + (2 * wave + i + ty) * (S2D_HW * S2D_PX) + a_off[tx]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: two half tiles of 128 rows through LDS
+    float* Cs = reinterpret_cast<float*>(smem);
+    const int c8 = (tid & 7) * 8;
+    float4v b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        b_lo = *reinterpret_cast<const float4v*>(p.bias + c8);
+        b_hi = *reinterpret_cast<const float4v*>(p.bias + c8 + 4);
+    }
+    half_t* const outp = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+        if ((wave >> 1) == pass) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wave & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        Cs[row * S2D_CP + j * 32 + (lane & 31)] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rl = (tid >> 3) + e * 32;
+            const int r = pass * 128 + rl;
+            const int gr = r0 + (r >> 5), gx = x0 + (r & 31);
+            if (gr < nrows && gx < p.W) {
+                const float* csp = Cs + rl * S2D_CP + c8;
+                float4v lo = *reinterpret_cast<const float4v*>(csp) + b_lo;
+                float4v hi = *reinterpret_cast<const float4v*>(csp + 4) + b_hi;
+                const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hi, half4);
+                half8 hv = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (p.relu) hv = __builtin_elementwise_max(hv, half8{0, 0, 0, 0, 0, 0, 0, 0});
+                *reinterpret_cast<half8*>(outp + ((long)gr * p.W + gx) * p.ldc + c8) = hv;
+            }
+        }
+    }
+}
+
+int launch_s2d(IgemmParams p, hipStream_t s) {
+    const int tiles_x = ceil_div(p.W, TW);
+    p.tiles_m = tiles_x * ceil_div((p.M / (p.H * p.W)) * p.H, TH);
+    p.tiles_n = 1;
+    hipLaunchKernelGGL(conv4x4_s2d_kernel, dim3(p.tiles_m), dim3(256), S2D_BYTES, s, p, tiles_x);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
 template <int BN, int WN>
 int launch(IgemmParams p, hipStream_t s) {
     using C = Halo<BN, WN>;
@@ -438,7 +570,14 @@ int launch(IgemmParams p, hipStream_t s) {
 //   res5 conv2 (19 x 32, 512 ch)    8 frames 0.084 / 0.048    24: 0.098 / 0.088    104: 0.260 / 0.292     -> igemm2 (too few patches per CU
 //   FPN out p5 (19 x 32, 256 ch)    8 frames 0.046 / 0.021    24: 0.049 / 0.033    104: 0.071 / 0.095        below ~100 frames)
 //   FPN out p4 / p3                 as res4 / 8 frames 0.118 / 0.130, 104: 1.053 / 1.268
+static bool s2d_stem_shape(const IgemmParams& p) {
+    return p.KH == 4 && p.KW == 4 && p.stride == 1 && p.pad == 2 && p.Ho == p.H && p.Wo == p.W && p.Cin == 16 && p.Cout == 64 && p.Kpad == 256 &&
+           p.res_mode == 0 && !p.out_f32 && p.splitk <= 1 && p.relu <= 1 && (p.ldc & 7) == 0 && p.H > 0 && p.W > 0 &&
+           p.M == (p.M / (p.H * p.W)) * p.H * p.W;
+}
+
 bool dvid_conv3x3_halo_supported(const IgemmParams& p) {
+    if (s2d_stem_shape(p)) return true;
     return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.H && p.Wo == p.W && (p.Cin & 31) == 0 && p.Cin >= 64 &&
            p.Kpad == 9 * p.Cin && ((p.Cout & 127) == 0 || (p.Cout == 64 && p.Cin == 64)) && p.res_mode == 0 && !p.out_f32 && p.splitk <= 1 && p.relu <= 1 && (p.ldc & 7) == 0 &&
            p.H > 0 && p.W > 0 && p.M == (p.M / (p.H * p.W)) * p.H * p.W;
@@ -451,6 +590,7 @@ bool dvid_conv3x3_halo_preferred(const IgemmParams& p) {
 
 int dvid_conv3x3_halo_launch(const IgemmParams& p, hipStream_t s) {
     if (!dvid_conv3x3_halo_supported(p)) return DVID_ERR_UNSUPPORTED;
+    if (s2d_stem_shape(p)) return launch_s2d(p, s);
     if (p.Cout == 64) return launch_c64(p, s);
     return (p.Cout & 255) == 0 ? launch<256, 4>(p, s) : launch<128, 2>(p, s);
 }

@@ -1354,8 +1354,10 @@ int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const
     cw.kh = kh;
     cw.kw = kw;
     cw.stride = stride;
-    cw.pad = pad;
+    cw.pad = pad < 0 ? -pad : pad;
+    cw.same_size = pad < 0;          // pad < 0: |pad| before, as many after as keep the output at the input's size (stride 1)
     cw.kpad = kpad;
+    if (pad < 0 && stride != 1) FAIL(DVID_ERR_ARG, "same-size padding needs stride 1");
     TRY(conv_run(cw, reinterpret_cast<const half_t*>(in), n, h, wd, out, relu, out_f32, residual, residual_mode, 0,
                  reinterpret_cast<hipStream_t>(stream)));
     return DVID_OK;

@@ -57,8 +57,11 @@ def conv2d_nhwc(x, w_packed, kpad, bias, cout, kh, kw, stride, pad, relu=False, 
     """x fp16 NHWC; returns NHWC fp16 (or fp32)."""
     x = _cuda(x, torch.float16)
     n, h, wd, cin = x.shape
-    ho = (h + 2 * pad - kh) // stride + 1
-    wo = (wd + 2 * pad - kw) // stride + 1
+    if pad < 0:          # same-size window: |pad| before, the rest after (stride 1)
+        ho, wo = h, wd
+    else:
+        ho = (h + 2 * pad - kh) // stride + 1
+        wo = (wd + 2 * pad - kw) // stride + 1
     out = torch.empty((n, ho, wo, cout), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
     call("dvid_conv2d_nhwc_f16", ptr(x), ptr(w_packed), ptr(bias), ptr(residual), ptr(out), n, h, wd, cin, cout, kh, kw,
          stride, pad, kpad, int(relu), int(out_f32), residual_mode, stream_ptr())

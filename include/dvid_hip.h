@@ -155,7 +155,8 @@ int dvid_cdist(const float* x, int n, int d, float* dist, void* stream);
 int dvid_fps_greedy(const float* dist, int n, int m, int bs_emul, int* idx, void* stream);
 int dvid_gather_rows(const float* x, const int* idx, float* y, int m, int d, void* stream);
 /* NHWC fp16 conv / linear (implicit GEMM on MFMA): w is [cout][kpad] fp16 with k = (ky*kw+kx)*cin + c,
- * kpad = round_up(kh*kw*cin, 64).  residual_mode: 0 none, 1 same shape, 2 nearest-x2 upsample. */
+ * kpad = round_up(kh*kw*cin, 64).  residual_mode: 0 none, 1 same shape, 2 nearest-x2 upsample.  pad < 0 (stride 1 only): |pad|
+ * rows / columns before the image and as many after as keep the output at the input's size (the space-to-depth stem's 4x4 window). */
 int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const void* residual, void* out, int n, int h,
                          int wd, int cin, int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int out_f32,
                          int residual_mode, void* stream);

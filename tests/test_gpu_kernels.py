@@ -664,3 +664,32 @@ def test_conv3x3_halo(dv, shape):
     assert d <= 4e-3 * max(1.0, ref.abs().max().item())
     if cout == 64:
         assert torch.equal(got, base)
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 35), (1, 40, 64), (3, 9, 33)])
+def test_conv4x4_s2d_stem_kernel(dv, shape):
+    """The space-to-depth stem's window (4x4 taps, stride 1, 2 rows / columns before and 1 after, 16 -> 64 channels) on
+    csrc/conv3x3.hip's conv4x4_s2d_kernel against torch (explicit asymmetric padding) and against the igemm2 small-channel path,
+    whose K order it keeps: bit-identical.  Ragged patch grids, patches straddling images."""
+    from diffusionvid_amd import _lib
+    lib = _lib.load()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(90 + h)
+    x = h16(torch.randn(n, 16, h, w, generator=g))
+    wt = h16(torch.randn(64, 16, 4, 4, generator=g) * 0.1)
+    bias = torch.randn(64, generator=g)
+    ref = F.relu(F.conv2d(F.pad(x, (2, 1, 2, 1)), wt, bias, stride=1))
+    wp, kpad = dv.pack_conv_weight(wt)
+    assert kpad == 256
+    xn = dv.nhwc_from_nchw(x.cuda())
+    try:
+        _lib.check(lib.dvid_igemm_set_conv3x3(2), "set_conv3x3")
+        got = dv.conv2d_nhwc(xn, wp.cuda(), kpad, bias.cuda(), 64, 4, 4, 1, -2, relu=True)
+        _lib.check(lib.dvid_igemm_set_conv3x3(0), "set_conv3x3")
+        base = dv.conv2d_nhwc(xn, wp.cuda(), kpad, bias.cuda(), 64, 4, 4, 1, -2, relu=True)
+    finally:
+        lib.dvid_igemm_set_conv3x3(-1)
+    torch.cuda.synchronize()
+    check("conv4x4_s2d", dv.nchw_from_nhwc(got), ref, 2e-3, 2e-3)
+    check("conv4x4_s2d.igemm2", dv.nchw_from_nhwc(base), ref, 2e-3, 2e-3)
+    assert torch.equal(got, base)
