@@ -560,16 +560,18 @@ int launch(IgemmParams p, hipStream_t s) {
 
 }  // namespace
 
-// Which launches take this kernel is decided by the layer and the image size alone -- never by a timing, and not by the number of
-// images in the launch either: the two kernels differ in fp32 summation order, and a frame's features must not depend on how many
-// frames share its launch (look-ahead groups, ragged video tails, streaming).  Rule: the layer type fits; the patch grid wastes
-// at most 1/8 of its columns (W against the next multiple of 32); the map has at least 2048 pixels.  Measured, frames of
-// 608 x 1024 (ms, this kernel vs igemm2; profiles/r02_conv3x3_halo.txt):
-//   res3 conv2 (76 x 128, 128 ch)   8 frames 0.038 / 0.044    24: 0.084 / 0.126    104: 0.336 / 0.419
-//   res4 conv2 (38 x 64, 256 ch)    8 frames 0.051 / 0.043    24: 0.069 / 0.080    104: 0.268 / 0.309     (22 layers)
-//   res5 conv2 (19 x 32, 512 ch)    8 frames 0.084 / 0.048    24: 0.098 / 0.088    104: 0.260 / 0.292     -> igemm2 (too few patches per CU
-//   FPN out p5 (19 x 32, 256 ch)    8 frames 0.046 / 0.021    24: 0.049 / 0.033    104: 0.071 / 0.095        below ~100 frames)
-//   FPN out p4 / p3                 as res4 / 8 frames 0.118 / 0.130, 104: 1.053 / 1.268
+// Which launches take these kernels is decided by the layer and the image size alone -- never by a timing, and not by the number of
+// images in the launch either: the chunked kernel differs from igemm2 in fp32 summation order, and a frame's features must not depend
+// on how many frames share its launch (look-ahead groups, ragged video tails, streaming).  Rule: the layer type fits; the patch grid
+// wastes at most 1/8 of its columns (W against the next multiple of 32); the map has at least 512 pixels.  (The 256- / 128-wide
+// weight tile of the chunked kernel IS chosen by launch size: both sum in the same order.)  Measured, frames of 608 x 1024
+// (ms, these kernels / igemm2; profiles/r02_conv3x3_halo.txt):
+//   res2 conv2 (152 x 256, 64 ch)   8 frames 0.033 / 0.049                         104: 0.381 / 0.615
+//   res3 conv2 (76 x 128, 128 ch)   8 frames 0.037 / 0.043    24: 0.084 / 0.126    104: 0.336 / 0.419
+//   res4 conv2 (38 x 64, 256 ch)    8 frames 0.031 / 0.044    24: 0.069 / 0.081    104: 0.268 / 0.309     (22 layers)
+//   res5 conv2 (19 x 32, 512 ch)    8 frames 0.048 / 0.048    24: 0.066 / 0.087    104: 0.260 / 0.292
+//   FPN out p5 (19 x 32, 256 ch)    8 frames 0.026 / 0.020    24: 0.029 / 0.034    104: 0.071 / 0.093
+//   FPN out p4 / p3                 as res4 / 8 frames 0.113 / 0.124, 104: 1.053 / 1.268
 static bool s2d_stem_shape(const IgemmParams& p) {
     return p.KH == 4 && p.KW == 4 && p.stride == 1 && p.pad == 2 && p.Ho == p.H && p.Wo == p.W && p.Cin == 16 && p.Cout == 64 && p.Kpad == 256 &&
            p.res_mode == 0 && !p.out_f32 && p.splitk <= 1 && p.relu <= 1 && (p.ldc & 7) == 0 && p.H > 0 && p.W > 0 &&
@@ -585,12 +587,15 @@ bool dvid_conv3x3_halo_supported(const IgemmParams& p) {
 
 bool dvid_conv3x3_halo_preferred(const IgemmParams& p) {
     if (!dvid_conv3x3_halo_supported(p)) return false;
-    return ceil_div(p.W, TW) * TW * 7 <= p.W * 8 && p.H * p.W >= 2048;
+    return ceil_div(p.W, TW) * TW * 7 <= p.W * 8 && p.H * p.W >= 512;
 }
 
 int dvid_conv3x3_halo_launch(const IgemmParams& p, hipStream_t s) {
     if (!dvid_conv3x3_halo_supported(p)) return DVID_ERR_UNSUPPORTED;
     if (s2d_stem_shape(p)) return launch_s2d(p, s);
     if (p.Cout == 64) return launch_c64(p, s);
-    return (p.Cout & 255) == 0 ? launch<256, 4>(p, s) : launch<128, 2>(p, s);
+    // 256-wide or 128-wide weight tiles: the same K order, bit-identical results -- so this choice may look at the launch size.  With
+    // fewer 256-wide workgroups than half the CUs (8 frames of 608 x 1024 at res4: 76) the narrower tile doubles the workgroups.
+    const long patches = (long)ceil_div(p.W, TW) * ceil_div(p.M / p.W, TH);
+    return ((p.Cout & 255) == 0 && patches * (p.Cout >> 8) > 128) ? launch<256, 4>(p, s) : launch<128, 2>(p, s);
 }

@@ -196,7 +196,7 @@ int dvid_igemm_set_tuning(int mode);
 /* 3x3 / stride-1 / pad-1 convolutions with Cin % 32 == 0 and Cout % 128 == 0 (the bottleneck conv2 layers of res3-res5, the FPN
  * output convolutions) on the halo-staged kernel (csrc/conv3x3.hip: the 8 x 32 output patch's input pixels are staged once per
  * 32-channel chunk and serve all nine taps): 1 = on where the shape rule prefers it (W within 1/8 of a multiple of 32, maps of at least
- * 2048 pixels -- a function of the layer and the image size, not of the number of frames in the launch), 2 = on wherever the layer type fits (tests), 0 = off (the igemm2 kernel), -1 = follow DVID_CONV3X3_HALO
+ * 512 pixels -- a function of the layer and the image size, not of the number of frames in the launch), 2 = on wherever the layer type fits (tests), 0 = off (the igemm2 kernel), -1 = follow DVID_CONV3X3_HALO
  * (default 1).  The choice depends on the layer's shape only; the two kernels differ in fp32 summation order. */
 int dvid_igemm_set_conv3x3(int mode);
 
