@@ -19,6 +19,8 @@
 //   "bdirect": B fragments global -> VGPR, only A by DMA   789 | 589 | 569     (fragment-shaped loads are dear)
 //   all DMA pieces in the R slot after its reads         1023 | 740 | 820
 //   same loop with the DMA removed (garbage results)     1557 | 973 | 1272
+//   round 2: pieces removed -- 3 of 4: 1080, weights only: 1369, A only: 1125 (profiles/r02_lab_dma_ablation.txt); buffer-addressed
+//   DMA (raw_ptr_buffer_load_lds, K step in the scalar offset) instead of global_load_lds: 892 vs 895 -- no difference
 // i.e. the global -> LDS DMA of the two operands costs ~0.25 us per 256x256x32 step wherever its instructions are placed
 // (between MFMAs, in the read slot, after the reads), and that is what separates this structure from ~1.5 PFLOP/s.  (igemm2's 256x256x64/2: 806 | 719 | 811-873.)
 //
@@ -51,6 +53,12 @@ __device__ __forceinline__ void glds16(const void* g, char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// buffer-addressed variant of the DMA: resource descriptor + 32-bit per-lane offset + scalar offset (the K step) -- no 64-bit
+// address arithmetic per piece, hardware range check
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
+
 constexpr int BM = 256, BN = 256, BK = 32, NSTAGE = 4;
 constexpr int STAGE = (BM + BN) * BK * 2;        // 32 KiB
 constexpr int A_BYTES = BM * BK * 2;
@@ -78,11 +86,25 @@ __global__ __launch_bounds__(512) void gemm_pingpong(const half_t* __restrict__ 
         b_src[i] = reinterpret_cast<const char*>(B + (long)(n0 + row) * K + lch * 8);
     }
     // which of the 4 pieces (0, 1: A; 2, 3: B) exist under the ablation
+    constexpr bool BUF = (ABL & 32) != 0;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(A), 0, (int)((long)M * K * 2 > 0x7fffffffL ? 0x7fffffff : (long)M * K * 2), 0x00027000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(B), 0, (int)((long)N * K * 2), 0x00027000);
+    int a_vo[2], b_vo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_vo[i] = (int)(a_src[i] - reinterpret_cast<const char*>(A));
+        b_vo[i] = (int)(b_src[i] - reinterpret_cast<const char*>(B));
+    }
     auto live = [](int pc) { return !((ABL & 4) && pc < 2) && !((ABL & 8) && pc >= 2) && !((ABL & 16) && pc == 1); };
     auto issue = [&](int t) {
         char* st = smem + (t % NSTAGE) * STAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (BUF) {
+                blds16(ra, a_vo[i], t * BK * 2, st + (wave + 8 * i) * 1024);
+                blds16(rb, b_vo[i], t * BK * 2, st + A_BYTES + (wave + 8 * i) * 1024);
+                continue;
+            }
             if (live(i)) glds16(a_src[i] + (long)t * BK * 2, st + (wave + 8 * i) * 1024);
             if (live(2 + i)) glds16(b_src[i] + (long)t * BK * 2, st + A_BYTES + (wave + 8 * i) * 1024);
         }
@@ -154,6 +176,11 @@ __global__ __launch_bounds__(512) void gemm_pingpong(const half_t* __restrict__ 
                 if (dma && (q & 3) == 1 && (q >> 2) >= RP) {          // remaining DMA pieces after MFMAs 1, 5, 9, 13
                     const int pc = q >> 2;          // 0, 1: A pieces; 2, 3: B pieces
                     if (!live(pc)) continue;
+                    if (BUF) {
+                        if (pc < 2) blds16(ra, a_vo[pc], (t + 3) * BK * 2, dst + (wave + 8 * pc) * 1024);
+                        else blds16(rb, b_vo[pc - 2], (t + 3) * BK * 2, dst + A_BYTES + (wave + 8 * (pc - 2)) * 1024);
+                        continue;
+                    }
                     if (pc < 2) glds16(a_src[pc] + (long)(t + 3) * BK * 2, dst + (wave + 8 * pc) * 1024);
                     else glds16(b_src[pc - 2] + (long)(t + 3) * BK * 2, dst + A_BYTES + (wave + 8 * (pc - 2)) * 1024);
                 }
@@ -452,10 +479,10 @@ __global__ void gemm_naive(const half_t* A, const half_t* B, float* C, int M, in
 int main() {
     const int smem = NSTAGE * STAGE;
     typedef void (*kern_t)(const half_t*, const half_t*, half_t*, int, int, int);
-    constexpr int NV = 6;
-    const kern_t kerns[NV] = {gemm_pingpong<true, true, 0>, gemm_pingpong<true, true, 0, 16>, gemm_pingpong<true, true, 0, 4>, gemm_pingpong<true, true, 0, 8>,
+    constexpr int NV = 7;
+    const kern_t kerns[NV] = {gemm_pingpong<true, true, 0>, gemm_pingpong<true, true, 0, 32>, gemm_pingpong<true, true, 0, 16>, gemm_pingpong<true, true, 0, 4>, gemm_pingpong<true, true, 0, 8>,
                               gemm_pingpong<true, true, 0, 1>, gemm_pingpong<true, true, 0, 3>};
-    const char* names[NV] = {"R0/M4", "3 of 4 pieces", "B pieces only", "A pieces only", "no DMA", "no DMA no reads"};
+    const char* names[NV] = {"R0/M4", "R0/M4 buffer-addr", "3 of 4 pieces", "B pieces only", "A pieces only", "no DMA", "no DMA no reads"};
     for (int v = 0; v < NV; ++v) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     for (int v = 0; v < NV; ++v) {
     const kern_t gemm_kernel = kerns[v];
