@@ -826,9 +826,25 @@ int dvid_igemm_set_conv3x3(int mode) {
     return DVID_OK;
 }
 
+// short-K / wide-N 1x1 layers on the weight-stationary kernel (wstat.hip): -1 = DVID_WSTAT or on, 0 = off, 1 = on where the shape rule
+// prefers it, 2 = on wherever the layer type fits (tests).  Bit-identical to igemm2, so the rule may look at the row count.
+static int g_wstat_mode = -1;
+int dvid_igemm_set_wstat(int mode) {
+    if (mode < -1 || mode > 2) return DVID_ERR_ARG;
+    g_wstat_mode = mode;
+    return DVID_OK;
+}
+
 int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
     if (p.Kpad % 64 != 0 || p.Kpad < 64) return DVID_ERR_ARG;
+    {
+        static const int ws_env = getenv("DVID_WSTAT") ? atoi(getenv("DVID_WSTAT")) : 1;
+        static const int cfg_forced_env0 = getenv("DVID_IGEMM_CFG") ? atoi(getenv("DVID_IGEMM_CFG")) : -1;
+        const bool forced = g_forced_cfg >= 0 || (g_forced_cfg < -1 && cfg_forced_env0 >= 0);
+        const int ws = g_wstat_mode >= 0 ? g_wstat_mode : ws_env;
+        if (ws && !forced && (ws >= 2 ? dvid_wstat_supported(p) : dvid_wstat_preferred(p))) return dvid_wstat_launch(p, s);
+    }
     {
         // a function of the shape only -- never of a timing: the two kernels sum the same products in different orders.  A forced
         // tile configuration (the bit-identity tests, experiments) means the igemm2 kernel.

@@ -23,6 +23,11 @@ bool dvid_conv3x3_halo_supported(const IgemmParams& p);   // the layer type fits
 bool dvid_conv3x3_halo_preferred(const IgemmParams& p);   // ... and the shape rule (patch grid waste, patches per CU) picks it
 int dvid_conv3x3_halo_launch(const IgemmParams& p, hipStream_t s);
 
+// wstat.hip: short-K / wide-N 1x1 layers with the weights stationary in registers (bit-identical to igemm2)
+bool dvid_wstat_supported(const IgemmParams& p);
+bool dvid_wstat_preferred(const IgemmParams& p);
+int dvid_wstat_launch(const IgemmParams& p, hipStream_t s);
+
 // c3c1.hip: conv3 (+ residual + ReLU) of one bottleneck fused with conv1 (+ ReLU) of the next; w3f / w1f are the two weight
 // matrices in MFMA B-fragment order (pack_frag_order in model.hip)
 struct C3C1Params {

@@ -1,0 +1,269 @@
+// Weight-stationary kernel for the short-K, wide-N 1x1 convolutions / linear layers (bottleneck conv3 + residual + ReLU:
+// K = 128 / 256 / 512 -> N = 512 / 1024 / 2048; the decoder's dynamic_layer: K = 256 -> N = 32768; linear1: 256 -> 2048).
+//
+// These layers move ~4.6 KB of HBM per output row and need ~12 % of the MFMA peak at the HBM rate; tiled as independent
+// 128 x 128 workgroups (igemm2) a tile lives ~19 us for 8 K steps -- every tile re-stages its A rows AND the same weight
+// rows through the global -> LDS path (4 bytes of DMA per output byte at K = 256), pays a first-load latency and an fp32
+// LDS round trip for its epilogue, and the launch ends at 2.9 TB/s (profiles/r02_igemm_vs_vendor_b104.txt).  Here the
+// WEIGHTS do not move at all: a workgroup of 8 waves owns a slab of 256 output channels, wave w keeps the [32 x K] weight rows of
+// its 32 channels in VGPRs as MFMA operands (K / 4 registers) for the whole launch, and the workgroup streams its range of
+// output rows through a ring of [32 x K] A tiles (DMA, 0.5 byte per output byte at K = 256).  The product is computed transposed
+// (D[n][m] = W A^T: the weights are the MFMA's first operand), so a lane ends up with channels of ONE output row; after a
+// v_permlane32_swap per register pair it holds 2 x 8 consecutive channels -> residual and output move as 16-byte pieces
+// straight from / to the accumulator layout, no fp32 LDS pass, no second barrier.  The residual rides the same DMA ring (each wave
+// fetches the 2 x 1 KiB it will read back lane-linearly), so the only waits are one counted `vmcnt` + one barrier per 32 rows.
+// One persistent workgroup per CU (256); XCD x owns rows [x M / 8, (x + 1) M / 8) so the slabs that read the same A rows share an L2.
+//
+// Same MFMA, same K order (ascending, 16 per instruction) and the same epilogue arithmetic as igemm2 (fp32: + bias, + residual; round
+// to fp16; ReLU): results are bit-identical to it (tests/test_gpu_kernels.py::test_wstat_matches_igemm2), so which of the two a
+// launch runs on never changes a value.
+#include <stdlib.h>
+
+#include "../../include/dvid_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page_ws[4] = {0u, 0u, 0u, 0u};
+
+template <int N>
+__device__ __forceinline__ void ws_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void ws_glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int kWsWaves = 8;
+constexpr int kWsSlab = 32 * kWsWaves;      // output channels per workgroup
+
+template <int K, int D>
+struct WsSmem {
+    static constexpr int kAStage = 32 * K * 2;
+    static constexpr int kRStage = kWsWaves * 2048;
+    static constexpr int kBytes = D * (kAStage + kRStage);
+};
+
+// K: reduction length (= Cin = Kpad); D: ring depth (tiles t .. t + D - 2 in flight while tile t is computed); HAS_RES: same-shape
+// fp16 residual.  Grid: 256 workgroups x 512 threads.
+template <int K, int D, bool HAS_RES>
+__global__ __launch_bounds__(64 * kWsWaves) void wstat_kernel(IgemmParams p, int nslab) {
+    constexpr int NW = kWsWaves;
+    constexpr int CH = K / 8;                     // 16-byte chunks per A row
+    constexpr int RPP = (K >= 512) ? 1 : 512 / K; // A rows per 1-KiB DMA piece
+    constexpr int PIECES = 32 / RPP;              // A pieces per tile
+    constexpr int APW = PIECES / NW;              // ... per wave
+    constexpr int RP = HAS_RES ? 2 : 0;           // residual pieces per wave per tile
+    constexpr int LG = APW + RP;                  // DMA instructions per wave per tile
+    constexpr int KS = K / 16;
+    constexpr int A_STAGE = WsSmem<K, D>::kAStage;
+    constexpr int R_STAGE = WsSmem<K, D>::kRStage;
+    static_assert(PIECES % NW == 0 && APW >= 1, "every wave issues the same number of A pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const a_ring = smem;
+    char* const r_ring = smem + D * A_STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lrow = lane & 31;
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page_ws);
+
+    // ---- rows of this workgroup: XCD x (= blockIdx % 8 under round-robin dispatch) owns an eighth of the 32-row blocks; inside it
+    // the 32 workgroups are (sub-range, slab) pairs, or -- more than 32 slabs -- each walks slabs q, q + 32, ... over the whole eighth
+    const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+    const int MB = (p.M + 31) >> 5;
+    const int xb0 = (int)((long)MB * xcd / 8), xb1 = (int)((long)MB * (xcd + 1) / 8);
+    int blk0 = xb0, blk1 = xb1, slab0 = q, slab_step = 32;
+    if (nslab <= 32) {
+        const int nsub = 32 / nslab, sub = q / nslab;
+        slab0 = q - sub * nslab;
+        slab_step = nslab;                       // one slab per workgroup
+        blk0 = xb0 + (int)((long)(xb1 - xb0) * sub / nsub);
+        blk1 = xb0 + (int)((long)(xb1 - xb0) * (sub + 1) / nsub);
+    }
+    const int T = blk1 - blk0;
+    if (T <= 0) return;                          // workgroup-uniform
+
+    // ---- A pieces: piece j = wave + NW * i covers tile rows [RPP j, RPP j + RPP); lane -> (row, physical chunk).  The LDS image is
+    // lane-linear; the XOR swizzle (key = row & 15) is applied to the SOURCE chunk and again on the fragment read.
+    const char* a_src[APW];
+    int a_rowm[APW];                             // global row of this lane's piece row in tile 0
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int piece = wave + NW * i;
+        const int row = piece * RPP + (CH >= 64 ? 0 : lane / CH);
+        const int pch = lane % CH;
+        const int lch = pch ^ (row & 15);
+        a_rowm[i] = blk0 * 32 + row;
+        a_src[i] = reinterpret_cast<const char*>(p.in) + ((long)a_rowm[i] * K + lch * 8) * 2;
+    }
+    const int frag_key = lrow & 15;
+    const int frag_row_off = lrow * (K * 2);
+
+    for (int slab = slab0; slab < nslab; slab += slab_step) {
+        const int n0 = slab * kWsSlab + 32 * wave;            // first channel of this wave
+        // ---- weights of this wave's 32 channels as MFMA first operands: lane -> (channel n0 + lane % 32, k = 16 ks + 8 (lane / 32))
+        half8 bf[KS];
+        {
+            const half_t* wrow = p.w + (long)(n0 + lrow) * p.Kpad + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bf[ks] = *reinterpret_cast<const half8*>(wrow + 16 * ks);
+        }
+        // bias of the channels this lane finishes: group g = channels n0 + 16 g + 8 hi + [0, 8)
+        float bs[2][8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bs[g][e] = p.bias ? p.bias[n0 + 16 * g + 8 * hi + e] : 0.f;
+        // residual / output element offsets of this lane's row in tile 0, group 0
+        const long col = n0 + 8 * hi;
+        const char* r_src = HAS_RES ? reinterpret_cast<const char*>(p.res) + ((long)(blk0 * 32 + lrow) * p.Cout + col) * 2 : zero;
+        half_t* o_dst = reinterpret_cast<half_t*>(p.out) + (long)(blk0 * 32 + lrow) * p.ldc + col;
+        const char* a_cur[APW];
+#pragma unroll
+        for (int i = 0; i < APW; ++i) a_cur[i] = a_src[i];
+
+        // the ordinary loads above are complete before the first DMA is issued (the compiler would otherwise wait vmcnt(0) at their
+        // first use, with the prologue's DMA in flight), and no wave still reads the previous slab's last tiles
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bf[ks]));
+        __builtin_amdgcn_s_barrier();
+
+        // DMA of tile `ti` (A pieces, then this wave's residual pieces) into stage ti % D; past the range: zero page (same count)
+        auto issue = [&](int ti) {
+            const int st = ti % D;
+            const bool live = ti < T;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const bool ok = live && a_rowm[i] + ti * 32 < p.M;
+                const char* src = ok ? a_cur[i] : zero;
+                asm volatile("" : "+v"(src));        // one DMA instruction per piece whatever the lanes' sources (the waits count them)
+                ws_glds16(src, a_ring + st * A_STAGE + (wave + NW * i) * 1024);
+                a_cur[i] += 32 * K * 2;
+            }
+            if (HAS_RES) {
+                const bool ok = live && (blk0 + ti) * 32 + lrow < p.M;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const char* src = ok ? r_src + 32 * g : zero;
+                    asm volatile("" : "+v"(src));
+                    ws_glds16(src, r_ring + st * R_STAGE + (wave * 2 + g) * 1024);
+                }
+                r_src += (long)32 * p.Cout * 2;
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) issue(d);
+
+        for (int t = 0; t < T; ++t) {
+            // own pieces of tile t have landed.  Issued after them: the loads of tiles t + 1 .. t + D - 2 and the stores of the last
+            // (up to) D - 1 steps; vmcnt retires in issue order.
+            if (t >= D - 1) ws_wait_vmcnt<(D - 2) * LG + (D - 1) * 2>();
+            else ws_wait_vmcnt<(D - 2) * LG>();
+            __builtin_amdgcn_s_barrier();        // tile t visible to every wave; nobody reads tile t - 1 any more
+            asm volatile("" ::: "memory");
+            issue(t + D - 1);                    // into the stage of tile t - 1
+
+            const int st = t % D;
+            const char* at = a_ring + st * A_STAGE + frag_row_off;
+            float16v acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // all fragment reads of the tile are issued up front (KS x 4 registers), the MFMA chain follows them with counted lgkmcnt
+            half8 fa[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) fa[ks] = *reinterpret_cast<const half8*>(at + (((2 * ks + hi) ^ frag_key) * 16));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], fa[ks], acc, 0, 0, 0);
+            // ---- epilogue from the accumulator layout.  acc[4 r4 + r] = channel 8 r4 + 4 hi + r of row lane % 32; one half-wave
+            // exchange per register pair (r4, r4 + 1) leaves lane < 32 with channels 16 g + [0, 8) and lane >= 32 with 16 g + 8 + [0, 8).
+            unsigned int u[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = acc[r];          // (a bit_cast of the vector element itself reads element 0 whatever r is)
+                u[r] = __float_as_uint(f);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(u[8 * g + r], u[8 * g + 4 + r], false, false);
+                    u[8 * g + r] = sw[0];
+                    u[8 * g + 4 + r] = sw[1];
+                }
+            const bool row_ok = (blk0 + t) * 32 + lrow < p.M;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float4v lo, hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = __uint_as_float(u[8 * g + e]) + bs[g][e];
+                    hv[e] = __uint_as_float(u[8 * g + 4 + e]) + bs[g][4 + e];
+                }
+                if (HAS_RES) {
+                    const half8 rv = *reinterpret_cast<const half8*>(r_ring + st * R_STAGE + (wave * 2 + g) * 1024 + lane * 16);
+                    lo += __builtin_convertvector(__builtin_shufflevector(rv, rv, 0, 1, 2, 3), float4v);
+                    hv += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
+                }
+                const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
+                half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (p.relu) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
+                if (row_ok) *reinterpret_cast<half8*>(o_dst + 16 * g) = o;
+            }
+            o_dst += (long)32 * p.ldc;
+        }
+        // the tail's zero-page DMAs and this slab's residual reads retire before the next slab's prologue re-uses the stages
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <int K, int D, bool HAS_RES>
+int ws_launch_k(const IgemmParams& p, int nslab, hipStream_t s) {
+    constexpr int smem = WsSmem<K, D>::kBytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat_kernel<K, D, HAS_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wstat_kernel<K, D, HAS_RES>), dim3(256), dim3(64 * kWsWaves), smem, s, p, nslab);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+}  // namespace
+
+// the layer type fits: 1x1 / linear over contiguous rows, K in {128, 256}, N a multiple of 256 with the slab count dividing (or a
+// multiple of) the 32 workgroups of an XCD, fp16 out, bias / ReLU / same-shape fp16 residual
+bool dvid_wstat_supported(const IgemmParams& p) {
+    if (p.ntaps != 1 || p.pad != 0 || p.stride != 1 || p.Ho != p.H || p.Wo != p.W) return false;
+    if (p.Cin != p.Kpad || (p.Kpad != 128 && p.Kpad != 256)) return false;
+    if (p.Cout % kWsSlab) return false;
+    const int ns = p.Cout / kWsSlab;
+    if (!(ns <= 32 ? 32 % ns == 0 : ns % 32 == 0)) return false;
+    if (p.out_f32 || p.splitk > 1 || p.relu > 1 || (p.ldc & 7)) return false;
+    if (p.res_mode > 1 || (p.res_mode == 1 && p.res_f32)) return false;
+    return true;
+}
+
+// ... and the launch is large enough for 256 persistent workgroups: every workgroup streams at least 24 row blocks per weight load
+bool dvid_wstat_preferred(const IgemmParams& p) {
+    if (!dvid_wstat_supported(p)) return false;
+    const int ns = p.Cout / kWsSlab;
+    const long blocks_per_xcd = ((long)p.M + 31) / 32 / 8;
+    const long per_wg = ns <= 32 ? blocks_per_xcd / (32 / ns) : blocks_per_xcd;
+    return per_wg >= 24;
+}
+
+int dvid_wstat_launch(const IgemmParams& p, hipStream_t s) {
+    if (!dvid_wstat_supported(p)) return DVID_ERR_UNSUPPORTED;
+    const int ns = p.Cout / kWsSlab;
+    const bool res = p.res_mode == 1;
+    switch (p.Kpad) {
+        case 128: return res ? ws_launch_k<128, 6, true>(p, ns, s) : ws_launch_k<128, 6, false>(p, ns, s);
+        default: return res ? ws_launch_k<256, 4, true>(p, ns, s) : ws_launch_k<256, 4, false>(p, ns, s);
+    }
+}

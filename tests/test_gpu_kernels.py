@@ -693,3 +693,41 @@ def test_conv4x4_s2d_stem_kernel(dv, shape):
     check("conv4x4_s2d", dv.nchw_from_nhwc(got), ref, 2e-3, 2e-3)
     check("conv4x4_s2d.igemm2", dv.nchw_from_nhwc(base), ref, 2e-3, 2e-3)
     assert torch.equal(got, base)
+
+
+@pytest.mark.parametrize("shape", [(8 * 32 * 40 + 13, 256, 1024, True, True), (5000, 128, 512, True, True), (70001, 256, 2048, False, True),
+                                   (3000, 256, 8192, False, False), (2400, 256, 32768, False, False), (31, 256, 256, True, False),
+                                   (9000, 128, 256, True, True), (40000, 256, 256, False, True)])
+def test_wstat_matches_igemm2(dv, shape):
+    """csrc/wstat.hip (weights stationary in registers, rows streamed through a DMA ring, epilogue from the accumulator layout)
+    against torch on the same fp16-rounded operands and against igemm2 on the same launch -- bit for bit: same MFMA, same K
+    order, same epilogue arithmetic.  Row counts that are not a multiple of 32, launches with idle workgroups (31 rows), one
+    slab per workgroup (N 256 .. 8192) and several (N 32768), with / without residual, bias, ReLU."""
+    from diffusionvid_amd import _lib
+    lib = _lib.load()
+    m, k, n, res, relu = shape
+    g = torch.Generator().manual_seed(m + n)
+    x = h16(torch.randn(m, k, generator=g))
+    wt = h16(torch.randn(n, k, generator=g) * (1.5 / k ** 0.5))
+    bias = torch.randn(n, generator=g) * 0.5
+    r = h16(torch.randn(m, n, generator=g)) if res else None
+    ref = x @ wt.t() + bias
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    wp, kpad = dv.pack_conv_weight(wt)
+    xd = x.to(torch.float16).cuda().view(m, 1, 1, k)
+    rd = r.to(torch.float16).cuda().view(m, 1, 1, n) if res else None
+    try:
+        _lib.check(lib.dvid_igemm_set_wstat(2), "set_wstat")           # 2: wherever the layer type fits, whatever the size rule says
+        got = dv.conv2d_nhwc(xd, wp.cuda(), kpad, bias.cuda(), n, 1, 1, 1, 0, relu=relu, residual=rd, residual_mode=1 if res else 0)
+        _lib.check(lib.dvid_igemm_set_wstat(0), "set_wstat")
+        base = dv.conv2d_nhwc(xd, wp.cuda(), kpad, bias.cuda(), n, 1, 1, 1, 0, relu=relu, residual=rd, residual_mode=1 if res else 0)
+    finally:
+        lib.dvid_igemm_set_wstat(-1)
+    torch.cuda.synchronize()
+    check("wstat", got.view(m, n), ref, 2e-3, 2e-3)
+    same = (got == base).float().mean().item()
+    print("wstat vs igemm2: identical %.6f, max |diff| %.3e" % (same, (got.float() - base.float()).abs().max().item()))
+    assert torch.equal(got, base)
