@@ -26,6 +26,7 @@
 namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_ws[4] = {0u, 0u, 0u, 0u};
+__device__ __attribute__((aligned(16))) unsigned int g_dump_ws[64 * 4];      // where the lanes of rows past M store (one 16-byte slot per lane)
 
 template <int N>
 __device__ __forceinline__ void ws_wait_vmcnt() {
@@ -36,34 +37,35 @@ __device__ __forceinline__ void ws_glds16(const void* gsrc, char* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-constexpr int kWsWaves = 8;
-constexpr int kWsSlab = 32 * kWsWaves;      // output channels per workgroup
-
-template <int K, int D>
+template <int K, int D, int TPS, int NW>
 struct WsSmem {
-    static constexpr int kAStage = 32 * K * 2;
-    static constexpr int kRStage = kWsWaves * 2048;
-    static constexpr int kBytes = D * (kAStage + kRStage);
+    static constexpr int kATile = 32 * K * 2;
+    static constexpr int kRTile = NW * 2048;
+    static constexpr int kStage = TPS * (kATile + kRTile);
+    static constexpr int kBytes = D * kStage;
 };
 
-// K: reduction length (= Cin = Kpad); D: ring depth (tiles t .. t + D - 2 in flight while tile t is computed); HAS_RES: same-shape
-// fp16 residual.  Grid: 256 workgroups x 512 threads.
-template <int K, int D, bool HAS_RES>
-__global__ __launch_bounds__(64 * kWsWaves) void wstat_kernel(IgemmParams p, int nslab) {
-    constexpr int NW = kWsWaves;
+// K: reduction length (= Cin = Kpad); TPS: 32-row tiles per step (one counted wait + one barrier per step; the TPS MFMA chains of a
+// wave are independent and issue interleaved); D: ring depth in steps (steps s + 1 .. s + D - 1 in flight while step s is computed);
+// HAS_RES: same-shape fp16 residual; RELU.  Grid: 256 workgroups x 512 threads.
+template <int K, int D, int TPS, int NW, bool HAS_RES, bool RELU>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, int nslab) {
+    constexpr int WPX = 256 / NW;                 // workgroups per XCD: 8 waves -> one workgroup per CU, 4 waves -> two
+    constexpr int SLAB = 32 * NW;                 // output channels per workgroup
     constexpr int CH = K / 8;                     // 16-byte chunks per A row
     constexpr int RPP = (K >= 512) ? 1 : 512 / K; // A rows per 1-KiB DMA piece
     constexpr int PIECES = 32 / RPP;              // A pieces per tile
     constexpr int APW = PIECES / NW;              // ... per wave
     constexpr int RP = HAS_RES ? 2 : 0;           // residual pieces per wave per tile
-    constexpr int LG = APW + RP;                  // DMA instructions per wave per tile
+    constexpr int LG = TPS * (APW + RP);          // DMA instructions per wave per step
+    constexpr int SG = TPS * 2;                   // store instructions per wave per step
     constexpr int KS = K / 16;
-    constexpr int A_STAGE = WsSmem<K, D>::kAStage;
-    constexpr int R_STAGE = WsSmem<K, D>::kRStage;
+    constexpr int A_TILE = WsSmem<K, D, TPS, NW>::kATile;
+    constexpr int R_TILE = WsSmem<K, D, TPS, NW>::kRTile;
+    constexpr int STAGE = WsSmem<K, D, TPS, NW>::kStage;
     static_assert(PIECES % NW == 0 && APW >= 1, "every wave issues the same number of A pieces");
+    static_assert((D - 2) * LG + (D - 1) * SG < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const a_ring = smem;
-    char* const r_ring = smem + D * A_STAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,16 +78,17 @@ __global__ __launch_bounds__(64 * kWsWaves) void wstat_kernel(IgemmParams p, int
     const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
     const int MB = (p.M + 31) >> 5;
     const int xb0 = (int)((long)MB * xcd / 8), xb1 = (int)((long)MB * (xcd + 1) / 8);
-    int blk0 = xb0, blk1 = xb1, slab0 = q, slab_step = 32;
-    if (nslab <= 32) {
-        const int nsub = 32 / nslab, sub = q / nslab;
+    int blk0 = xb0, blk1 = xb1, slab0 = q, slab_step = WPX;
+    if (nslab <= WPX) {
+        const int nsub = WPX / nslab, sub = q / nslab;
         slab0 = q - sub * nslab;
         slab_step = nslab;                       // one slab per workgroup
         blk0 = xb0 + (int)((long)(xb1 - xb0) * sub / nsub);
         blk1 = xb0 + (int)((long)(xb1 - xb0) * (sub + 1) / nsub);
     }
-    const int T = blk1 - blk0;
+    const int T = blk1 - blk0;                   // tiles
     if (T <= 0) return;                          // workgroup-uniform
+    const int S = (T + TPS - 1) / TPS;           // steps
 
     // ---- A pieces: piece j = wave + NW * i covers tile rows [RPP j, RPP j + RPP); lane -> (row, physical chunk).  The LDS image is
     // lane-linear; the XOR swizzle (key = row & 15) is applied to the SOURCE chunk and again on the fragment read.
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void wstat_kernel(IgemmParams p, int
     const int frag_row_off = lrow * (K * 2);
 
     for (int slab = slab0; slab < nslab; slab += slab_step) {
-        const int n0 = slab * kWsSlab + 32 * wave;            // first channel of this wave
+        const int n0 = slab * SLAB + 32 * wave;            // first channel of this wave
         // ---- weights of this wave's 32 channels as MFMA first operands: lane -> (channel n0 + lane % 32, k = 16 ks + 8 (lane / 32))
         half8 bf[KS];
         {
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void wstat_kernel(IgemmParams p, int
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int e = 0; e < 8; ++e) bs[g][e] = p.bias ? p.bias[n0 + 16 * g + 8 * hi + e] : 0.f;
-        // residual / output element offsets of this lane's row in tile 0, group 0
+        // residual / output addresses of this lane's row in tile 0, group 0
         const long col = n0 + 8 * hi;
         const char* r_src = HAS_RES ? reinterpret_cast<const char*>(p.res) + ((long)(blk0 * 32 + lrow) * p.Cout + col) * 2 : zero;
         half_t* o_dst = reinterpret_cast<half_t*>(p.out) + (long)(blk0 * 32 + lrow) * p.ldc + col;
@@ -133,126 +136,154 @@ __global__ __launch_bounds__(64 * kWsWaves) void wstat_kernel(IgemmParams p, int
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bf[ks]));
         __builtin_amdgcn_s_barrier();
 
-        // DMA of tile `ti` (A pieces, then this wave's residual pieces) into stage ti % D; past the range: zero page (same count)
-        auto issue = [&](int ti) {
-            const int st = ti % D;
-            const bool live = ti < T;
+        // DMA of step `si` (per tile: A pieces, then this wave's residual pieces) into stage si % D; tiles past the range and rows
+        // past M come from the zero page -- always the same number of instructions, the waits count them
+        auto issue = [&](int si) {
+            char* const stg = smem + (si % D) * STAGE;
 #pragma unroll
-            for (int i = 0; i < APW; ++i) {
-                const bool ok = live && a_rowm[i] + ti * 32 < p.M;
-                const char* src = ok ? a_cur[i] : zero;
-                asm volatile("" : "+v"(src));        // one DMA instruction per piece whatever the lanes' sources (the waits count them)
-                ws_glds16(src, a_ring + st * A_STAGE + (wave + NW * i) * 1024);
-                a_cur[i] += 32 * K * 2;
-            }
-            if (HAS_RES) {
-                const bool ok = live && (blk0 + ti) * 32 + lrow < p.M;
+            for (int j = 0; j < TPS; ++j) {
+                const int ti = si * TPS + j;
+                const bool live = ti < T;
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const char* src = ok ? r_src + 32 * g : zero;
+                for (int i = 0; i < APW; ++i) {
+                    const bool ok = live && a_rowm[i] + ti * 32 < p.M;
+                    const char* src = ok ? a_cur[i] : zero;
                     asm volatile("" : "+v"(src));
-                    ws_glds16(src, r_ring + st * R_STAGE + (wave * 2 + g) * 1024);
+                    ws_glds16(src, stg + j * A_TILE + (wave + NW * i) * 1024);
+                    a_cur[i] += 32 * K * 2;
                 }
-                r_src += (long)32 * p.Cout * 2;
+                if (HAS_RES) {
+                    const bool ok = live && (blk0 + ti) * 32 + lrow < p.M;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const char* src = ok ? r_src + 32 * g : zero;
+                        asm volatile("" : "+v"(src));
+                        ws_glds16(src, stg + TPS * A_TILE + j * R_TILE + (wave * 2 + g) * 1024);
+                    }
+                    r_src += (long)32 * p.Cout * 2;
+                }
             }
         };
 #pragma unroll
         for (int d = 0; d < D - 1; ++d) issue(d);
 
-        for (int t = 0; t < T; ++t) {
-            // own pieces of tile t have landed.  Issued after them: the loads of tiles t + 1 .. t + D - 2 and the stores of the last
+        for (int si = 0; si < S; ++si) {
+            // own pieces of step si have landed.  Issued after them: the loads of steps si + 1 .. si + D - 2 and the stores of the last
             // (up to) D - 1 steps; vmcnt retires in issue order.
-            if (t >= D - 1) ws_wait_vmcnt<(D - 2) * LG + (D - 1) * 2>();
+            if (si >= D - 1) ws_wait_vmcnt<(D - 2) * LG + (D - 1) * SG>();
             else ws_wait_vmcnt<(D - 2) * LG>();
-            __builtin_amdgcn_s_barrier();        // tile t visible to every wave; nobody reads tile t - 1 any more
+            __builtin_amdgcn_s_barrier();        // step si visible to every wave; nobody reads step si - 1 any more
             asm volatile("" ::: "memory");
-            issue(t + D - 1);                    // into the stage of tile t - 1
+            issue(si + D - 1);                   // into the stage of step si - 1
 
-            const int st = t % D;
-            const char* at = a_ring + st * A_STAGE + frag_row_off;
-            float16v acc;
+            const char* const stg = smem + (si % D) * STAGE;
+            float16v acc[TPS];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            // all fragment reads of the tile are issued up front (KS x 4 registers), the MFMA chain follows them with counted lgkmcnt
-            half8 fa[KS];
+            for (int j = 0; j < TPS; ++j)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) fa[ks] = *reinterpret_cast<const half8*>(at + (((2 * ks + hi) ^ frag_key) * 16));
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            // TPS independent chains, K ascending, sharing the weight fragment of each K step
+            // TPS independent chains, K ascending, sharing the weight fragment of each K step.  (Pinning all fragment reads in front of the
+            // first MFMA, two tiles per step, the epilogue of tile t - 1 spread over the MFMAs of tile t, and 4-wave workgroups two to a
+            // CU were all measured: none is faster -- profiles/r02_wstat.txt.)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], fa[ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int j = 0; j < TPS; ++j) {
+                    const half8 fa = *reinterpret_cast<const half8*>(stg + j * A_TILE + frag_row_off + (((2 * ks + hi) ^ frag_key) * 16));
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], fa, acc[j], 0, 0, 0);
+                }
+            }
             // ---- epilogue from the accumulator layout.  acc[4 r4 + r] = channel 8 r4 + 4 hi + r of row lane % 32; one half-wave
             // exchange per register pair (r4, r4 + 1) leaves lane < 32 with channels 16 g + [0, 8) and lane >= 32 with 16 g + 8 + [0, 8).
-            unsigned int u[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float f = acc[r];          // (a bit_cast of the vector element itself reads element 0 whatever r is)
-                u[r] = __float_as_uint(f);
+            for (int j = 0; j < TPS; ++j) {
+                unsigned int u[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float f = acc[j][r];   // (a bit_cast of the vector element itself reads element 0 whatever r is)
+                    u[r] = __float_as_uint(f);
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(u[8 * g + r], u[8 * g + 4 + r], false, false);
+                        u[8 * g + r] = sw[0];
+                        u[8 * g + 4 + r] = sw[1];
+                    }
+                const int ti = si * TPS + j;
+                const bool row_ok = ti < T && (blk0 + ti) * 32 + lrow < p.M;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float4v lo, hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] = __uint_as_float(u[8 * g + e]) + bs[g][e];
+                        hv[e] = __uint_as_float(u[8 * g + 4 + e]) + bs[g][4 + e];
+                    }
+                    if (HAS_RES) {
+                        const half8 rv = *reinterpret_cast<const half8*>(stg + TPS * A_TILE + j * R_TILE + (wave * 2 + g) * 1024 + lane * 16);
+                        lo += __builtin_convertvector(__builtin_shufflevector(rv, rv, 0, 1, 2, 3), float4v);
+                        hv += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
+                    }
+                    const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
+                    half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
+                    // rows past M / tiles past the range store to a dump slot: no branch in the loop body, every step issues all its stores
+                    half_t* dst = row_ok ? o_dst + 16 * g : reinterpret_cast<half_t*>(g_dump_ws) + lane * 8;
+                    asm volatile("" : "+v"(dst));
+                    *(__attribute__((address_space(1))) half8*)dst = o;      // a global store (a flat one would also count on lgkmcnt)
+                }
+                o_dst += (long)32 * p.ldc;
             }
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(u[8 * g + r], u[8 * g + 4 + r], false, false);
-                    u[8 * g + r] = sw[0];
-                    u[8 * g + 4 + r] = sw[1];
-                }
-            const bool row_ok = (blk0 + t) * 32 + lrow < p.M;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                float4v lo, hv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    lo[e] = __uint_as_float(u[8 * g + e]) + bs[g][e];
-                    hv[e] = __uint_as_float(u[8 * g + 4 + e]) + bs[g][4 + e];
-                }
-                if (HAS_RES) {
-                    const half8 rv = *reinterpret_cast<const half8*>(r_ring + st * R_STAGE + (wave * 2 + g) * 1024 + lane * 16);
-                    lo += __builtin_convertvector(__builtin_shufflevector(rv, rv, 0, 1, 2, 3), float4v);
-                    hv += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
-                }
-                const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
-                half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
-                if (p.relu) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
-                if (row_ok) *reinterpret_cast<half8*>(o_dst + 16 * g) = o;
-            }
-            o_dst += (long)32 * p.ldc;
         }
         // the tail's zero-page DMAs and this slab's residual reads retire before the next slab's prologue re-uses the stages
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
 }
 
-template <int K, int D, bool HAS_RES>
-int ws_launch_k(const IgemmParams& p, int nslab, hipStream_t s) {
-    constexpr int smem = WsSmem<K, D>::kBytes;
+template <int K, int D, int TPS, int NW, bool HAS_RES, bool RELU>
+int ws_launch_k(const IgemmParams& p, hipStream_t s) {
+    constexpr int smem = WsSmem<K, D, TPS, NW>::kBytes;
+    static_assert(smem * (8 / NW) <= 160 * 1024, "LDS");
+    const int nslab = p.Cout / (32 * NW);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat_kernel<K, D, HAS_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat_kernel<K, D, TPS, NW, HAS_RES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((wstat_kernel<K, D, HAS_RES>), dim3(256), dim3(64 * kWsWaves), smem, s, p, nslab);
+    hipLaunchKernelGGL((wstat_kernel<K, D, TPS, NW, HAS_RES, RELU>), dim3(2048 / NW), dim3(64 * NW), smem, s, p, nslab);
     LAUNCH_CHECK();
     return DVID_OK;
+}
+
+template <int K, int D, int TPS, int NW>
+int ws_launch_v(const IgemmParams& p, hipStream_t s) {
+    const bool res = p.res_mode == 1, relu = p.relu == 1;
+    if (res) return relu ? ws_launch_k<K, D, TPS, NW, true, true>(p, s) : ws_launch_k<K, D, TPS, NW, true, false>(p, s);
+    return relu ? ws_launch_k<K, D, TPS, NW, false, true>(p, s) : ws_launch_k<K, D, TPS, NW, false, false>(p, s);
 }
 
 }  // namespace
 
 // the layer type fits: 1x1 / linear over contiguous rows, K in {128, 256}, N a multiple of 256 with the slab count dividing (or a
-// multiple of) the 32 workgroups of an XCD, fp16 out, bias / ReLU / same-shape fp16 residual
+// multiple of) the workgroups of an XCD, fp16 out, bias / ReLU / same-shape fp16 residual
 bool dvid_wstat_supported(const IgemmParams& p) {
     if (p.ntaps != 1 || p.pad != 0 || p.stride != 1 || p.Ho != p.H || p.Wo != p.W) return false;
     if (p.Cin != p.Kpad || (p.Kpad != 128 && p.Kpad != 256)) return false;
-    if (p.Cout % kWsSlab) return false;
-    const int ns = p.Cout / kWsSlab;
+    if (p.Cout % 256) return false;
+    const int ns = p.Cout / 256;
     if (!(ns <= 32 ? 32 % ns == 0 : ns % 32 == 0)) return false;
     if (p.out_f32 || p.splitk > 1 || p.relu > 1 || (p.ldc & 7)) return false;
     if (p.res_mode > 1 || (p.res_mode == 1 && p.res_f32)) return false;
     return true;
 }
 
-// ... and the launch is large enough for 256 persistent workgroups: every workgroup streams at least 24 row blocks per weight load
+// ... and the launch is large enough for the persistent workgroups: each streams at least 24 row blocks per weight load
 bool dvid_wstat_preferred(const IgemmParams& p) {
     if (!dvid_wstat_supported(p)) return false;
-    const int ns = p.Cout / kWsSlab;
+    const int ns = p.Cout / 256;
     const long blocks_per_xcd = ((long)p.M + 31) / 32 / 8;
     const long per_wg = ns <= 32 ? blocks_per_xcd / (32 / ns) : blocks_per_xcd;
     return per_wg >= 24;
@@ -260,10 +291,6 @@ bool dvid_wstat_preferred(const IgemmParams& p) {
 
 int dvid_wstat_launch(const IgemmParams& p, hipStream_t s) {
     if (!dvid_wstat_supported(p)) return DVID_ERR_UNSUPPORTED;
-    const int ns = p.Cout / kWsSlab;
-    const bool res = p.res_mode == 1;
-    switch (p.Kpad) {
-        case 128: return res ? ws_launch_k<128, 6, true>(p, ns, s) : ws_launch_k<128, 6, false>(p, ns, s);
-        default: return res ? ws_launch_k<256, 4, true>(p, ns, s) : ws_launch_k<256, 4, false>(p, ns, s);
-    }
+    if (p.Kpad == 128) return ws_launch_v<128, 6, 1, 8>(p, s);
+    return ws_launch_v<256, 4, 1, 8>(p, s);
 }
