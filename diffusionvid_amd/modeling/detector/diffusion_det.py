@@ -13,6 +13,7 @@ DDIM loop, ensemble) is sequenced here; every numerical step is a HIP kernel lau
 shape)` when set (parity/bench), else torch.randn on the device like the reference.
 """
 import math
+import os
 from collections import deque
 
 import torch
@@ -156,6 +157,9 @@ class DiffusionDet(nn.Module):
         self._srm1_host = torch.sqrt(1.0 / alphas_cumprod - 1)
         self.noise_fn = None
         self.after_first_launch = None      # optional callable, run once the first backbone launch of a call is queued
+        self.memory_on_side_stream = os.environ.get("DVID_MEMORY_SIDE_STREAM", "1") != "0"
+        self._mem_stream = None
+        self._mem_side_pending = False
         self.debug_taps = None      # dict -> receives intermediates (parity tests)
         # True: a batch's detections come back with ONE device->host copy and the BoxLists hold CPU tensors
         # (what engine/inference.py does next anyway, there with ~3 copies per frame); False: GPU tensors
@@ -307,21 +311,23 @@ class DiffusionDet(nn.Module):
             raise NotImplementedError("more local frames than INFER_BATCH in one call")
         gsplit = None
         if ref_l_run or ref_g or ahead_keys:
-            fresh_local, gsplit, fresh_ahead = self._extract(frame_id, ref_l_run, ref_g, {fb: ahead[fb] for fb in ahead_keys}, whwh)
+            fresh_local, gsplit, fresh_ahead = self._extract(frame_id, ref_l_run, ref_g, {fb: ahead[fb] for fb in ahead_keys}, whwh,
+                                                             on_global=self._build_memory_aside if ref_g else None)
             if fresh_local is not None:
                 local_split = fresh_local
             self._ahead.update(fresh_ahead)
         splits = [local_split]
 
-        # 2. global memory, once per video with the shipped config (diffusion_det.py:479-488)
+        # 2. global memory, once per video with the shipped config (diffusion_det.py:479-488).  When more launch sequences followed
+        # the one that held the global frames, _extract has already queued it on the side stream (1800 x 1800 distances and two
+        # greedy farthest-point passes = 899 + 149 dependent arg-max steps on ONE workgroup, ~3 ms beside which the rest of the
+        # chip would idle); everything after this point reads the memory, so the launch stream waits for it here.
         if ref_g:
-            g1 = gsplit["k1"].reshape(-1, self.hidden_dim)
-            g2 = gsplit["k2"].reshape(-1, self.hidden_dim)
-            m0, _ = ops.update_erase_memory(g1, self.head.proposal_feats_global[0], self.mem_management_size_test)
-            m1, _ = ops.update_erase_memory(g2, self.head.proposal_feats_global[1], 150)
-            self.head.proposal_feats_global = [m0, m1]
-            if self.debug_taps is not None:
-                self.debug_taps["memory"] = [m0, m1]
+            if self._mem_side_pending:
+                torch.cuda.current_stream().wait_stream(self._mem_stream)
+                self._mem_side_pending = False
+            else:
+                self._build_memory(gsplit)
 
         # 3. local queue (diffusion_det.py:491-506)
         n_local = len(ref_l)
@@ -370,7 +376,38 @@ class DiffusionDet(nn.Module):
         feats_cur, cached = self._gather_entries(entries)
         return self._final_stage(feats_cur, cached, whwh, w, h, pairs, [(frame_id, batch)], ddim_draws, slots=batch)
 
-    def _extract(self, frame_id, ref_l, ref_g, ahead, whwh):
+    @staticmethod
+    def _fire_on_global(on_global, take, len_l, n_own, done, total):
+        """Once the launch sequences so far cover every global frame and at least one more sequence follows: hand the global
+        frames' split over (-> True when the hook has run, so it runs once)."""
+        if done < n_own or done >= total:
+            return done >= n_own          # nothing follows: the caller builds the memory in line
+        on_global(take(len_l, n_own))
+        return True
+
+    def _build_memory(self, gsplit):
+        g1 = gsplit["k1"].reshape(-1, self.hidden_dim)
+        g2 = gsplit["k2"].reshape(-1, self.hidden_dim)
+        m0, _ = ops.update_erase_memory(g1, self.head.proposal_feats_global[0], self.mem_management_size_test)
+        m1, _ = ops.update_erase_memory(g2, self.head.proposal_feats_global[1], 150)
+        self.head.proposal_feats_global = [m0, m1]
+        if self.debug_taps is not None:
+            self.debug_taps["memory"] = [m0, m1]
+
+    def _build_memory_aside(self, gsplit):
+        """The memory build on a second stream, behind everything queued so far (the global frames' extraction) and beside what
+        the launch stream queues next; same kernels on the same inputs, so the same memory."""
+        if not self.memory_on_side_stream:
+            return False
+        if self._mem_stream is None:
+            self._mem_stream = torch.cuda.Stream(device=self.device)
+        self._mem_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._mem_stream):
+            self._build_memory(gsplit)
+        self._mem_side_pending = True
+        return True
+
+    def _extract(self, frame_id, ref_l, ref_g, ahead, whwh, on_global=None):
         """Backbone + the 3 extraction RCNNHeads + top-k feature selection over [local | global | look-ahead] frames.
         Every stage here is per-frame independent, so the reference's splits of INFER_BATCH -- and with
         INPUT.LOOKAHEAD_BATCHES > 1 the frames of the next batches -- run as launches of up to INFER_BATCH *
@@ -396,34 +433,6 @@ class DiffusionDet(nn.Module):
         cap = self.infer_batch * self.lookahead
         eng.reserve(min(cap, total.shape[0]), total.shape[-2], total.shape[-1], M)
         per_frame = []          # (launch result dict, index inside the launch) for every frame slot of `total`
-        for ci, a in enumerate(range(0, total.shape[0], cap)):
-            chunk = total[a:a + cap].contiguous()
-            feats = eng.backbone(chunk)
-            if ci == 0 and self.after_first_launch is not None:
-                self.after_first_launch()          # e.g. the data layer's prefetch of the next group: behind this call's own uploads
-            B = chunk.shape[0]
-            if self.skip_unobservable:
-                # x4 (SURVEY.md Appendix B): of the extraction pass only the backbone features of every frame and the top-k
-                # object features of the GLOBAL frames are ever read -- the 3 heads run on the global frames of this chunk only
-                g0, g1 = max(len_l, a) - a, min(n_own, a + B) - a
-                dev, d = self.device, self.hidden_dim
-                res = {"feats": feats, "logits": torch.empty((B, M, self.num_classes), device=dev), "boxes": torch.empty((B, M, 4), device=dev),
-                       "obj": torch.empty((B, M, d), device=dev), "k1": torch.empty((B, self.top_k[0], d), device=dev),
-                       "k2": torch.empty((B, self.top_k[1], d), device=dev)}
-                if g1 > g0:
-                    t = torch.full((g1 - g0,), 999, dtype=torch.long)
-                    (cl, bx, pf), k1, k2 = self.model_predictions([f[g0:g1] for f in feats], whwh, box_init_all[a + g0:a + g1], t, box_extract=ci + 1)
-                    res["k1"][g0:g1] = k1.view(g1 - g0, self.top_k[0], d)
-                    res["k2"][g0:g1] = k2.view(g1 - g0, self.top_k[1], d)
-                per_frame += [(res, i) for i in range(B)]
-                continue
-            t = torch.full((B,), 999, dtype=torch.long)
-            (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init_all[a:a + B], t, box_extract=ci + 1)
-            res = {"feats": feats, "logits": cl, "boxes": bx, "obj": pf[0].view(B, M, self.hidden_dim),
-                   "k1": k1.view(B, self.top_k[0], self.hidden_dim), "k2": k2.view(B, self.top_k[1], self.hidden_dim)}
-            per_frame += [(res, i) for i in range(B)]
-            if self.debug_taps is not None:
-                self.debug_taps.setdefault("extract", []).append((cl, bx, pf[0], feats))
 
         def take(a, b):
             """result slots [a, b) as one split: views when they sit in one launch, else a concatenation"""
@@ -444,6 +453,38 @@ class DiffusionDet(nn.Module):
             out = {k: torch.cat([src[k][i0:i1] for src, i0, i1 in runs]) for k in keys}
             out["feats"] = [torch.cat([src["feats"][l][i0:i1] for src, i0, i1 in runs]) for l in range(3)]
             return out
+
+        fired = on_global is None or not ref_g
+        for ci, a in enumerate(range(0, total.shape[0], cap)):
+            chunk = total[a:a + cap].contiguous()
+            feats = eng.backbone(chunk)
+            if ci == 0 and self.after_first_launch is not None:
+                self.after_first_launch()          # e.g. the data layer's prefetch of the next group: behind this call's own uploads
+            B = chunk.shape[0]
+            if self.skip_unobservable:
+                # x4 (SURVEY.md Appendix B): of the extraction pass only the backbone features of every frame and the top-k
+                # object features of the GLOBAL frames are ever read -- the 3 heads run on the global frames of this chunk only
+                g0, g1 = max(len_l, a) - a, min(n_own, a + B) - a
+                dev, d = self.device, self.hidden_dim
+                res = {"feats": feats, "logits": torch.empty((B, M, self.num_classes), device=dev), "boxes": torch.empty((B, M, 4), device=dev),
+                       "obj": torch.empty((B, M, d), device=dev), "k1": torch.empty((B, self.top_k[0], d), device=dev),
+                       "k2": torch.empty((B, self.top_k[1], d), device=dev)}
+                if g1 > g0:
+                    t = torch.full((g1 - g0,), 999, dtype=torch.long)
+                    (cl, bx, pf), k1, k2 = self.model_predictions([f[g0:g1] for f in feats], whwh, box_init_all[a + g0:a + g1], t, box_extract=ci + 1)
+                    res["k1"][g0:g1] = k1.view(g1 - g0, self.top_k[0], d)
+                    res["k2"][g0:g1] = k2.view(g1 - g0, self.top_k[1], d)
+                per_frame += [(res, i) for i in range(B)]
+                fired = fired or self._fire_on_global(on_global, take, len_l, n_own, a + B, total.shape[0])
+                continue
+            t = torch.full((B,), 999, dtype=torch.long)
+            (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init_all[a:a + B], t, box_extract=ci + 1)
+            res = {"feats": feats, "logits": cl, "boxes": bx, "obj": pf[0].view(B, M, self.hidden_dim),
+                   "k1": k1.view(B, self.top_k[0], self.hidden_dim), "k2": k2.view(B, self.top_k[1], self.hidden_dim)}
+            per_frame += [(res, i) for i in range(B)]
+            if self.debug_taps is not None:
+                self.debug_taps.setdefault("extract", []).append((cl, bx, pf[0], feats))
+            fired = fired or self._fire_on_global(on_global, take, len_l, n_own, a + B, total.shape[0])
 
         local = take(0, len_l) if len_l else None
         glob = take(len_l, n_own) if ref_g else None

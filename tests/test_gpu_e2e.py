@@ -777,3 +777,43 @@ def test_host_fed_prefetch_equals_resident_frames():
             assert torch.equal(ref[i].bbox, got[i].bbox) and torch.equal(ref[i].get_field("scores"), got[i].get_field("scores"))
     assert hf.h2d_bytes >= 2 * 75 * 3 * 128 * 224 * 4
     model.after_first_launch = None
+
+
+@pytest.mark.gpu
+def test_memory_build_on_side_stream_is_identical():
+    """The first call of a video queues the global-memory build (cdist + two farthest-point passes + gathers) on a second stream
+    when more launch sequences follow the one that held the global frames (look-ahead 4: 8 + 24 + 24 frames in groups of 32).
+    Same kernels on the same inputs: memory and detections must equal the in-line build bit for bit, video after video."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["INPUT.LOOKAHEAD_BATCHES", 4], "configs/BASE_RCNN_1gpu.yaml")
+    cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+    model = model.to("cuda").eval()
+    model.noise_fn = synthetic.noise_fn
+    ds = SyntheticVIDDataset([44, 20, 36], cfg, height=120, width=200, device="cuda", smooth=True)
+    outs, mems, used = {}, {}, {}
+    for aside in (False, True):
+        model.memory_on_side_stream = aside
+        res, mem, n_side = [], [], 0
+        with torch.no_grad():
+            for idx in range(len(ds)):
+                item = ds[idx][0]
+                model.debug_taps = {}
+                res += model(item)
+                if "memory" in model.debug_taps:
+                    mem.append([m.clone() for m in model.debug_taps["memory"]])
+                    n_side += int(model._mem_stream is not None and aside)
+        model.debug_taps = None
+        outs[aside], mems[aside], used[aside] = res, mem, n_side
+    assert used[True] == 3 and len(mems[True]) == 3 and len(mems[False]) == 3
+    for a, b in zip(mems[False], mems[True]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert len(outs[False]) == len(outs[True]) == 100
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
+        assert torch.equal(a.get_field("labels"), b.get_field("labels"))
