@@ -48,16 +48,15 @@ struct WsSmem {
 // K: reduction length (= Cin = Kpad); TPS: 32-row tiles per step (one counted wait + one barrier per step; the TPS MFMA chains of a
 // wave are independent and issue interleaved); D: ring depth in steps (steps s + 1 .. s + D - 1 in flight while step s is computed);
 // HAS_RES: same-shape fp16 residual; RELU.  Grid: 256 workgroups x 512 threads.
-template <int K, int D, int TPS, int NW, bool HAS_RES, bool RELU, bool RREG>
+template <int K, int D, int TPS, int NW, bool HAS_RES, bool RELU>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, int nslab) {
-    static_assert(!RREG || (HAS_RES && TPS == 1), "register-staged residual: one tile per step");
     constexpr int WPX = 256 / NW;                 // workgroups per XCD: 8 waves -> one workgroup per CU, 4 waves -> two
     constexpr int SLAB = 32 * NW;                 // output channels per workgroup
     constexpr int CH = K / 8;                     // 16-byte chunks per A row
     constexpr int RPP = (K >= 512) ? 1 : 512 / K; // A rows per 1-KiB DMA piece
     constexpr int PIECES = 32 / RPP;              // A pieces per tile
     constexpr int APW = PIECES / NW;              // ... per wave
-    constexpr int RP = (HAS_RES && !RREG) ? 2 : 0; // residual pieces per wave per tile on the DMA ring
+    constexpr int RP = HAS_RES ? 2 : 0;           // residual pieces per wave per tile
     constexpr int LG = TPS * (APW + RP);          // DMA instructions per wave per step
     constexpr int SG = TPS * 2;                   // store instructions per wave per step
     constexpr int KS = K / 16;
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
                     ws_glds16(src, stg + j * A_TILE + (wave + NW * i) * 1024);
                     a_cur[i] += 32 * K * 2;
                 }
-                if (HAS_RES && !RREG) {
+                if (HAS_RES) {
                     const bool ok = live && (blk0 + ti) * 32 + lrow < p.M;
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
@@ -165,86 +164,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
                 }
             }
         };
-        if constexpr (RREG) {
-            // Residual straight into registers (2 x 16 bytes per lane per tile, the addresses the DMA pieces used), one tile ahead, by
-            // inline-asm loads the compiler does not track: every use sits behind an explicit counted wait that names the registers.
-            // Two register sets with fixed roles (the step loop is unrolled by two) -- a copy of a set that has not landed would read
-            // stale registers.  Per step a wave issues: APW DMA pieces (tile t + D - 1), 2 residual loads (tile t + 1), 2 stores (tile t).
-            auto rload = [&](int ti, half8& r0, half8& r1) {
-                const bool ok = ti < T && (blk0 + ti) * 32 + lrow < p.M;
-                const char* src = ok ? r_src : zero;
-                asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:32"
-                             : "=&v"(r0), "=&v"(r1)
-                             : "v"(src)
-                             : "memory");
-                r_src += (long)32 * p.Cout * 2;
-            };
-            auto step = [&](int t, half8& u0, half8& u1, half8& l0, half8& l1) {
-                // A(t) has landed: behind it RES(t - D + 2), ST(t - D + 1) and D - 2 whole steps (APW + 4 each); fewer in the first steps
-                if (t >= D - 1) ws_wait_vmcnt<4 + (D - 2) * (APW + 4)>();
-                else ws_wait_vmcnt<(D - 2) * APW + 2>();
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                issue(t + D - 1);
-                rload(t + 1, l0, l1);
-                const char* const stg = smem + (t % D) * STAGE;
-                float16v acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const half8 fa = *reinterpret_cast<const half8*>(stg + frag_row_off + (((2 * ks + hi) ^ frag_key) * 16));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], fa, acc, 0, 0, 0);
-                }
-                unsigned int u[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float f = acc[r];
-                    u[r] = __float_as_uint(f);
-                }
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap(u[8 * g + r], u[8 * g + 4 + r], false, false);
-                        u[8 * g + r] = sw[0];
-                        u[8 * g + 4 + r] = sw[1];
-                    }
-                // RES(t) has landed: behind it ST(t - 1), the DMA pieces of this step and RES(t + 1)
-                if (t >= 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(u0), "+v"(u1) : "n"(APW + 4) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(u0), "+v"(u1) : "n"(APW + 2) : "memory");
-                const bool row_ok = (blk0 + t) * 32 + lrow < p.M;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const half8 rv = g ? u1 : u0;
-                    float4v lo, hv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        lo[e] = __uint_as_float(u[8 * g + e]) + bs[g][e];
-                        hv[e] = __uint_as_float(u[8 * g + 4 + e]) + bs[g][4 + e];
-                    }
-                    lo += __builtin_convertvector(__builtin_shufflevector(rv, rv, 0, 1, 2, 3), float4v);
-                    hv += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
-                    const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
-                    half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
-                    half_t* dst = row_ok ? o_dst + 16 * g : reinterpret_cast<half_t*>(g_dump_ws) + lane * 8;
-                    asm volatile("" : "+v"(dst));
-                    *(__attribute__((address_space(1))) half8*)dst = o;
-                }
-                o_dst += (long)32 * p.ldc;
-            };
-#pragma unroll
-            for (int d = 0; d < D - 1; ++d) issue(d);
-            half8 ra0, ra1, rb0, rb1;
-            rload(0, ra0, ra1);
-            int t = 0;
-            for (; t + 1 < T; t += 2) {
-                step(t, ra0, ra1, rb0, rb1);
-                step(t + 1, rb0, rb1, ra0, ra1);
-            }
-            if (t < T) step(t, ra0, ra1, rb0, rb1);
-        } else {
 #pragma unroll
         for (int d = 0; d < D - 1; ++d) issue(d);
 
@@ -319,23 +238,22 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
                 o_dst += (long)32 * p.ldc;
             }
         }
-        }
         // the tail's zero-page DMAs and this slab's residual reads retire before the next slab's prologue re-uses the stages
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
 }
 
-template <int K, int D, int TPS, int NW, bool HAS_RES, bool RELU, bool RREG = false>
+template <int K, int D, int TPS, int NW, bool HAS_RES, bool RELU>
 int ws_launch_k(const IgemmParams& p, hipStream_t s) {
     constexpr int smem = WsSmem<K, D, TPS, NW>::kBytes;
     static_assert(smem * (8 / NW) <= 160 * 1024, "LDS");
     const int nslab = p.Cout / (32 * NW);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat_kernel<K, D, TPS, NW, HAS_RES, RELU, RREG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat_kernel<K, D, TPS, NW, HAS_RES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((wstat_kernel<K, D, TPS, NW, HAS_RES, RELU, RREG>), dim3(2048 / NW), dim3(64 * NW), smem, s, p, nslab);
+    hipLaunchKernelGGL((wstat_kernel<K, D, TPS, NW, HAS_RES, RELU>), dim3(2048 / NW), dim3(64 * NW), smem, s, p, nslab);
     LAUNCH_CHECK();
     return DVID_OK;
 }
@@ -343,8 +261,6 @@ int ws_launch_k(const IgemmParams& p, hipStream_t s) {
 template <int K, int D, int TPS, int NW>
 int ws_launch_v(const IgemmParams& p, hipStream_t s) {
     const bool res = p.res_mode == 1, relu = p.relu == 1;
-    static const bool rreg = !(getenv("DVID_WSTAT_RREG") && atoi(getenv("DVID_WSTAT_RREG")) == 0);     // A/B measurements
-    if (res && rreg) return relu ? ws_launch_k<K, D, TPS, NW, true, true, true>(p, s) : ws_launch_k<K, D, TPS, NW, true, false, true>(p, s);
     if (res) return relu ? ws_launch_k<K, D, TPS, NW, true, true>(p, s) : ws_launch_k<K, D, TPS, NW, true, false>(p, s);
     return relu ? ws_launch_k<K, D, TPS, NW, false, true>(p, s) : ws_launch_k<K, D, TPS, NW, false, false>(p, s);
 }
