@@ -243,6 +243,236 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
     }
 }
 
+// ---- row-coalesced variant ---------------------------------------------------------------------------------------------------
+// Same products and epilogue arithmetic; what changes is how the residual and the output meet global memory.  Above, a wave's
+// residual piece / store covers 32 rows x 32 bytes (one accumulator tile's rows): 32 requests of a quarter line each, rows one row
+// pitch apart.  Here the workgroup's [32 x 256] residual tile rides the DMA ring row-major (2 rows x 512 contiguous bytes per piece,
+// XOR-swizzled like the A tile, read back in the accumulator layout), and the finished fp16 tile goes through a double-buffered
+// [32 x 256] LDS image: written in the accumulator layout at the end of step t, read back lane-linearly after the barrier of step
+// t + 1 and stored 2 rows x 512 contiguous bytes per instruction -- every global access of the kernel is whole 512-byte row segments.
+template <int K, int D>
+struct Ws2Smem {
+    static constexpr int kATile = 32 * K * 2;
+    static constexpr int kRTile = 32 * 256 * 2;
+    static constexpr int kStage = kATile + kRTile;
+    static constexpr int kCOff = D * kStage;
+    static constexpr int kBytes = kCOff + 2 * kRTile;
+};
+
+template <int K, int D, bool HAS_RES, bool RELU>
+__global__ __launch_bounds__(512) void wstat2_kernel(IgemmParams p, int nslab) {
+    constexpr int NW = 8, WPX = 32, SLAB = 256;
+    constexpr int CH = K / 8;
+    constexpr int RPP = 512 / K;
+    constexpr int PIECES = 32 / RPP;
+    constexpr int APW = PIECES / NW;
+    constexpr int RP = HAS_RES ? 2 : 0;
+    constexpr int LG = APW + RP;
+    constexpr int KS = K / 16;
+    constexpr int A_TILE = Ws2Smem<K, D>::kATile;
+    constexpr int R_TILE = Ws2Smem<K, D>::kRTile;
+    constexpr int STAGE = Ws2Smem<K, D>::kStage;
+    static_assert(PIECES % NW == 0 && APW >= 1, "every wave issues the same number of A pieces");
+    static_assert((D - 2) * LG + (D - 1) * 2 < 64, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const c_img = smem + Ws2Smem<K, D>::kCOff;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lrow = lane & 31;
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page_ws);
+
+    const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+    const int MB = (p.M + 31) >> 5;
+    const int xb0 = (int)((long)MB * xcd / 8), xb1 = (int)((long)MB * (xcd + 1) / 8);
+    int blk0 = xb0, blk1 = xb1, slab0 = q, slab_step = WPX;
+    if (nslab <= WPX) {
+        const int nsub = WPX / nslab, sub = q / nslab;
+        slab0 = q - sub * nslab;
+        slab_step = nslab;
+        blk0 = xb0 + (int)((long)(xb1 - xb0) * sub / nsub);
+        blk1 = xb0 + (int)((long)(xb1 - xb0) * (sub + 1) / nsub);
+    }
+    const int T = blk1 - blk0;
+    if (T <= 0) return;
+
+    const char* a_src[APW];
+    int a_rowm[APW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int piece = wave + NW * i;
+        const int row = piece * RPP + lane / CH;
+        const int lch = (lane % CH) ^ (row & 15);
+        a_rowm[i] = blk0 * 32 + row;
+        a_src[i] = reinterpret_cast<const char*>(p.in) + ((long)a_rowm[i] * K + lch * 8) * 2;
+    }
+    const int frag_key = lrow & 15;
+    const int frag_row_off = lrow * (K * 2);
+    // row-major [32 x 256] images (residual stage, output image): piece / store j = wave + 8 i covers rows 2 j, 2 j + 1; lane -> (row 2 j
+    // + lane / 32, physical chunk lane % 32); logical chunk = physical ^ (row & 15)
+    int rc_row[2], rc_lch[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rc_row[i] = 2 * (wave + NW * i) + hi;
+        rc_lch[i] = lrow ^ (rc_row[i] & 15);
+    }
+    // this lane's two accumulator-layout chunks in such an image: row lane % 32, logical chunk 4 wave + 2 g + hi
+    int acc_off[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) acc_off[g] = lrow * 512 + (((4 * wave + 2 * g + hi) ^ frag_key) * 16);
+
+    for (int slab = slab0; slab < nslab; slab += slab_step) {
+        const int n0 = slab * SLAB + 32 * wave;
+        half8 bf[KS];
+        {
+            const half_t* wrow = p.w + (long)(n0 + lrow) * p.Kpad + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bf[ks] = *reinterpret_cast<const half8*>(wrow + 16 * ks);
+        }
+        float bs[2][8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bs[g][e] = p.bias ? p.bias[n0 + 16 * g + 8 * hi + e] : 0.f;
+        const char* r_src[2];
+        half_t* o_dst[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long row = (long)blk0 * 32 + rc_row[i];
+            const long col = (long)slab * SLAB + rc_lch[i] * 8;
+            r_src[i] = HAS_RES ? reinterpret_cast<const char*>(p.res) + (row * p.Cout + col) * 2 : zero;
+            o_dst[i] = reinterpret_cast<half_t*>(p.out) + row * p.ldc + col;
+        }
+        const char* a_cur[APW];
+#pragma unroll
+        for (int i = 0; i < APW; ++i) a_cur[i] = a_src[i];
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bf[ks]));
+        __builtin_amdgcn_s_barrier();
+
+        auto issue = [&](int ti) {
+            char* const stg = smem + (ti % D) * STAGE;
+            const bool live = ti < T;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const bool ok = live && a_rowm[i] + ti * 32 < p.M;
+                const char* src = ok ? a_cur[i] : zero;
+                asm volatile("" : "+v"(src));
+                ws_glds16(src, stg + (wave + NW * i) * 1024);
+                a_cur[i] += 32 * K * 2;
+            }
+            if (HAS_RES) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool ok = live && (blk0 + ti) * 32 + rc_row[i] < p.M;
+                    const char* src = ok ? r_src[i] : zero;
+                    asm volatile("" : "+v"(src));
+                    ws_glds16(src, stg + A_TILE + (wave + NW * i) * 1024);
+                    r_src[i] += (long)32 * p.Cout * 2;
+                }
+            }
+        };
+        // the finished tile `ti` from its LDS image to global memory: 2 stores of 2 rows x 512 bytes
+        auto store_tile = [&](int ti) {
+            const char* img = c_img + (ti & 1) * R_TILE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const half8 o = *reinterpret_cast<const half8*>(img + (wave + NW * i) * 1024 + lane * 16);
+                const bool row_ok = ti >= 0 && (blk0 + ti) * 32 + rc_row[i] < p.M;
+                half_t* dst = row_ok ? o_dst[i] : reinterpret_cast<half_t*>(g_dump_ws) + lane * 8;
+                asm volatile("" : "+v"(dst));
+                *(__attribute__((address_space(1))) half8*)dst = o;
+                if (ti >= 0) o_dst[i] += (long)32 * p.ldc;
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) issue(d);
+
+        for (int t = 0; t < T; ++t) {
+            if (t >= D) ws_wait_vmcnt<(D - 2) * LG + (D - 1) * 2>();
+            else ws_wait_vmcnt<(D - 2) * LG>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's part of the output image is written
+            __builtin_amdgcn_s_barrier();        // tile t (A and residual) visible; tile t - 1's output image complete; stage t - 1 free
+            asm volatile("" ::: "memory");
+            issue(t + D - 1);
+            store_tile(t - 1);                   // (t = 0: two dump stores, so that every step issues the same instructions)
+
+            const char* const stg = smem + (t % D) * STAGE;
+            float16v acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 fa = *reinterpret_cast<const half8*>(stg + frag_row_off + (((2 * ks + hi) ^ frag_key) * 16));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], fa, acc, 0, 0, 0);
+            }
+            unsigned int u[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = acc[r];
+                u[r] = __float_as_uint(f);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(u[8 * g + r], u[8 * g + 4 + r], false, false);
+                    u[8 * g + r] = sw[0];
+                    u[8 * g + 4 + r] = sw[1];
+                }
+            char* const img = c_img + (t & 1) * R_TILE;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float4v lo, hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = __uint_as_float(u[8 * g + e]) + bs[g][e];
+                    hv[e] = __uint_as_float(u[8 * g + 4 + e]) + bs[g][4 + e];
+                }
+                if (HAS_RES) {
+                    const half8 rv = *reinterpret_cast<const half8*>(stg + A_TILE + acc_off[g]);
+                    lo += __builtin_convertvector(__builtin_shufflevector(rv, rv, 0, 1, 2, 3), float4v);
+                    hv += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
+                }
+                const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
+                half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
+                *reinterpret_cast<half8*>(img + acc_off[g]) = o;
+            }
+        }
+        // last tile: its image is complete once every wave is here
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        store_tile(T - 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <int K, int D, bool HAS_RES, bool RELU>
+int ws2_launch_k(const IgemmParams& p, hipStream_t s) {
+    constexpr int smem = Ws2Smem<K, D>::kBytes;
+    static_assert(smem <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat2_kernel<K, D, HAS_RES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wstat2_kernel<K, D, HAS_RES, RELU>), dim3(256), dim3(512), smem, s, p, p.Cout / 256);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+template <int K, int D>
+int ws2_launch_v(const IgemmParams& p, hipStream_t s) {
+    const bool res = p.res_mode == 1, relu = p.relu == 1;
+    if (res) return relu ? ws2_launch_k<K, D, true, true>(p, s) : ws2_launch_k<K, D, true, false>(p, s);
+    return relu ? ws2_launch_k<K, D, false, true>(p, s) : ws2_launch_k<K, D, false, false>(p, s);
+}
+
 template <int K, int D, int TPS, int NW, bool HAS_RES, bool RELU>
 int ws_launch_k(const IgemmParams& p, hipStream_t s) {
     constexpr int smem = WsSmem<K, D, TPS, NW>::kBytes;
@@ -291,6 +521,10 @@ bool dvid_wstat_preferred(const IgemmParams& p) {
 
 int dvid_wstat_launch(const IgemmParams& p, hipStream_t s) {
     if (!dvid_wstat_supported(p)) return DVID_ERR_UNSUPPORTED;
+    // layers with a residual: the row-coalesced variant (res3 conv3 0.460 vs 0.497 ms, res4 conv3 0.291 vs 0.300 at 104 frames); without
+    // one (dynamic_layer, linear1) the accumulator-layout stores are as fast or faster (0.780 vs 0.791).  DVID_WSTAT_V2=0 / 1 forces one.
+    static const int v2 = getenv("DVID_WSTAT_V2") ? atoi(getenv("DVID_WSTAT_V2")) : -1;
+    if (v2 > 0 || (v2 < 0 && p.res_mode == 1)) return p.Kpad == 128 ? ws2_launch_v<128, 4>(p, s) : ws2_launch_v<256, 3>(p, s);
     if (p.Kpad == 128) return ws_launch_v<128, 6, 1, 8>(p, s);
     return ws_launch_v<256, 4, 1, 8>(p, s);
 }
