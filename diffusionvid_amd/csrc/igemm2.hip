@@ -845,6 +845,12 @@ int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
         const int ws = g_wstat_mode >= 0 ? g_wstat_mode : ws_env;
         if (ws && !forced && (ws >= 2 ? dvid_wstat_supported(p) : dvid_wstat_preferred(p))) return dvid_wstat_launch(p, s);
     }
+    return dvid_igemm2_launch(p, s);
+}
+
+int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
+    if (p.Kpad % 64 != 0 || p.Kpad < 64) return DVID_ERR_ARG;
     {
         // a function of the shape only -- never of a timing: the two kernels sum the same products in different orders.  A forced
         // tile configuration (the bit-identity tests, experiments) means the igemm2 kernel.

@@ -16,7 +16,8 @@ struct IgemmParams {
     long split_stride;                      //       written to out + split * split_stride (elements)
     int tiles_m, tiles_n;                   // filled by the launcher
 };
-int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);   // igemm2.hip: per-shape tuned tile configuration
+int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);   // igemm2.hip: picks the kernel family (wstat / conv3x3 / igemm2) by the layer's shape
+int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s);  // igemm2.hip: the igemm2 kernel with its per-shape tuned tile configuration
 
 // conv3x3.hip: 3x3 / stride-1 / pad-1 layers with the input patch + halo staged once per channel chunk (all nine taps read it)
 bool dvid_conv3x3_halo_supported(const IgemmParams& p);   // the layer type fits the kernel

@@ -28,6 +28,31 @@ namespace {
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_ws[4] = {0u, 0u, 0u, 0u};
 __device__ __attribute__((aligned(16))) unsigned int g_dump_ws[64 * 4];      // where the lanes of rows past M store (one 16-byte slot per lane)
 
+// x + float(h) in one instruction: v_fma_mix_f32 (h * 1.0 + x, fp16 source promoted exactly, one rounding -- the value of cvt + add)
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float ws_mix_add_lo(unsigned int h2, float x) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(x));
+    return d;
+}
+__device__ __forceinline__ float ws_mix_add_hi(unsigned int h2, float x) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(x));
+    return d;
+}
+// lo / hv += the eight halves of rv
+__device__ __forceinline__ void ws_add_res8(float4v& lo, float4v& hv, half8 rv) {
+    const uint4v r = __builtin_bit_cast(uint4v, rv);
+    lo[0] = ws_mix_add_lo(r[0], lo[0]);
+    lo[1] = ws_mix_add_hi(r[0], lo[1]);
+    lo[2] = ws_mix_add_lo(r[1], lo[2]);
+    lo[3] = ws_mix_add_hi(r[1], lo[3]);
+    hv[0] = ws_mix_add_lo(r[2], hv[0]);
+    hv[1] = ws_mix_add_hi(r[2], hv[1]);
+    hv[2] = ws_mix_add_lo(r[3], hv[2]);
+    hv[3] = ws_mix_add_hi(r[3], hv[3]);
+}
+
 template <int N>
 __device__ __forceinline__ void ws_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -136,31 +161,24 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bf[ks]));
         __builtin_amdgcn_s_barrier();
 
-        // DMA of step `si` (per tile: A pieces, then this wave's residual pieces) into stage si % D; tiles past the range and rows
-        // past M come from the zero page -- always the same number of instructions, the waits count them
+        // DMA of step `si` (per tile: A pieces, then this wave's residual pieces) into stage si % D.  M is a multiple of 32 here (the
+        // launcher hands a ragged tail to igemm2), so no lane needs a mask; the waits count instructions, so steps past the range
+        // issue theirs too (re-fetching the last tile)
         auto issue = [&](int si) {
             char* const stg = smem + (si % D) * STAGE;
 #pragma unroll
             for (int j = 0; j < TPS; ++j) {
                 const int ti = si * TPS + j;
-                const bool live = ti < T;
+                const bool more = ti + 1 < T;        // (wave-uniform) past the range the last tile is fetched again: same instruction count, no masks
 #pragma unroll
                 for (int i = 0; i < APW; ++i) {
-                    const bool ok = live && a_rowm[i] + ti * 32 < p.M;
-                    const char* src = ok ? a_cur[i] : zero;
-                    asm volatile("" : "+v"(src));
-                    ws_glds16(src, stg + j * A_TILE + (wave + NW * i) * 1024);
-                    a_cur[i] += 32 * K * 2;
+                    ws_glds16(a_cur[i], stg + j * A_TILE + (wave + NW * i) * 1024);
+                    a_cur[i] += more ? 32 * K * 2 : 0;
                 }
                 if (HAS_RES) {
-                    const bool ok = live && (blk0 + ti) * 32 + lrow < p.M;
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const char* src = ok ? r_src + 32 * g : zero;
-                        asm volatile("" : "+v"(src));
-                        ws_glds16(src, stg + TPS * A_TILE + j * R_TILE + (wave * 2 + g) * 1024);
-                    }
-                    r_src += (long)32 * p.Cout * 2;
+                    for (int g = 0; g < 2; ++g) ws_glds16(r_src + 32 * g, stg + TPS * A_TILE + j * R_TILE + (wave * 2 + g) * 1024);
+                    r_src += more ? (long)32 * p.Cout * 2 : 0L;
                 }
             }
         };
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
                         u[8 * g + 4 + r] = sw[1];
                     }
                 const int ti = si * TPS + j;
-                const bool row_ok = ti < T && (blk0 + ti) * 32 + lrow < p.M;
+                const bool row_ok = ti < T;          // (only the second tile of the last step can be past the range)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     float4v lo, hv;
@@ -224,16 +242,19 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
                     }
                     if (HAS_RES) {
                         const half8 rv = *reinterpret_cast<const half8*>(stg + TPS * A_TILE + j * R_TILE + (wave * 2 + g) * 1024 + lane * 16);
-                        lo += __builtin_convertvector(__builtin_shufflevector(rv, rv, 0, 1, 2, 3), float4v);
-                        hv += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
+                        ws_add_res8(lo, hv, rv);
                     }
                     const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
                     half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
                     if (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
-                    // rows past M / tiles past the range store to a dump slot: no branch in the loop body, every step issues all its stores
-                    half_t* dst = row_ok ? o_dst + 16 * g : reinterpret_cast<half_t*>(g_dump_ws) + lane * 8;
-                    asm volatile("" : "+v"(dst));
-                    *(__attribute__((address_space(1))) half8*)dst = o;      // a global store (a flat one would also count on lgkmcnt)
+                    if (TPS == 1) {
+                        *reinterpret_cast<half8*>(o_dst + 16 * g) = o;
+                    } else {
+                        // a tile past the range stores to a dump slot: no branch in the loop body, every step issues all its stores
+                        half_t* dst = row_ok ? o_dst + 16 * g : reinterpret_cast<half_t*>(g_dump_ws) + lane * 8;
+                        asm volatile("" : "+v"(dst));
+                        *(__attribute__((address_space(1))) half8*)dst = o;      // a global store (a flat one would also count on lgkmcnt)
+                    }
                 }
                 o_dst += (long)32 * p.ldc;
             }
@@ -355,23 +376,17 @@ __global__ __launch_bounds__(512) void wstat2_kernel(IgemmParams p, int nslab) {
 
         auto issue = [&](int ti) {
             char* const stg = smem + (ti % D) * STAGE;
-            const bool live = ti < T;
+            const bool more = ti + 1 < T;            // past the range the last tile is fetched again (same instruction count, no masks)
 #pragma unroll
             for (int i = 0; i < APW; ++i) {
-                const bool ok = live && a_rowm[i] + ti * 32 < p.M;
-                const char* src = ok ? a_cur[i] : zero;
-                asm volatile("" : "+v"(src));
-                ws_glds16(src, stg + (wave + NW * i) * 1024);
-                a_cur[i] += 32 * K * 2;
+                ws_glds16(a_cur[i], stg + (wave + NW * i) * 1024);
+                a_cur[i] += more ? 32 * K * 2 : 0;
             }
             if (HAS_RES) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const bool ok = live && (blk0 + ti) * 32 + rc_row[i] < p.M;
-                    const char* src = ok ? r_src[i] : zero;
-                    asm volatile("" : "+v"(src));
-                    ws_glds16(src, stg + A_TILE + (wave + NW * i) * 1024);
-                    r_src[i] += (long)32 * p.Cout * 2;
+                    ws_glds16(r_src[i], stg + A_TILE + (wave + NW * i) * 1024);
+                    r_src[i] += more ? (long)32 * p.Cout * 2 : 0L;
                 }
             }
         };
@@ -381,11 +396,8 @@ __global__ __launch_bounds__(512) void wstat2_kernel(IgemmParams p, int nslab) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const half8 o = *reinterpret_cast<const half8*>(img + (wave + NW * i) * 1024 + lane * 16);
-                const bool row_ok = ti >= 0 && (blk0 + ti) * 32 + rc_row[i] < p.M;
-                half_t* dst = row_ok ? o_dst[i] : reinterpret_cast<half_t*>(g_dump_ws) + lane * 8;
-                asm volatile("" : "+v"(dst));
-                *(__attribute__((address_space(1))) half8*)dst = o;
-                if (ti >= 0) o_dst[i] += (long)32 * p.ldc;
+                *reinterpret_cast<half8*>(o_dst[i]) = o;
+                o_dst[i] += (long)32 * p.ldc;
             }
         };
 #pragma unroll
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(512) void wstat2_kernel(IgemmParams p, int nslab) {
             __builtin_amdgcn_s_barrier();        // tile t (A and residual) visible; tile t - 1's output image complete; stage t - 1 free
             asm volatile("" ::: "memory");
             issue(t + D - 1);
-            store_tile(t - 1);                   // (t = 0: two dump stores, so that every step issues the same instructions)
+            if (t) store_tile(t - 1);            // (the counted waits only assume these stores from step D on)
 
             const char* const stg = smem + (t % D) * STAGE;
             float16v acc;
@@ -434,8 +446,7 @@ __global__ __launch_bounds__(512) void wstat2_kernel(IgemmParams p, int nslab) {
                 }
                 if (HAS_RES) {
                     const half8 rv = *reinterpret_cast<const half8*>(stg + A_TILE + acc_off[g]);
-                    lo += __builtin_convertvector(__builtin_shufflevector(rv, rv, 0, 1, 2, 3), float4v);
-                    hv += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
+                    ws_add_res8(lo, hv, rv);
                 }
                 const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
                 half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -519,8 +530,30 @@ bool dvid_wstat_preferred(const IgemmParams& p) {
     return per_wg >= 24;
 }
 
+static int wstat_launch_rows32(const IgemmParams& p, hipStream_t s);
+
+// The kernels take whole 32-row blocks (no lane masks in their loops); a ragged tail of < 32 rows goes to igemm2 -- same values.
 int dvid_wstat_launch(const IgemmParams& p, hipStream_t s) {
     if (!dvid_wstat_supported(p)) return DVID_ERR_UNSUPPORTED;
+    const int m0 = p.M & ~31, rem = p.M - m0;
+    if (m0) {
+        IgemmParams q = p;
+        q.M = m0;
+        const int rc = wstat_launch_rows32(q, s);
+        if (rc != DVID_OK) return rc;
+    }
+    if (rem) {
+        IgemmParams q = p;
+        q.M = rem;
+        q.in = p.in + (long)m0 * p.Kpad;
+        q.out = reinterpret_cast<half_t*>(p.out) + (long)m0 * p.ldc;
+        if (p.res) q.res = reinterpret_cast<const half_t*>(p.res) + (long)m0 * p.Cout;
+        return dvid_igemm2_launch(q, s);
+    }
+    return DVID_OK;
+}
+
+static int wstat_launch_rows32(const IgemmParams& p, hipStream_t s) {
     // layers with a residual: the row-coalesced variant (res3 conv3 0.460 vs 0.497 ms, res4 conv3 0.291 vs 0.300 at 104 frames); without
     // one (dynamic_layer, linear1) the accumulator-layout stores are as fast or faster (0.780 vs 0.791).  DVID_WSTAT_V2=0 / 1 forces one.
     static const int v2 = getenv("DVID_WSTAT_V2") ? atoi(getenv("DVID_WSTAT_V2")) : -1;
