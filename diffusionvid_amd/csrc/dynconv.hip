@@ -7,7 +7,7 @@
 // runtime's weight repack: P1T[j][c] (64x256) then P2T[c][j] (256x64), i.e. both are
 // "[N][K], K contiguous" MFMA B operands that each wave pulls straight from global memory
 // (every parameter is read exactly once per box).  The 49x256 RoI tile (zero-padded to 64 rows)
-// is staged once in LDS (528-byte pitch: conflict-free ds_read_b128 A fragments); the N
+// is staged once in LDS (528-byte pitch: conflict-free ds_read_b128 fragments); the N
 // dimension of both products is split over the 4 waves, so LayerNorm row statistics are
 // combined across waves through a tiny LDS buffer (mean first, then centred variance, fp32).
 #include "common.h"
@@ -21,15 +21,18 @@ constexpr int DD = 64;          // dynamic dim
 constexpr int A_PITCH = D + 8;  // halves
 constexpr int H_PITCH = DD + 8;
 
-__device__ __forceinline__ float group16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+// sum over the four 16-lane groups of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48)
+__device__ __forceinline__ float groups4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 
-__global__ __launch_bounds__(256) void dynconv_kernel(const half_t* __restrict__ roi, const half_t* __restrict__ params,
+// Both products are computed TRANSPOSED (the per-box parameters are the MFMA's first operand): a lane then holds 4 consecutive
+// channels of ONE tile row instead of 4 rows of one channel, so a LayerNorm statistic is 3-15 in-lane adds + 2 shuffles per row tile
+// (it was 4 shuffles per accumulator register: 64 per pass), and the fp16 results leave as 8-byte LDS writes (they were 2-byte ones).
+// Same products, same K order; only the order of the fp32 sums inside the LayerNorm statistics differs from the row-major form.
+__global__ __launch_bounds__(256, 3) void dynconv_kernel(const half_t* __restrict__ roi, const half_t* __restrict__ params,
                                                        const float* __restrict__ g1, const float* __restrict__ b1,
                                                        const float* __restrict__ g2, const float* __restrict__ b2,
                                                        half_t* __restrict__ out) {
@@ -52,14 +55,14 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const half_t* __restrict__
         const half8 v = *reinterpret_cast<const half8*>(roi_b + (long)(r < NP ? r : 0) * D + cv * 8);
         *reinterpret_cast<half8*>(As + r * A_PITCH + cv * 8) = (r < NP) ? v : zero8;
     }
-    // B fragments of bmm #1: this wave owns output columns [wave*16, +16)
+    // parameter fragments of bmm #1: this wave owns output channels [wave*16, +16)
     half8 bf[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
         bf[ks] = *reinterpret_cast<const half8*>(p1t + (wave * 16 + l15) * D + ks * 32 + l4 * 8);
     __syncthreads();
 
-    // ---- bmm #1: [64x256] x [256x16] per wave ----------------------------------------
+    // ---- bmm #1 (transposed): acc1[mt][r] = F1[row mt*16 + l15][channel wave*16 + 4*l4 + r] -----------------------------
     float4v acc1[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc1[mt] = (float4v){0.f, 0.f, 0.f, 0.f};
@@ -68,10 +71,10 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const half_t* __restrict__
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const half8 af = *reinterpret_cast<const half8*>(As + (mt * 16 + l15) * A_PITCH + ks * 32 + l4 * 8);
-            acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[ks], acc1[mt], 0, 0, 0);
+            acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks], af, acc1[mt], 0, 0, 0);
         }
     }
-    // prefetch this wave's bmm #2 B fragments (columns [wave*64, +64)), first K half
+    // prefetch this wave's bmm #2 parameter fragments (channels [wave*64, +64))
     half8 b2f[4][2];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -79,48 +82,47 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const half_t* __restrict__
         for (int ks = 0; ks < 2; ++ks)
             b2f[nt][ks] = *reinterpret_cast<const half8*>(p2t + (wave * 64 + nt * 16 + l15) * DD + ks * 32 + l4 * 8);
 
-    // ---- LayerNorm(64) + ReLU over rows; element (row = mt*16 + l4*4 + r, col = wave*16 + l15)
-    float mean[4][4], rstd[4][4];
+    // ---- LayerNorm(64) + ReLU over rows ------------------------------------------------------------------------------------
+    float mean[4], rstd[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float s = group16_sum(acc1[mt][r]);
-            if (l15 == 0) red[(mt * 16 + l4 * 4 + r) * 4 + wave] = s;
-        }
+    for (int mt = 0; mt < 4; ++mt) {
+        const float s = groups4_sum((acc1[mt][0] + acc1[mt][1]) + (acc1[mt][2] + acc1[mt][3]));
+        if (l4 == 0) red[(mt * 16 + l15) * 4 + wave] = s;
+    }
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float4v t = *reinterpret_cast<const float4v*>(red + (mt * 16 + l4 * 4 + r) * 4);
-            mean[mt][r] = (t[0] + t[1] + t[2] + t[3]) * (1.f / DD);
-        }
+    for (int mt = 0; mt < 4; ++mt) {
+        const float4v t = *reinterpret_cast<const float4v*>(red + (mt * 16 + l15) * 4);
+        mean[mt] = (t[0] + t[1] + t[2] + t[3]) * (1.f / DD);
+    }
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float c = acc1[mt][r] - mean[mt][r];
-            const float s = group16_sum(c * c);
-            if (l15 == 0) red[(mt * 16 + l4 * 4 + r) * 4 + wave] = s;
+            const float c = acc1[mt][r] - mean[mt];
+            s += c * c;
         }
+        s = groups4_sum(s);
+        if (l4 == 0) red[(mt * 16 + l15) * 4 + wave] = s;
+    }
     __syncthreads();
     {
-        const float gg = g1[wave * 16 + l15], bb = b1[wave * 16 + l15];
+        const float4v gg = *reinterpret_cast<const float4v*>(g1 + wave * 16 + l4 * 4), bb = *reinterpret_cast<const float4v*>(b1 + wave * 16 + l4 * 4);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt) {
+            const float4v t = *reinterpret_cast<const float4v*>(red + (mt * 16 + l15) * 4);
+            rstd[mt] = rsqrtf((t[0] + t[1] + t[2] + t[3]) * (1.f / DD) + 1e-5f);
+            half4 y;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float4v t = *reinterpret_cast<const float4v*>(red + (mt * 16 + l4 * 4 + r) * 4);
-                rstd[mt][r] = rsqrtf((t[0] + t[1] + t[2] + t[3]) * (1.f / DD) + 1e-5f);
-                const float y = fmaxf((acc1[mt][r] - mean[mt][r]) * rstd[mt][r] * gg + bb, 0.f);
-                Hs[(mt * 16 + l4 * 4 + r) * H_PITCH + wave * 16 + l15] = (half_t)y;
-            }
+            for (int r = 0; r < 4; ++r) y[r] = (half_t)fmaxf((acc1[mt][r] - mean[mt]) * rstd[mt] * gg[r] + bb[r], 0.f);
+            *reinterpret_cast<half4*>(Hs + (mt * 16 + l15) * H_PITCH + wave * 16 + l4 * 4) = y;
+        }
     }
     __syncthreads();   // Hs complete; As (RoI) is dead from here on; red reusable
 
-    // ---- bmm #2: [64x64] x [64x64] per wave --------------------------------------------
+    // ---- bmm #2 (transposed): acc2[mt][nt][r] = F2[row mt*16 + l15][channel wave*64 + nt*16 + 4*l4 + r] -------------------
     float4v acc2[4][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -133,58 +135,55 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const half_t* __restrict__
             const half8 af = *reinterpret_cast<const half8*>(Hs + (mt * 16 + l15) * H_PITCH + ks * 32 + l4 * 8);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, b2f[nt][ks], acc2[mt][nt], 0, 0, 0);
+                acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2f[nt][ks], af, acc2[mt][nt], 0, 0, 0);
         }
     }
-    // ---- LayerNorm(256) + ReLU; element (row = mt*16 + l4*4 + r, col = wave*64 + nt*16 + l15)
+    // ---- LayerNorm(256) + ReLU ----------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float s = group16_sum(acc2[mt][0][r] + acc2[mt][1][r] + acc2[mt][2][r] + acc2[mt][3][r]);
-            if (l15 == 0) red[(mt * 16 + l4 * 4 + r) * 4 + wave] = s;
-        }
+        for (int nt = 0; nt < 4; ++nt) s += (acc2[mt][nt][0] + acc2[mt][nt][1]) + (acc2[mt][nt][2] + acc2[mt][nt][3]);
+        s = groups4_sum(s);
+        if (l4 == 0) red[(mt * 16 + l15) * 4 + wave] = s;
+    }
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float4v t = *reinterpret_cast<const float4v*>(red + (mt * 16 + l4 * 4 + r) * 4);
-            mean[mt][r] = (t[0] + t[1] + t[2] + t[3]) * (1.f / D);
-        }
+    for (int mt = 0; mt < 4; ++mt) {
+        const float4v t = *reinterpret_cast<const float4v*>(red + (mt * 16 + l15) * 4);
+        mean[mt] = (t[0] + t[1] + t[2] + t[3]) * (1.f / D);
+    }
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const float c = acc2[mt][nt][r] - mean[mt][r];
-                s += c * c;
-            }
-            s = group16_sum(s);
-            if (l15 == 0) red[(mt * 16 + l4 * 4 + r) * 4 + wave] = s;
-        }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float4v t = *reinterpret_cast<const float4v*>(red + (mt * 16 + l4 * 4 + r) * 4);
-            rstd[mt][r] = rsqrtf((t[0] + t[1] + t[2] + t[3]) * (1.f / D) + 1e-5f);
-        }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int col = wave * 64 + nt * 16 + l15;
-        const float gg = g2[col], bb = b2[col];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float y = fmaxf((acc2[mt][nt][r] - mean[mt][r]) * rstd[mt][r] * gg + bb, 0.f);
-                As[(mt * 16 + l4 * 4 + r) * A_PITCH + col] = (half_t)y;
+                const float c = acc2[mt][nt][r] - mean[mt];
+                s += c * c;
             }
+        s = groups4_sum(s);
+        if (l4 == 0) red[(mt * 16 + l15) * 4 + wave] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const float4v t = *reinterpret_cast<const float4v*>(red + (mt * 16 + l15) * 4);
+        rstd[mt] = rsqrtf((t[0] + t[1] + t[2] + t[3]) * (1.f / D) + 1e-5f);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = wave * 64 + nt * 16 + l4 * 4;
+        const float4v gg = *reinterpret_cast<const float4v*>(g2 + col), bb = *reinterpret_cast<const float4v*>(b2 + col);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            half4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (half_t)fmaxf((acc2[mt][nt][r] - mean[mt]) * rstd[mt] * gg[r] + bb[r], 0.f);
+            *reinterpret_cast<half4*>(As + (mt * 16 + l15) * A_PITCH + col) = y;
+        }
     }
     __syncthreads();
     // ---- coalesced 16-byte stores of the 49 valid rows ---------------------------------
