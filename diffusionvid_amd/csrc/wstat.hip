@@ -26,7 +26,6 @@
 namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_ws[4] = {0u, 0u, 0u, 0u};
-__device__ __attribute__((aligned(16))) unsigned int g_dump_ws[64 * 4];      // where the lanes of rows past M store (one 16-byte slot per lane)
 
 // x + float(h) in one instruction: v_fma_mix_f32 (h * 1.0 + x, fp16 source promoted exactly, one rounding -- the value of cvt + add)
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
@@ -62,32 +61,31 @@ __device__ __forceinline__ void ws_glds16(const void* gsrc, char* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int K, int D, int TPS, int NW>
+template <int K, int D, int TN, bool HAS_RES>
 struct WsSmem {
     static constexpr int kATile = 32 * K * 2;
-    static constexpr int kRTile = NW * 2048;
-    static constexpr int kStage = TPS * (kATile + kRTile);
+    static constexpr int kRTile = HAS_RES ? 8 * TN * 2048 : 0;       // per wave and accumulator tile: 2 pieces of 1 KiB
+    static constexpr int kStage = kATile + kRTile;
     static constexpr int kBytes = D * kStage;
 };
 
-// K: reduction length (= Cin = Kpad); TPS: 32-row tiles per step (one counted wait + one barrier per step; the TPS MFMA chains of a
-// wave are independent and issue interleaved); D: ring depth in steps (steps s + 1 .. s + D - 1 in flight while step s is computed);
-// HAS_RES: same-shape fp16 residual; RELU.  Grid: 256 workgroups x 512 threads.
-template <int K, int D, int TPS, int NW, bool HAS_RES, bool RELU>
-__global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, int nslab) {
-    constexpr int WPX = 256 / NW;                 // workgroups per XCD: 8 waves -> one workgroup per CU, 4 waves -> two
-    constexpr int SLAB = 32 * NW;                 // output channels per workgroup
+// K: reduction length (= Cin = Kpad); D: ring depth (tiles t + 1 .. t + D - 1 in flight while tile t is computed); TN: 32-channel
+// accumulator tiles per wave (a workgroup owns 256 TN channels; the TN chains of a wave share every A fragment read and the A tile's
+// DMA serves TN times the outputs); HAS_RES: same-shape fp16 residual; RELU.  Grid: 256 workgroups x 512 threads.  M % 32 == 0.
+template <int K, int D, int TN, bool HAS_RES, bool RELU>
+__global__ __launch_bounds__(512) void wstat_kernel(IgemmParams p, int nslab) {
+    constexpr int NW = 8, WPX = 32;
+    constexpr int SLAB = 256 * TN;                // output channels per workgroup
     constexpr int CH = K / 8;                     // 16-byte chunks per A row
-    constexpr int RPP = (K >= 512) ? 1 : 512 / K; // A rows per 1-KiB DMA piece
+    constexpr int RPP = 512 / K;                  // A rows per 1-KiB DMA piece
     constexpr int PIECES = 32 / RPP;              // A pieces per tile
     constexpr int APW = PIECES / NW;              // ... per wave
-    constexpr int RP = HAS_RES ? 2 : 0;           // residual pieces per wave per tile
-    constexpr int LG = TPS * (APW + RP);          // DMA instructions per wave per step
-    constexpr int SG = TPS * 2;                   // store instructions per wave per step
+    constexpr int RP = HAS_RES ? 2 * TN : 0;      // residual pieces per wave per tile
+    constexpr int LG = APW + RP;                  // DMA instructions per wave per step
+    constexpr int SG = 2 * TN;                    // store instructions per wave per step
     constexpr int KS = K / 16;
-    constexpr int A_TILE = WsSmem<K, D, TPS, NW>::kATile;
-    constexpr int R_TILE = WsSmem<K, D, TPS, NW>::kRTile;
-    constexpr int STAGE = WsSmem<K, D, TPS, NW>::kStage;
+    constexpr int A_TILE = WsSmem<K, D, TN, HAS_RES>::kATile;
+    constexpr int STAGE = WsSmem<K, D, TN, HAS_RES>::kStage;
     static_assert(PIECES % NW == 0 && APW >= 1, "every wave issues the same number of A pieces");
     static_assert((D - 2) * LG + (D - 1) * SG < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,12 +94,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lrow = lane & 31;
-    const char* const zero = reinterpret_cast<const char*>(g_zero_page_ws);
 
     // ---- rows of this workgroup: XCD x (= blockIdx % 8 under round-robin dispatch) owns an eighth of the 32-row blocks; inside it
     // the 32 workgroups are (sub-range, slab) pairs, or -- more than 32 slabs -- each walks slabs q, q + 32, ... over the whole eighth
     const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
-    const int MB = (p.M + 31) >> 5;
+    const int MB = p.M >> 5;
     const int xb0 = (int)((long)MB * xcd / 8), xb1 = (int)((long)MB * (xcd + 1) / 8);
     int blk0 = xb0, blk1 = xb1, slab0 = q, slab_step = WPX;
     if (nslab <= WPX) {
@@ -113,42 +110,41 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
     }
     const int T = blk1 - blk0;                   // tiles
     if (T <= 0) return;                          // workgroup-uniform
-    const int S = (T + TPS - 1) / TPS;           // steps
 
     // ---- A pieces: piece j = wave + NW * i covers tile rows [RPP j, RPP j + RPP); lane -> (row, physical chunk).  The LDS image is
     // lane-linear; the XOR swizzle (key = row & 15) is applied to the SOURCE chunk and again on the fragment read.
     const char* a_src[APW];
-    int a_rowm[APW];                             // global row of this lane's piece row in tile 0
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
         const int piece = wave + NW * i;
-        const int row = piece * RPP + (CH >= 64 ? 0 : lane / CH);
-        const int pch = lane % CH;
-        const int lch = pch ^ (row & 15);
-        a_rowm[i] = blk0 * 32 + row;
-        a_src[i] = reinterpret_cast<const char*>(p.in) + ((long)a_rowm[i] * K + lch * 8) * 2;
+        const int row = piece * RPP + lane / CH;
+        const int lch = (lane % CH) ^ (row & 15);
+        a_src[i] = reinterpret_cast<const char*>(p.in) + ((long)(blk0 * 32 + row) * K + lch * 8) * 2;
     }
     const int frag_key = lrow & 15;
     const int frag_row_off = lrow * (K * 2);
 
     for (int slab = slab0; slab < nslab; slab += slab_step) {
-        const int n0 = slab * SLAB + 32 * wave;            // first channel of this wave
-        // ---- weights of this wave's 32 channels as MFMA first operands: lane -> (channel n0 + lane % 32, k = 16 ks + 8 (lane / 32))
-        half8 bf[KS];
-        {
-            const half_t* wrow = p.w + (long)(n0 + lrow) * p.Kpad + 8 * hi;
+        const int n0 = slab * SLAB + 32 * TN * wave;          // first channel of this wave
+        // ---- weights of this wave's 32 TN channels as MFMA first operands: lane -> (channel n0 + 32 j + lane % 32, k = 16 ks + 8 (lane / 32))
+        half8 bf[TN][KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) bf[ks] = *reinterpret_cast<const half8*>(wrow + 16 * ks);
+        for (int j = 0; j < TN; ++j) {
+            const half_t* wrow = p.w + (long)(n0 + 32 * j + lrow) * p.Kpad + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bf[j][ks] = *reinterpret_cast<const half8*>(wrow + 16 * ks);
         }
-        // bias of the channels this lane finishes: group g = channels n0 + 16 g + 8 hi + [0, 8)
-        float bs[2][8];
+        // bias of the channels this lane finishes: tile j, group g = channels n0 + 32 j + 16 g + 8 hi + [0, 8)
+        float bs[TN][2][8];
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bs[g][e] = p.bias ? p.bias[n0 + 16 * g + 8 * hi + e] : 0.f;
-        // residual / output addresses of this lane's row in tile 0, group 0
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bs[j][g][e] = p.bias ? p.bias[n0 + 32 * j + 16 * g + 8 * hi + e] : 0.f;
+        // residual / output addresses of this lane's row in tile 0, accumulator tile 0, group 0
         const long col = n0 + 8 * hi;
-        const char* r_src = HAS_RES ? reinterpret_cast<const char*>(p.res) + ((long)(blk0 * 32 + lrow) * p.Cout + col) * 2 : zero;
+        const char* r_src = HAS_RES ? reinterpret_cast<const char*>(p.res) + ((long)(blk0 * 32 + lrow) * p.Cout + col) * 2 : nullptr;
         half_t* o_dst = reinterpret_cast<half_t*>(p.out) + (long)(blk0 * 32 + lrow) * p.ldc + col;
         const char* a_cur[APW];
 #pragma unroll
@@ -158,64 +154,61 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
         // first use, with the prologue's DMA in flight), and no wave still reads the previous slab's last tiles
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bf[ks]));
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bf[j][ks]));
         __builtin_amdgcn_s_barrier();
 
-        // DMA of step `si` (per tile: A pieces, then this wave's residual pieces) into stage si % D.  M is a multiple of 32 here (the
-        // launcher hands a ragged tail to igemm2), so no lane needs a mask; the waits count instructions, so steps past the range
-        // issue theirs too (re-fetching the last tile)
-        auto issue = [&](int si) {
-            char* const stg = smem + (si % D) * STAGE;
+        // DMA of tile `ti` (A pieces, then this wave's residual pieces) into stage ti % D.  M is a multiple of 32 here (the launcher hands
+        // a ragged tail to igemm2), so no lane needs a mask; the waits count instructions, so steps past the range issue theirs too
+        // (re-fetching the last tile)
+        auto issue = [&](int ti) {
+            char* const stg = smem + (ti % D) * STAGE;
+            const bool more = ti + 1 < T;        // wave-uniform
 #pragma unroll
-            for (int j = 0; j < TPS; ++j) {
-                const int ti = si * TPS + j;
-                const bool more = ti + 1 < T;        // (wave-uniform) past the range the last tile is fetched again: same instruction count, no masks
+            for (int i = 0; i < APW; ++i) {
+                ws_glds16(a_cur[i], stg + (wave + NW * i) * 1024);
+                a_cur[i] += more ? 32 * K * 2 : 0;
+            }
+            if (HAS_RES) {
 #pragma unroll
-                for (int i = 0; i < APW; ++i) {
-                    ws_glds16(a_cur[i], stg + j * A_TILE + (wave + NW * i) * 1024);
-                    a_cur[i] += more ? 32 * K * 2 : 0;
-                }
-                if (HAS_RES) {
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) ws_glds16(r_src + 32 * g, stg + TPS * A_TILE + j * R_TILE + (wave * 2 + g) * 1024);
-                    r_src += more ? (long)32 * p.Cout * 2 : 0L;
-                }
+                    for (int g = 0; g < 2; ++g) ws_glds16(r_src + 64 * j + 32 * g, stg + A_TILE + ((wave * TN + j) * 2 + g) * 1024);
+                r_src += more ? (long)32 * p.Cout * 2 : 0L;
             }
         };
 #pragma unroll
         for (int d = 0; d < D - 1; ++d) issue(d);
 
-        for (int si = 0; si < S; ++si) {
-            // own pieces of step si have landed.  Issued after them: the loads of steps si + 1 .. si + D - 2 and the stores of the last
+        for (int t = 0; t < T; ++t) {
+            // own pieces of tile t have landed.  Issued after them: the loads of tiles t + 1 .. t + D - 2 and the stores of the last
             // (up to) D - 1 steps; vmcnt retires in issue order.
-            if (si >= D - 1) ws_wait_vmcnt<(D - 2) * LG + (D - 1) * SG>();
+            if (t >= D - 1) ws_wait_vmcnt<(D - 2) * LG + (D - 1) * SG>();
             else ws_wait_vmcnt<(D - 2) * LG>();
-            __builtin_amdgcn_s_barrier();        // step si visible to every wave; nobody reads step si - 1 any more
+            __builtin_amdgcn_s_barrier();        // tile t visible to every wave; nobody reads tile t - 1 any more
             asm volatile("" ::: "memory");
-            issue(si + D - 1);                   // into the stage of step si - 1
+            issue(t + D - 1);                    // into the stage of tile t - 1
 
-            const char* const stg = smem + (si % D) * STAGE;
-            float16v acc[TPS];
+            const char* const stg = smem + (t % D) * STAGE;
+            float16v acc[TN];
 #pragma unroll
-            for (int j = 0; j < TPS; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-            // TPS independent chains, K ascending, sharing the weight fragment of each K step
-            // TPS independent chains, K ascending, sharing the weight fragment of each K step.  (Pinning all fragment reads in front of the
-            // first MFMA, two tiles per step, the epilogue of tile t - 1 spread over the MFMAs of tile t, and 4-wave workgroups two to a
-            // CU were all measured: none is faster -- profiles/r02_wstat.txt.)
+            // TN chains, K ascending, sharing the A fragment of each K step.  (Pinning all fragment reads in front of the first MFMA, two
+            // row tiles per step, a skewed epilogue, anti-phase wave groups and 4-wave workgroups two to a CU were all measured: none is
+            // faster -- the step is bound by its instruction count, profiles/r02_wstat.txt.)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+                const half8 fa = *reinterpret_cast<const half8*>(stg + frag_row_off + (((2 * ks + hi) ^ frag_key) * 16));
 #pragma unroll
-                for (int j = 0; j < TPS; ++j) {
-                    const half8 fa = *reinterpret_cast<const half8*>(stg + j * A_TILE + frag_row_off + (((2 * ks + hi) ^ frag_key) * 16));
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], fa, acc[j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][ks], fa, acc[j], 0, 0, 0);
             }
             // ---- epilogue from the accumulator layout.  acc[4 r4 + r] = channel 8 r4 + 4 hi + r of row lane % 32; one half-wave
             // exchange per register pair (r4, r4 + 1) leaves lane < 32 with channels 16 g + [0, 8) and lane >= 32 with 16 g + 8 + [0, 8).
 #pragma unroll
-            for (int j = 0; j < TPS; ++j) {
+            for (int j = 0; j < TN; ++j) {
                 unsigned int u[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -230,36 +223,27 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wstat_kernel(IgemmParams p, i
                         u[8 * g + r] = sw[0];
                         u[8 * g + 4 + r] = sw[1];
                     }
-                const int ti = si * TPS + j;
-                const bool row_ok = ti < T;          // (only the second tile of the last step can be past the range)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     float4v lo, hv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        lo[e] = __uint_as_float(u[8 * g + e]) + bs[g][e];
-                        hv[e] = __uint_as_float(u[8 * g + 4 + e]) + bs[g][4 + e];
+                        lo[e] = __uint_as_float(u[8 * g + e]) + bs[j][g][e];
+                        hv[e] = __uint_as_float(u[8 * g + 4 + e]) + bs[j][g][4 + e];
                     }
                     if (HAS_RES) {
-                        const half8 rv = *reinterpret_cast<const half8*>(stg + TPS * A_TILE + j * R_TILE + (wave * 2 + g) * 1024 + lane * 16);
+                        const half8 rv = *reinterpret_cast<const half8*>(stg + A_TILE + ((wave * TN + j) * 2 + g) * 1024 + lane * 16);
                         ws_add_res8(lo, hv, rv);
                     }
                     const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
                     half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
                     if (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
-                    if (TPS == 1) {
-                        *reinterpret_cast<half8*>(o_dst + 16 * g) = o;
-                    } else {
-                        // a tile past the range stores to a dump slot: no branch in the loop body, every step issues all its stores
-                        half_t* dst = row_ok ? o_dst + 16 * g : reinterpret_cast<half_t*>(g_dump_ws) + lane * 8;
-                        asm volatile("" : "+v"(dst));
-                        *(__attribute__((address_space(1))) half8*)dst = o;      // a global store (a flat one would also count on lgkmcnt)
-                    }
+                    *reinterpret_cast<half8*>(o_dst + 32 * j + 16 * g) = o;
                 }
-                o_dst += (long)32 * p.ldc;
             }
+            o_dst += (long)32 * p.ldc;
         }
-        // the tail's zero-page DMAs and this slab's residual reads retire before the next slab's prologue re-uses the stages
+        // the tail's extra DMAs and this slab's residual reads retire before the next slab's prologue re-uses the stages
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
 }
@@ -484,26 +468,28 @@ int ws2_launch_v(const IgemmParams& p, hipStream_t s) {
     return relu ? ws2_launch_k<K, D, false, true>(p, s) : ws2_launch_k<K, D, false, false>(p, s);
 }
 
-template <int K, int D, int TPS, int NW, bool HAS_RES, bool RELU>
+template <int K, int D, int TN, bool HAS_RES, bool RELU>
 int ws_launch_k(const IgemmParams& p, hipStream_t s) {
-    constexpr int smem = WsSmem<K, D, TPS, NW>::kBytes;
-    static_assert(smem * (8 / NW) <= 160 * 1024, "LDS");
-    const int nslab = p.Cout / (32 * NW);
+    constexpr int smem = WsSmem<K, D, TN, HAS_RES>::kBytes;
+    static_assert(smem <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat_kernel<K, D, TPS, NW, HAS_RES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat_kernel<K, D, TN, HAS_RES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((wstat_kernel<K, D, TPS, NW, HAS_RES, RELU>), dim3(2048 / NW), dim3(64 * NW), smem, s, p, nslab);
+    hipLaunchKernelGGL((wstat_kernel<K, D, TN, HAS_RES, RELU>), dim3(256), dim3(512), smem, s, p, p.Cout / (256 * TN));
     LAUNCH_CHECK();
     return DVID_OK;
 }
 
-template <int K, int D, int TPS, int NW>
+template <int K, int D, int TN>
 int ws_launch_v(const IgemmParams& p, hipStream_t s) {
     const bool res = p.res_mode == 1, relu = p.relu == 1;
-    if (res) return relu ? ws_launch_k<K, D, TPS, NW, true, true>(p, s) : ws_launch_k<K, D, TPS, NW, true, false>(p, s);
-    return relu ? ws_launch_k<K, D, TPS, NW, false, true>(p, s) : ws_launch_k<K, D, TPS, NW, false, false>(p, s);
+    if constexpr (TN == 1) {          // (64 channels per wave + a residual ring does not fit the LDS; those layers take the row-coalesced kernel anyway)
+        if (res) return relu ? ws_launch_k<K, D, TN, true, true>(p, s) : ws_launch_k<K, D, TN, true, false>(p, s);
+    }
+    if (res) return DVID_ERR_UNSUPPORTED;
+    return relu ? ws_launch_k<K, D, TN, false, true>(p, s) : ws_launch_k<K, D, TN, false, false>(p, s);
 }
 
 }  // namespace
@@ -555,9 +541,14 @@ int dvid_wstat_launch(const IgemmParams& p, hipStream_t s) {
 
 static int wstat_launch_rows32(const IgemmParams& p, hipStream_t s) {
     // layers with a residual: the row-coalesced variant (res3 conv3 0.460 vs 0.497 ms, res4 conv3 0.291 vs 0.300 at 104 frames); without
-    // one (dynamic_layer, linear1) the accumulator-layout stores are as fast or faster (0.780 vs 0.791).  DVID_WSTAT_V2=0 / 1 forces one.
+    // one (dynamic_layer, linear1) the accumulator-layout stores are as fast or faster (0.780 vs 0.791), and 64 channels per wave
+    // (512-channel slabs: every A fragment read and every DMA piece serves two MFMA chains) where the slab count allows it.
+    // DVID_WSTAT_V2=0 / 1 forces one, DVID_WSTAT_TN=1 the 32-channel form.
     static const int v2 = getenv("DVID_WSTAT_V2") ? atoi(getenv("DVID_WSTAT_V2")) : -1;
+    static const int tn_env = getenv("DVID_WSTAT_TN") ? atoi(getenv("DVID_WSTAT_TN")) : 2;
     if (v2 > 0 || (v2 < 0 && p.res_mode == 1)) return p.Kpad == 128 ? ws2_launch_v<128, 4>(p, s) : ws2_launch_v<256, 3>(p, s);
-    if (p.Kpad == 128) return ws_launch_v<128, 6, 1, 8>(p, s);
-    return ws_launch_v<256, 4, 1, 8>(p, s);
+    const int ns2 = p.Cout / 512;
+    const bool wide = tn_env == 2 && p.res_mode == 0 && p.Cout % 512 == 0 && ns2 >= 32 && ns2 % 32 == 0;      // dynamic_layer: 0.749 vs 0.775 ms; linear1 (4 slabs) is slower that way
+    if (p.Kpad == 128) return wide ? ws_launch_v<128, 6, 2>(p, s) : ws_launch_v<128, 6, 1>(p, s);
+    return wide ? ws_launch_v<256, 4, 2>(p, s) : ws_launch_v<256, 4, 1>(p, s);
 }
