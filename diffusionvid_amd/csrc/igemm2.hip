@@ -297,7 +297,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j], 0, 0, 0);      // transposed: see the epilogue
         }
         // pin the issue order the source spells out (hipcc otherwise folds the two register sets into one and waits
         // for every read right before its MFMAs): reads(0), then per sub-step reads(ks+1) ahead of MFMAs(ks)
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 const int ks = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
                 if (ld && q % (NM / P) == 1) rg[q / (NM / P)] = *reinterpret_cast<const half8*>(piece_src(q / (NM / P)));
             }
             if (ld) advance();
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 const int ks = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
                 if (dma && q % (NM / P) == 1) issue_piece(kt0 + t + 3, (t + 3) & 3, q / (NM / P));
             }
             if (dma) advance();
@@ -486,15 +486,19 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     for (int half = 0; half < 2; ++half) {
         if (half) __syncthreads();
         if (wm == half) {
+            // The products are computed transposed (the weight fragment is the MFMA's first operand: D[n][m], same sums bit for bit),
+            // so a lane holds 4 consecutive channels of ONE tile row per register quad: 16-byte LDS writes, 4 per accumulator tile
+            // instead of 16 scalar ones (the short-K layers are bound by their instruction count).
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        const int col = wn * (BN / WN) + j * 32 + (lane & 31);
-                        Cs[row * CP + col] = acc[i][j][r];
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int row = i * 32 + (lane & 31);
+                        const int col = wn * (BN / WN) + j * 32 + 8 * r4 + 4 * (lane >> 5);
+                        *reinterpret_cast<float4v*>(Cs + row * CP + col) =
+                            (float4v){acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
                     }
         }
         __syncthreads();
