@@ -19,7 +19,7 @@ host sync; --lookahead 1 is the reference's schedule and gives the same detectio
 
 Extra objects on the JSON line:
   roofline     the dominant kernels are the implicit-GEMM MFMA conv/linear kernels (igemm2_kernel<...>, and conv3x3_* for the
-               3x3 / stride-1 layers; ~80 % of the GPU time, profiles/r02_kernel_stats.txt).  An instrumented repeat of one
+               3x3 / stride-1 layers; ~80 % of the GPU time, profiles/r02c_kernel_stats.txt).  An instrumented repeat of one
                step right after the timed region brackets every such launch with HIP events on its launch stream (sub-batch
                chains off, so launches do not overlap) and sums durations, algorithmic FLOP (2*M*N*K) and the layer-wise
                byte model (input + weights + output + residual, each once).  bound = "mfma" (249.3 GFLOP
@@ -51,7 +51,7 @@ from diffusionvid_amd.engine import inference as engine  # noqa: E402
 from diffusionvid_amd.modeling.detector import build_detection_model  # noqa: E402
 from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
-TRAFFIC_FILE = "r02_pmc_igemm_traffic.json"
+TRAFFIC_FILE = "r02c_pmc_igemm_traffic.json"
 PEAK_FP16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 # algorithmic work per output frame: backbone + heads + global attention, faithful pass counts
