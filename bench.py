@@ -13,13 +13,13 @@ value = frames emitted by all ranks / max-over-ranks wall time (barrier + device
 N > 1: one process per GPU, each rank owns whole videos (weak scaling, no data-path collective); the
 single RCCL gather of the predictions to rank 0 is inside the timed region.
 
-Schedule: INPUT.LOOKAHEAD_BATCHES (--lookahead, default 13 = 104 frames) 8-frame batches are processed as one group:
+Schedule: INPUT.LOOKAHEAD_BATCHES (--lookahead, default 38 = the whole 304-frame video; 104-frame groups measured 3-5 % slower) 8-frame batches are processed as one group:
 every stage is per-frame independent given the video's global memory, so the group shares its launches and its one
 host sync; --lookahead 1 is the reference's schedule and gives the same detections (tests/test_gpu_e2e.py::test_lookahead_batches_do_not_change_results).
 
 Extra objects on the JSON line:
   roofline     the dominant kernels are the implicit-GEMM MFMA conv/linear kernels (igemm2_kernel<...>, and conv3x3_* for the
-               3x3 / stride-1 layers; ~80 % of the GPU time, profiles/r02c_kernel_stats.txt).  An instrumented repeat of one
+               3x3 / stride-1 layers; ~80 % of the GPU time, profiles/r02d_kernel_stats.txt).  An instrumented repeat of one
                step right after the timed region brackets every such launch with HIP events on its launch stream (sub-batch
                chains off, so launches do not overlap) and sums durations, algorithmic FLOP (2*M*N*K) and the layer-wise
                byte model (input + weights + output + residual, each once).  bound = "mfma" (249.3 GFLOP
@@ -51,7 +51,7 @@ from diffusionvid_amd.engine import inference as engine  # noqa: E402
 from diffusionvid_amd.modeling.detector import build_detection_model  # noqa: E402
 from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
-TRAFFIC_FILE = "r02c_pmc_igemm_traffic.json"
+TRAFFIC_FILE = "r02d_pmc_igemm_traffic.json"
 PEAK_FP16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 # algorithmic work per output frame: backbone + heads + global attention, faithful pass counts
@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--frames", type=int, default=304, help="frames per synthetic video")
     ap.add_argument("--lookahead", type=int, default=0,
                     help="INPUT.LOOKAHEAD_BATCHES: INFER_BATCH groups whose backbone + extraction heads share one launch sequence "
-                         "(1 = the reference's schedule; default 0 = 104 frames' worth: 13 for R101, 26 for Swin-B)")
+                         "(1 = the reference's schedule; default 0 = 304 frames' worth: 38 for R101, 76 for Swin-B)")
     ap.add_argument("--arch", choices=("r101", "swinb"), default="r101",
                     help="r101 = the BASELINE.json headline configuration; swinb = configs/vid_Swin_B_DiffusionVID.yaml (INFER_BATCH 4)")
     ap.add_argument("--sample-step", type=int, default=1, help="MODEL.DiffusionDet.SAMPLE_STEP (4 = the x4 configuration)")
@@ -262,7 +262,7 @@ def main():
 
     headline = args.arch == "r101" and args.sample_step == 1
     if args.lookahead <= 0:
-        args.lookahead = 13 if args.arch == "r101" else 26
+        args.lookahead = 38 if args.arch == "r101" else 76          # one launch group per 304-frame video (~60 GB of workspace on a 288 GB part)
     H, W, L = 600, 1000, args.frames
 
     def barrier():
@@ -432,10 +432,10 @@ def main():
     if not args.no_side_configs:
         side("reference_protocol_lookahead_1", args.arch, args.sample_step, 1, 2)
         if headline and world == 1:
-            side("r101_x4", "r101", 4, 13, 2)
+            side("r101_x4", "r101", 4, 38, 2)
             # 12 observable head passes per frame instead of the faithful 19 (same detections)
-            side("r101_x4_observable_passes_only", "r101", 4, 13, 2, skip_unobservable=True)
-            side("swinb_x1", "swinb", 1, 26, 2)
+            side("r101_x4_observable_passes_only", "r101", 4, 38, 2, skip_unobservable=True)
+            side("swinb_x1", "swinb", 1, 76, 2)
 
     if rank == 0:
         line = {

@@ -298,10 +298,12 @@ def test_lookahead_batches_do_not_change_results(sample_step):
     print(f"[x{sample_step}] lookahead 4 vs 1: {n_exact}/64 frames bit-identical")
 
 
-@pytest.mark.parametrize("arch,sample_step,groups", [("r101", 1, (6, 13)), ("r101", 4, (13,)), ("swinb", 1, (26,))])
-def test_lookahead_invariance_full_size(arch, sample_step, groups):
-    """BASELINE.json's full configurations (ResNet-101 x1 / x4, Swin-B x1; 1000x600, 300 boxes) on one 120-frame video:
-    the bench schedules (groups of 48 / 104 frames per launch group) must reproduce the detections of the reference
+@pytest.mark.parametrize("arch,sample_step,groups,frames", [("r101", 1, (6, 13), 120), ("r101", 4, (13,), 120), ("swinb", 1, (26,), 120),
+                                                            ("r101", 1, (38,), 304), ("r101", 4, (38,), 304)])
+def test_lookahead_invariance_full_size(arch, sample_step, groups, frames):
+    """BASELINE.json's full configurations (ResNet-101 x1 / x4, Swin-B x1; 1000x600, 300 boxes) on one 120-frame video -- and on the
+    bench's own 304-frame video as ONE launch group (38 batches: 304 + 24 frames per launch sequence, 91200 boxes, a 6-GB
+    dynamic-parameter tensor whose element count exceeds 2^31): the bench schedules must reproduce the detections of the reference
     schedule (1) -- a size-independent property that also guards the index arithmetic at the largest launch sizes."""
     from diffusionvid_amd.config import get_cfg
     from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
@@ -316,12 +318,12 @@ def test_lookahead_invariance_full_size(arch, sample_step, groups):
         model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
         model = model.to("cuda").eval()
         model.noise_fn = synthetic.noise_fn
-        ds = SyntheticVIDDataset([120], cfg, height=600, width=1000, device="cuda", smooth=True)
+        ds = SyntheticVIDDataset([frames], cfg, height=600, width=1000, device="cuda", smooth=True)
         res = []
         with torch.no_grad():
             for idx in range(len(ds)):
                 res += model(ds[idx][0])
-        assert len(res) == 120
+        assert len(res) == frames
         outs[la] = [r.to(torch.device("cpu")) for r in res]
         del model, ds
         torch.cuda.empty_cache()
@@ -335,7 +337,7 @@ def test_lookahead_invariance_full_size(arch, sample_step, groups):
             assert torch.allclose(a.bbox, b.bbox, atol=1e-3, rtol=0)
             assert torch.allclose(a.get_field("scores"), b.get_field("scores"), atol=1e-5, rtol=0)
         assert sum(len(a) for a in outs[1]) > 0
-        print(f"{arch} x{sample_step}: look-ahead {la} vs 1 at full size: max |dbox| = {worst:.2e} px over 120 frames")
+        print(f"{arch} x{sample_step}: look-ahead {la} vs 1 at full size: max |dbox| = {worst:.2e} px over {frames} frames")
 
 
 @pytest.mark.parametrize("arch,sample_step", [("r101", 1), ("r101", 4), ("swinb", 1)])
