@@ -6,7 +6,10 @@
 // 64 queries x 4 key partitions, K/V tiles of 32 keys staged in LDS (row pitch 33 floats so the
 // four partitions land on distinct banks), online softmax per 8-key chunk, partitions merged
 // with wave shuffles.  Softmax statistics are fp32 as apex amp keeps them.
+#include <stdlib.h>
+
 #include "common.h"
+#include "igemm_epilogue.h"
 #include "kernels.h"
 
 namespace {
@@ -274,17 +277,29 @@ namespace {
 
 __global__ __launch_bounds__(256) void swin_window_attn_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ qkv_bias16,
                                                                 const float* __restrict__ relbias, half_t* __restrict__ out, int H,
-                                                                int W, int C, int nheads, int shift, float scaling) {
-    constexpr int WS = 7, NT = 49;
+                                                                int W, int C, int nheads, int shift, float scaling, int nwin,
+                                                                int head_major) {
+    constexpr int WS = 7, NT = 49, RB_PITCH = SWIN_RELBIAS_PITCH;
     __shared__ __attribute__((aligned(16))) half_t Ks[64 * 32];      // [key][32 dims]
     __shared__ __attribute__((aligned(16))) half_t Vt[32 * 72];      // [dim][key], pitch 72 halves
     __shared__ int tok[64];                                          // token row or -1 (padded position)
     __shared__ int region[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.y;
+    // Launch order.  The heads of a window read neighbouring 64-byte pieces of the same qkv rows (two heads per 128-byte line) and
+    // write neighbouring pieces of the same output rows: with the head innermost AND the workgroups of an XCD taking one contiguous
+    // run of (window, head) pairs, those pieces meet in that XCD's L2 while the line is there; window-major order per head (the
+    // former 2-D grid) fetched every line once per head that touches it.  head_major = 0 keeps the old order for A/B runs.
+    int h, wid;
+    if (head_major) {
+        const int lid = igemm_xcd_remap((int)blockIdx.x, nwin * nheads);
+        wid = lid / nheads;
+        h = lid - wid * nheads;
+    } else {
+        h = (int)blockIdx.x / nwin;
+        wid = (int)blockIdx.x - h * nwin;
+    }
     const int Hp = (H + WS - 1) / WS * WS, Wp = (W + WS - 1) / WS * WS;
     const int nwx = Wp / WS, nwy = Hp / WS;
-    int wid = blockIdx.x;
     const int wx = wid % nwx;
     wid /= nwx;
     const int wy = wid % nwy;
@@ -309,30 +324,32 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const half_t* __r
         region[tid] = reg;
     }
     __syncthreads();
-    // ---- stage K rows and V^T: thread -> (key, 16-byte chunk) ----
-    {
-        const int key = tid >> 2, ch = tid & 3;
-        half8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < NT) {
-            const int t = tok[key];
-            const half_t* src = t >= 0 ? qkv + (long)t * 3 * C : qkv_bias16;
-            kv = *reinterpret_cast<const half8*>(src + C + h * 32 + ch * 8);
-            vv = *reinterpret_cast<const half8*>(src + 2 * C + h * 32 + ch * 8);
-        }
-        *reinterpret_cast<half8*>(Ks + key * 32 + ch * 8) = kv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * 72 + key] = vv[e];
-    }
-    __syncthreads();
-
+    // ---- every global read of the workgroup goes out here, ahead of the LDS staging and its barrier: K / V of the thread's
+    // (key, 16-byte chunk), the lane's query fragment and its relative-position bias (4 x 16 bytes of the query's 64-float row)
     const int qi = lane & 15, g = lane >> 4;
     const int qpos = wave * 16 + qi;                                   // query position inside the window (>= 49: idle)
     const int qp = min(qpos, NT - 1);
     const int tq = tok[qp];
+    const int qreg = region[qp];
+    const int key_s = tid >> 2, ch = tid & 3;
+    half8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (key_s < NT) {
+        const int t = tok[key_s];
+        const half_t* src = t >= 0 ? qkv + (long)t * 3 * C : qkv_bias16;
+        kv = *reinterpret_cast<const half8*>(src + C + h * 32 + ch * 8);
+        vv = *reinterpret_cast<const half8*>(src + 2 * C + h * 32 + ch * 8);
+    }
     const half_t* qsrc = tq >= 0 ? qkv + (long)tq * 3 * C : qkv_bias16;
     const half8 qf = *reinterpret_cast<const half8*>(qsrc + h * 32 + g * 8);
-    const float* brow = relbias + ((long)h * NT + qp) * NT;
-    const int qreg = region[qp];
+    const float* brow = relbias + ((long)h * NT + qp) * RB_PITCH + 4 * g;
+    float4v bias4[4];                                                  // keys 4g.., 16 + 4g.., 32 + 4g.., 48 + 4g.. of the query's row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias4[i] = *reinterpret_cast<const float4v*>(brow + 16 * i);
+    // ---- stage K rows and V^T ----
+    *reinterpret_cast<half8*>(Ks + key_s * 32 + ch * 8) = kv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * 72 + key_s] = vv[e];
+    __syncthreads();
 
     float4v o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
     float m = -1e30f, l = 0.f;
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const half_t* __r
             const int key = k0 + (r < 4 ? 4 * g + r : 16 + 4 * g + (r - 4));
             float v = -1e30f;
             if (key < NT) {
-                v = (r < 4 ? s0[r] : s1[r - 4]) * scaling + brow[key];
+                v = (r < 4 ? s0[r] * scaling + bias4[k0 / 16][r] : s1[r - 4] * scaling + bias4[k0 / 16 + 1][r - 4]);
                 if (shift > 0 && region[key] != qreg) v += -100.0f;
             }
             sc[r] = v;
@@ -397,13 +414,16 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const half_t* __r
 
 }  // namespace
 
-// qkv fp16 [B*H*W, 3C] (q | k | v, head h at columns 32h..), relbias fp32 [nheads][49][49], out fp16 [B*H*W, C]
+// qkv fp16 [B*H*W, 3C] (q | k | v, head h at columns 32h..), relbias fp32 [nheads][49][SWIN_RELBIAS_PITCH] (rows padded to 64 keys), out fp16 [B*H*W, C]
 int dvid_swin_window_attn_launch(const half_t* qkv, const half_t* qkv_bias16, const float* relbias, half_t* out, int batch, int H,
                                  int W, int C, int nheads, int shift, hipStream_t s) {
     if (C != nheads * 32) return DVID_ERR_UNSUPPORTED;
     const int nwy = (H + 6) / 7, nwx = (W + 6) / 7;
-    hipLaunchKernelGGL(swin_window_attn_kernel, dim3(batch * nwy * nwx, nheads), dim3(256), 0, s, qkv, qkv_bias16, relbias, out, H, W, C,
-                       nheads, shift, 1.0f / sqrtf(32.f));
+    static const int head_major = getenv("DVID_SWIN_ATTN_ORDER") ? atoi(getenv("DVID_SWIN_ATTN_ORDER")) : 1;      // 0: A/B measurements
+    const long nblk = (long)batch * nwy * nwx * nheads;
+    if (nblk > 0x7fffffffL) return DVID_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(swin_window_attn_kernel, dim3((unsigned)nblk), dim3(256), 0, s, qkv, qkv_bias16, relbias, out, H, W, C, nheads,
+                       shift, 1.0f / sqrtf(32.f), batch * nwy * nwx, head_major);
     LAUNCH_CHECK();
     return DVID_OK;
 }

@@ -1,5 +1,7 @@
 // HBM-bound row / pixel kernels: image prep, max-pool, layout converts, fused
 // residual+LayerNorm, time/cond modulation, SiLU.  All loads/stores are 8-16 bytes per lane.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -177,6 +179,90 @@ __global__ void add_layernorm_kernel(const float* __restrict__ x, const float* _
     }
 }
 
+// The same LayerNorm for the short rows (d = 4 * LPR exactly: 128 or 256, one slab): R * (64 / LPR) rows per wave, every lane one
+// float4 of each of its R rows and all of a wave's loads in flight before its first reduction.  One row per wave keeps a single
+// 512-byte / 1-KB load per wave outstanding (32 waves per CU: ~2 TB/s at the memory latency; at d = 128 half of the lanes idle).
+// Per-row arithmetic is add_layernorm_kernel's operation by operation -- lane sums in the same order, the same xor butterfly
+// (its 32-lane step adds the idle half's zeros when d = 128) -- so the results are bit-identical.
+template <int LPR, int R>
+__global__ __launch_bounds__(256) void add_layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                                 const float* __restrict__ g, const float* __restrict__ b,
+                                                                 float* __restrict__ y32, half_t* __restrict__ y16, int rows, int relu,
+                                                                 const float* __restrict__ xbias) {
+    constexpr int SUB = 64 / LPR, RPW = R * SUB, D = 4 * LPR;
+    const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+    const int lane = threadIdx.x & 63, l = lane % LPR, sub = lane / LPR;
+    float4v v[R], rv[R];
+    long off[R];
+    bool ok[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const long row = row0 + i * SUB + sub;
+        ok[i] = row < rows;
+        off[i] = (ok[i] ? row : (long)rows - 1) * D + l * 4;          // rows past the end re-read the last row and store nothing
+        v[i] = *reinterpret_cast<const float4v*>(x + off[i]);
+    }
+    if (r) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) rv[i] = *reinterpret_cast<const float4v*>(r + off[i]);
+    }
+    const float4v gg = *reinterpret_cast<const float4v*>(g + l * 4);
+    const float4v bb = *reinterpret_cast<const float4v*>(b + l * 4);
+    if (xbias) {
+        const float4v xb = *reinterpret_cast<const float4v*>(xbias + l * 4);
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] += xb;
+    }
+    if (r) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] += rv[i];
+    }
+    float sum[R], sq[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        sum[i] = 0.f;
+        sum[i] += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < R; ++i) sum[i] += __shfl_xor(sum[i], o, 64);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const float mean = sum[i] / D;
+        sum[i] = mean;
+        sq[i] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = v[i][e] - mean;
+            sq[i] += t * t;
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < R; ++i) sq[i] += __shfl_xor(sq[i], o, 64);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const float mean = sum[i];
+        const float rstd = rsqrtf(sq[i] / D + 1e-5f);
+        float4v o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+            if (relu) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (ok[i]) {
+            if (y32) *reinterpret_cast<float4v*>(y32 + off[i]) = o;
+            if (y16) {
+                half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                *reinterpret_cast<half4*>(y16 + off[i]) = h;
+            }
+        }
+    }
+}
+
 // Swin PatchMerging front half (swintransformer.py:296-319): gather the 2x2 neighbourhood
 // [x(2i,2j) | x(2i+1,2j) | x(2i,2j+1) | x(2i+1,2j+1)] (zeros beyond an odd H/W), LayerNorm over 4C, fp16 out.
 // One wave per output token; the bias-free reduction Linear(4C -> 2C) that follows is an igemm launch.
@@ -325,6 +411,17 @@ int dvid_add_layernorm_launch(const float* x, const float* r, const float* g, co
                               int d, int relu, hipStream_t s, int nsplit, long split_stride, const float* xbias) {
     if (d % 4 || d > 1024) return DVID_ERR_ARG;
     const int wpb = 4;
+    static const int rows_env = getenv("DVID_LN_ROWS") ? atoi(getenv("DVID_LN_ROWS")) : 1;      // 0: one row per wave everywhere (A/B)
+    if (rows_env && nsplit == 1 && rows > 0 && (d == 128 || d == 256)) {
+        constexpr int R = 4;
+        const dim3 blk(64 * wpb);
+        if (d == 128)
+            hipLaunchKernelGGL((add_layernorm_rows_kernel<32, R>), dim3(ceil_div(rows, 2 * R * wpb)), blk, 0, s, x, r, g, b, y32, y16, rows, relu, xbias);
+        else
+            hipLaunchKernelGGL((add_layernorm_rows_kernel<64, R>), dim3(ceil_div(rows, R * wpb)), blk, 0, s, x, r, g, b, y32, y16, rows, relu, xbias);
+        LAUNCH_CHECK();
+        return DVID_OK;
+    }
     const dim3 grid(ceil_div(rows, wpb)), block(64 * wpb);
     if (d <= 256)
         hipLaunchKernelGGL(add_layernorm_kernel<1>, grid, block, 0, s, x, r, g, b, y32, y16, rows, d, relu, nsplit, split_stride, xbias);

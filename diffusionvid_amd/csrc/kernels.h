@@ -84,6 +84,7 @@ int dvid_mha_core_launch(const float* q, const float* k, const float* v, float* 
 int dvid_mha_mfma_launch(const half_t* q, const half_t* k, const half_t* v, half_t* out, half_t* vt_scratch, int batch, int lq,
                          int lk, int nheads, int q_ld, int kv_ld, int out_ld, long q_bs, long kv_bs, long out_bs, hipStream_t s);
 
+constexpr int SWIN_RELBIAS_PITCH = 64;      // floats per query row of the relative-position bias table [heads][49][64] (keys 49..63 = 0)
 int dvid_swin_window_attn_launch(const half_t* qkv, const half_t* qkv_bias16, const float* relbias, half_t* out, int batch, int H,
                                  int W, int C, int nheads, int shift, hipStream_t s);
 int dvid_patch_merge_ln_launch(const float* x, const float* g, const float* b, half_t* y16, int B, int H, int W, int C, hipStream_t s);

@@ -176,7 +176,7 @@ struct SwinBlockW {
     LNW norm1, norm2;
     ConvW qkv, proj, fc1, fc2;
     half_t* qkv_bias16 = nullptr;   // q/k/v of a padded window position = the qkv bias
-    float* relbias = nullptr;       // [heads][49][49] relative-position bias, gathered from the table at load
+    float* relbias = nullptr;       // [heads][49][SWIN_RELBIAS_PITCH] relative-position bias, gathered from the table at load
 };
 struct SwinStageW {
     std::vector<SwinBlockW> blocks;
@@ -799,10 +799,12 @@ int dvid_model_finalize(dvid_model* m) {
                 TRY(m->upload(qb16.data(), qb16.size() * sizeof(half_t), reinterpret_cast<void**>(&B.qkv_bias16)));
                 NEED(tb, p + ".attn.relative_position_bias_table");
                 if (tb->shape[0] != 169 || tb->shape[1] != S.heads) FAIL(DVID_ERR_ARG, "%s: bad bias table shape", p.c_str());
-                std::vector<float> rb((size_t)S.heads * 49 * 49);
+                // one 256-byte row per (head, query): a lane fetches the bias of its 16 keys as four aligned 16-byte loads
+                std::vector<float> rb((size_t)S.heads * 49 * SWIN_RELBIAS_PITCH, 0.f);
                 for (int h = 0; h < S.heads; ++h)
                     for (int i = 0; i < 49; ++i)
-                        for (int j = 0; j < 49; ++j) rb[((size_t)h * 49 + i) * 49 + j] = tb->v[(size_t)relidx[i][j] * S.heads + h];
+                        for (int j = 0; j < 49; ++j)
+                            rb[((size_t)h * 49 + i) * SWIN_RELBIAS_PITCH + j] = tb->v[(size_t)relidx[i][j] * S.heads + h];
                 TRY(upload_f32(m, rb, &B.relbias));
             }
             S.has_down = st < 3;

@@ -6,7 +6,10 @@
 // walk the 49 bins.  Output is [box][bin][channel] fp16 -- exactly the A operand of the
 // DynamicConv batched matmul -- plus the optional fp32 mean over the 49 bins that RCNNHead
 // uses as initial proposal features (box_head.py:509-510).  Coordinate math is fp32.
+#include <stdlib.h>
+
 #include "common.h"
+#include "igemm_epilogue.h"
 #include "kernels.h"
 
 namespace {
@@ -65,9 +68,12 @@ __device__ __forceinline__ Tap axis_tap(float y, int limit) {
 }
 
 __global__ __launch_bounds__(256) void roialign_kernel(RoiLevels lv, const float* __restrict__ boxes, int boxes_per_img,
-                                                        half_t* __restrict__ roi_out, float* __restrict__ mean_out) {
+                                                        half_t* __restrict__ roi_out, float* __restrict__ mean_out, int nbox,
+                                                        int xcd_major) {
     __shared__ float red[8][256];
-    const int box = blockIdx.x;
+    // an XCD takes one contiguous run of boxes, i.e. whole images: the boxes that gather from one image's pyramid meet in one L2
+    // instead of pulling that image's lines into all eight (xcd_major = 0: round-robin, for A/B runs)
+    const int box = xcd_major ? igemm_xcd_remap((int)blockIdx.x, nbox) : (int)blockIdx.x;
     const int img = box / boxes_per_img;
     const int tid = threadIdx.x;
     const int grp = tid >> 5, ln = tid & 31;
@@ -147,7 +153,8 @@ int dvid_roialign_launch(const RoiLevels& lv, int channels, const float* boxes, 
     if (channels != 256) return DVID_ERR_UNSUPPORTED;
     const int nbox = n_img * boxes_per_img;
     if (nbox == 0) return DVID_OK;
-    hipLaunchKernelGGL(roialign_kernel, dim3(nbox), dim3(256), 0, s, lv, boxes, boxes_per_img, roi_out, mean_out);
+    static const int xcd_major = getenv("DVID_ROI_XCD") ? atoi(getenv("DVID_ROI_XCD")) : 1;      // 0: A/B measurements
+    hipLaunchKernelGGL(roialign_kernel, dim3(nbox), dim3(256), 0, s, lv, boxes, boxes_per_img, roi_out, mean_out, nbox, xcd_major);
     LAUNCH_CHECK();
     return DVID_OK;
 }

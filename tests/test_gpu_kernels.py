@@ -169,6 +169,31 @@ def test_add_layernorm(dv):
     check("add_layernorm", out, ref, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("rows,d,with_r,relu", [(1003, 128, False, False), (1003, 128, True, True), (777, 256, True, False), (5, 256, False, True),
+                                                 (40, 512, True, False)])
+def test_add_layernorm_rows_per_wave_bit_identical(dv, tmp_path, rows, d, with_r, relu):
+    """The several-rows-per-wave LayerNorm (d = 128 / 256) against the oracle AND bit for bit against the one-row-per-wave kernel,
+    which a child process with DVID_LN_ROWS=0 runs on the same inputs (the switch is read once per process)."""
+    import subprocess
+    import sys
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, d, generator=g) * 3 + 1
+    r = torch.randn(rows, d, generator=g) if with_r else None
+    gm, bt = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2
+    ref = F.layer_norm(x + r if with_r else x, (d,), gm, bt)
+    ref = F.relu(ref) if relu else ref
+    out = dv.add_layernorm(x.cuda(), None if r is None else r.cuda(), gm.cuda(), bt.cuda(), relu=relu)
+    check(f"add_layernorm_rows[{rows},{d}]", out, ref, 1e-4, 1e-4)
+    torch.save({"x": x, "r": r, "g": gm, "b": bt, "relu": relu}, tmp_path / "in.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r); from diffusionvid_amd import ops; d = torch.load(%r); "
+            "y = ops.add_layernorm(d['x'].cuda(), None if d['r'] is None else d['r'].cuda(), d['g'].cuda(), d['b'].cuda(), relu=d['relu']); "
+            "torch.save(y.cpu(), %r)" % (root, str(tmp_path / "in.pt"), str(tmp_path / "out.pt")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, DVID_LN_ROWS="0"), timeout=600)
+    one_row = torch.load(tmp_path / "out.pt")
+    assert torch.equal(out.cpu(), one_row), "rows-per-wave LayerNorm differs from the one-row-per-wave kernel"
+
+
 def _head_setup(seed=0):
     from diffusionvid_amd.utils import synthetic
     sd = synthetic.make_head_state_dict(seed)
