@@ -126,6 +126,9 @@ template <int MAXV>
 __global__ void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ g,
                                      const float* __restrict__ b, float* __restrict__ y32, half_t* __restrict__ y16, int rows, int d,
                                      int relu, int nsplit, long split_stride, const float* __restrict__ xbias) {
+    // no mul + add contraction: add_layernorm_rows_kernel below must round exactly like this kernel, and which products the
+    // compiler fuses otherwise depends on the code around them
+#pragma clang fp contract(off)
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -183,12 +186,14 @@ __global__ void add_layernorm_kernel(const float* __restrict__ x, const float* _
 // float4 of each of its R rows and all of a wave's loads in flight before its first reduction.  One row per wave keeps a single
 // 512-byte / 1-KB load per wave outstanding (32 waves per CU: ~2 TB/s at the memory latency; at d = 128 half of the lanes idle).
 // Per-row arithmetic is add_layernorm_kernel's operation by operation -- lane sums in the same order, the same xor butterfly
-// (its 32-lane step adds the idle half's zeros when d = 128) -- so the results are bit-identical.
+// (its 32-lane step adds the idle half's zeros when d = 128), no contraction in either kernel, division by the power of two d exact
+// either way -- so the results are bit-identical (tests/test_gpu_kernels.py::test_add_layernorm_rows_per_wave_bit_identical).
 template <int LPR, int R>
 __global__ __launch_bounds__(256) void add_layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                                  const float* __restrict__ g, const float* __restrict__ b,
                                                                  float* __restrict__ y32, half_t* __restrict__ y16, int rows, int relu,
                                                                  const float* __restrict__ xbias) {
+#pragma clang fp contract(off)
     constexpr int SUB = 64 / LPR, RPW = R * SUB, D = 4 * LPR;
     const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW;
     if (row0 >= rows) return;
