@@ -38,6 +38,33 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Exact (erf) GELU, nn.GELU's default, as x * Phi(x) with Phi through the complementary error function:
+//   erfc(z) = t exp(-z^2 + P(t)),  t = 1 / (1 + z / 2),  z = |x| / sqrt(2) >= 0     (W. H. Press et al., Numerical Recipes, erfcc:
+//   fractional error < 1.2e-7 for every z),   Phi(-|x|) = erfc(z) / 2,   Phi(|x|) = 1 - erfc(z) / 2.
+// 20 branch-free instructions (one v_rcp_f32, one v_exp_f32) against ~45 with two divergent branches for 0.5 x (1 + erff(x / sqrt 2)):
+// Swin's fc1 layers apply it to 4C values per token and their launches were bound by exactly those instructions
+// (profiles/r02e_swinb_kernel_stats.txt).  It is also the more accurate form where x < 0: 1 + erf(..) cancels there (relative error
+// up to 0.6 for x < -5), erfc does not (2.7e-6 over [-14, 14]; 0.011 % of the results differ from the exactly rounded fp16 value,
+// 2.8 % with the erf form).  Explicit fma / no contraction: every call site rounds alike.
+__device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)
+    const float z = __builtin_fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.5f, z, 1.f));
+    float p = 0.17087277f;
+    p = __builtin_fmaf(p, t, -0.82215223f);
+    p = __builtin_fmaf(p, t, 1.48851587f);
+    p = __builtin_fmaf(p, t, -1.13520398f);
+    p = __builtin_fmaf(p, t, 0.27886807f);
+    p = __builtin_fmaf(p, t, -0.18628806f);
+    p = __builtin_fmaf(p, t, 0.09678418f);
+    p = __builtin_fmaf(p, t, 0.37409196f);
+    p = __builtin_fmaf(p, t, 1.00002368f);
+    p = __builtin_fmaf(p, t, -1.26551223f);
+    const float e = t * __expf(__builtin_fmaf(-z, z, p));      // erfc(z)
+    const float tail = 0.5f * e;                                // Phi(-|x|)
+    const float phi = x >= 0.f ? __builtin_fmaf(-0.5f, e, 1.f) : tail;
+    return x * phi;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -535,8 +535,8 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
                             if (EPI == 3) {          // exact GELU (nn.GELU default)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
-                                    lo[q] = 0.5f * lo[q] * (1.f + erff(lo[q] * 0.70710678118654752440f));
-                                    hi[q] = 0.5f * hi[q] * (1.f + erff(hi[q] * 0.70710678118654752440f));
+                                    lo[q] = gelu_erf(lo[q]);
+                                    hi[q] = gelu_erf(hi[q]);
                                 }
                             }
                             const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hi, half4);

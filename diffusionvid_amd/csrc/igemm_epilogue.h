@@ -53,7 +53,7 @@ __device__ __forceinline__ void igemm_store_row8(const IgemmParams& p, const flo
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     } else if (p.relu == 2) {      // exact GELU (nn.GELU default), Swin MLP
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
     }
     const long oidx = (long)m * p.ldc + n;
     if (p.out_f32) {

@@ -1,3 +1,6 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "add_layernorm or swin or rcnn_head or dynamic_head or xattn" 2>&1 | grep -v "^$" | tail -15
+rm -f gpurun_out/parity_report.txt
+timeout 1000 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^$" | tail -8 > gpurun_out/r02e_gpu_pytest.log
+cat gpurun_out/r02e_gpu_pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
