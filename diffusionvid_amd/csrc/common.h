@@ -8,6 +8,7 @@ typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
@@ -60,9 +61,35 @@ __device__ __forceinline__ float gelu_erf(float x) {
     p = __builtin_fmaf(p, t, 0.37409196f);
     p = __builtin_fmaf(p, t, 1.00002368f);
     p = __builtin_fmaf(p, t, -1.26551223f);
-    const float e = t * __expf(__builtin_fmaf(-z, z, p));      // erfc(z)
+    const float e = t * __builtin_amdgcn_exp2f(__builtin_fmaf(-z, z, p) * 1.4426950408889634f);      // erfc(z); exp(a) = 2^(a log2 e)
     const float tail = 0.5f * e;                                // Phi(-|x|)
     const float phi = x >= 0.f ? __builtin_fmaf(-0.5f, e, 1.f) : tail;
+    return x * phi;
+}
+// Two values at a time: the same operations in the same order as gelu_erf (so the same bits), with the multiplies and fused
+// multiply-adds as packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per issue slot) -- the epilogue that
+// applies it is bound by exactly these instructions.
+__device__ __forceinline__ float2v gelu_erf2(float2v x) {
+#pragma clang fp contract(off)
+    const float2v z = __builtin_elementwise_abs(x) * (float2v){0.70710678118654752440f, 0.70710678118654752440f};
+    const float2v d = __builtin_elementwise_fma((float2v){0.5f, 0.5f}, z, (float2v){1.f, 1.f});
+    const float2v t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    float2v p = {0.17087277f, 0.17087277f};
+    p = __builtin_elementwise_fma(p, t, (float2v){-0.82215223f, -0.82215223f});
+    p = __builtin_elementwise_fma(p, t, (float2v){1.48851587f, 1.48851587f});
+    p = __builtin_elementwise_fma(p, t, (float2v){-1.13520398f, -1.13520398f});
+    p = __builtin_elementwise_fma(p, t, (float2v){0.27886807f, 0.27886807f});
+    p = __builtin_elementwise_fma(p, t, (float2v){-0.18628806f, -0.18628806f});
+    p = __builtin_elementwise_fma(p, t, (float2v){0.09678418f, 0.09678418f});
+    p = __builtin_elementwise_fma(p, t, (float2v){0.37409196f, 0.37409196f});
+    p = __builtin_elementwise_fma(p, t, (float2v){1.00002368f, 1.00002368f});
+    p = __builtin_elementwise_fma(p, t, (float2v){-1.26551223f, -1.26551223f});
+    const float2v a = __builtin_elementwise_fma(-z, z, p);
+    const float2v b = a * (float2v){1.4426950408889634f, 1.4426950408889634f};
+    const float2v e = t * (float2v){__builtin_amdgcn_exp2f(b[0]), __builtin_amdgcn_exp2f(b[1])};
+    const float2v tail = (float2v){0.5f, 0.5f} * e;
+    const float2v head = __builtin_elementwise_fma((float2v){-0.5f, -0.5f}, e, (float2v){1.f, 1.f});
+    const float2v phi = {x[0] >= 0.f ? head[0] : tail[0], x[1] >= 0.f ? head[1] : tail[1]};
     return x * phi;
 }
 __device__ __forceinline__ float wave_max(float v) {

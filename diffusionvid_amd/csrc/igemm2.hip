@@ -533,11 +533,11 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
                                 hi += __builtin_convertvector(__builtin_shufflevector(rv, rv, 4, 5, 6, 7), float4v);
                             }
                             if (EPI == 3) {          // exact GELU (nn.GELU default)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    lo[q] = gelu_erf(lo[q]);
-                                    hi[q] = gelu_erf(hi[q]);
-                                }
+                                // pairs: packed fp32 multiplies / fmas (same bits as the scalar gelu_erf of the general epilogue)
+                                const float2v g0 = gelu_erf2((float2v){lo[0], lo[1]}), g1 = gelu_erf2((float2v){lo[2], lo[3]});
+                                const float2v g2 = gelu_erf2((float2v){hi[0], hi[1]}), g3 = gelu_erf2((float2v){hi[2], hi[3]});
+                                lo = (float4v){g0[0], g0[1], g1[0], g1[1]};
+                                hi = (float4v){g2[0], g2[1], g3[0], g3[1]};
                             }
                             const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hi, half4);
                             half8 hv = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
