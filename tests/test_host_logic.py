@@ -504,3 +504,30 @@ def test_engine_builds_lookahead_from_unchanged_dataset(tmp_path):
         got = {fb: [px(im) for im in fr] for fb, fr in images.get("ref_ahead", {}).items()}
         exp = {fb: [px(im) for im in fr] for fb, fr in want.get("ref_ahead", {}).items()}
         assert got == exp, idx
+
+
+def test_gelu_erfc_form_matches_exact_gelu():
+    """csrc/common.h gelu_erf: x * Phi(x) with Phi through erfc(z) = t exp(-z^2 + P(t)), restated here in float32 step by step (the
+    coefficients are parsed from the header, so the test follows the kernel).  It must agree with nn.GELU's exact (erf) form -- the
+    reference's Mlp activation, swintransformer.py:21-37 -- to well under an fp16 ulp of the fc1 output it produces."""
+    src = open(os.path.join(ROOT, "diffusionvid_amd", "csrc", "common.h")).read()
+    body = src[src.index("float gelu_erf(float x)"):src.index("float2v gelu_erf2(float2v x)")]
+    coef = [float(c) for c in re.findall(r"(?:float p = |fmaf\(p, t, )(-?\d+\.\d+)f", body)]
+    assert len(coef) == 10, coef
+    f = np.float32
+    x = np.concatenate([np.linspace(-12, 12, 400001), np.random.RandomState(0).randn(400000) * 2]).astype(f)
+    z = (np.abs(x) * f(0.70710678118654752440)).astype(f)
+    t = (f(1) / (f(0.5) * z + f(1))).astype(f)
+    p = np.full_like(x, f(coef[0]))
+    for c in coef[1:]:
+        p = (p * t + f(c)).astype(f)
+    e = (t * np.exp2(((p - z * z).astype(f) * f(1.4426950408889634)).astype(np.float64)).astype(f)).astype(f)
+    phi = np.where(x >= 0, (f(1) - f(0.5) * e).astype(f), (f(0.5) * e).astype(f))
+    got = (x * phi).astype(f)
+    want = torch.nn.functional.gelu(torch.from_numpy(x).double()).numpy()
+    err = np.abs(got - want)
+    assert err.max() < 1e-6, err.max()
+    big = np.abs(want) > 1e-6
+    assert (err[big] / np.abs(want[big])).max() < 2e-5
+    # after the fp16 store of the fc1 output: essentially always the exactly rounded value
+    assert (got.astype(np.float16) != want.astype(np.float16)).mean() < 1e-3
