@@ -275,6 +275,7 @@ int dvid_mha_mfma_launch(const half_t* q, const half_t* k, const half_t* v, half
 // =============================================================================================
 namespace {
 
+template <int WPB>
 __global__ __launch_bounds__(256) void swin_window_attn_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ qkv_bias16,
                                                                 const float* __restrict__ relbias, half_t* __restrict__ out, int H,
                                                                 int W, int C, int nheads, int shift, float scaling, int nwin,
@@ -289,17 +290,33 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const half_t* __r
     // write neighbouring pieces of the same output rows: with the head innermost AND the workgroups of an XCD taking one contiguous
     // run of (window, head) pairs, those pieces meet in that XCD's L2 while the line is there; window-major order per head (the
     // former 2-D grid) fetched every line once per head that touches it.  head_major = 0 keeps the old order for A/B runs.
-    int h, wid;
+    // A workgroup takes WPB consecutive windows of ONE head: a lane's relative-position bias depends on its query position and the
+    // head only, so it is fetched once per workgroup instead of once per window (16 of the 36 load / store instructions a
+    // (window, head) pair costs the CU's L1 path otherwise).
+    const int ngrp = (nwin + WPB - 1) / WPB;
+    int h, grp;
     if (head_major) {
-        const int lid = igemm_xcd_remap((int)blockIdx.x, nwin * nheads);
-        wid = lid / nheads;
-        h = lid - wid * nheads;
+        const int lid = igemm_xcd_remap((int)blockIdx.x, ngrp * nheads);
+        grp = lid / nheads;
+        h = lid - grp * nheads;
     } else {
-        h = (int)blockIdx.x / nwin;
-        wid = (int)blockIdx.x - h * nwin;
+        h = (int)blockIdx.x / ngrp;
+        grp = (int)blockIdx.x - h * ngrp;
     }
     const int Hp = (H + WS - 1) / WS * WS, Wp = (W + WS - 1) / WS * WS;
     const int nwx = Wp / WS, nwy = Hp / WS;
+    const int qi = lane & 15, g = lane >> 4;
+    const int qpos = wave * 16 + qi;                                   // query position inside the window (>= 49: idle)
+    const int qp = min(qpos, NT - 1);
+    const float* brow = relbias + ((long)h * NT + qp) * RB_PITCH + 4 * g;
+    float4v bias4[4];                                                  // keys 4g.., 16 + 4g.., 32 + 4g.., 48 + 4g.. of the query's row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias4[i] = *reinterpret_cast<const float4v*>(brow + 16 * i);
+
+    for (int w = 0; w < WPB; ++w) {
+    int wid = grp * WPB + w;
+    if (wid >= nwin) break;                                            // (uniform over the workgroup)
+    if (w) __syncthreads();                                            // the previous window's LDS reads are done
     const int wx = wid % nwx;
     wid /= nwx;
     const int wy = wid % nwy;
@@ -324,11 +341,8 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const half_t* __r
         region[tid] = reg;
     }
     __syncthreads();
-    // ---- every global read of the workgroup goes out here, ahead of the LDS staging and its barrier: K / V of the thread's
-    // (key, 16-byte chunk), the lane's query fragment and its relative-position bias (4 x 16 bytes of the query's 64-float row)
-    const int qi = lane & 15, g = lane >> 4;
-    const int qpos = wave * 16 + qi;                                   // query position inside the window (>= 49: idle)
-    const int qp = min(qpos, NT - 1);
+    // ---- every global read of the window goes out here, ahead of the LDS staging and its barrier: K / V of the thread's
+    // (key, 16-byte chunk) and the lane's query fragment (its bias, 4 x 16 bytes of the query's 64-float row, is loaded above)
     const int tq = tok[qp];
     const int qreg = region[qp];
     const int key_s = tid >> 2, ch = tid & 3;
@@ -341,10 +355,6 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const half_t* __r
     }
     const half_t* qsrc = tq >= 0 ? qkv + (long)tq * 3 * C : qkv_bias16;
     const half8 qf = *reinterpret_cast<const half8*>(qsrc + h * 32 + g * 8);
-    const float* brow = relbias + ((long)h * NT + qp) * RB_PITCH + 4 * g;
-    float4v bias4[4];                                                  // keys 4g.., 16 + 4g.., 32 + 4g.., 48 + 4g.. of the query's row
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bias4[i] = *reinterpret_cast<const float4v*>(brow + 16 * i);
     // ---- stage K rows and V^T ----
     *reinterpret_cast<half8*>(Ks + key_s * 32 + ch * 8) = kv;
 #pragma unroll
@@ -403,13 +413,15 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const half_t* __r
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    if (qpos >= NT || tq < 0) return;                                  // padded positions produce no output
-    const float inv = 1.f / l;
-    half_t* op = out + (long)tq * C + h * 32 + 4 * g;
-    const half4 w0 = {(half_t)(o0[0] * inv), (half_t)(o0[1] * inv), (half_t)(o0[2] * inv), (half_t)(o0[3] * inv)};
-    const half4 w1 = {(half_t)(o1[0] * inv), (half_t)(o1[1] * inv), (half_t)(o1[2] * inv), (half_t)(o1[3] * inv)};
-    *reinterpret_cast<half4*>(op) = w0;
-    *reinterpret_cast<half4*>(op + 16) = w1;
+    if (qpos < NT && tq >= 0) {                                        // padded positions produce no output
+        const float inv = 1.f / l;
+        half_t* op = out + (long)tq * C + h * 32 + 4 * g;
+        const half4 w0 = {(half_t)(o0[0] * inv), (half_t)(o0[1] * inv), (half_t)(o0[2] * inv), (half_t)(o0[3] * inv)};
+        const half4 w1 = {(half_t)(o1[0] * inv), (half_t)(o1[1] * inv), (half_t)(o1[2] * inv), (half_t)(o1[3] * inv)};
+        *reinterpret_cast<half4*>(op) = w0;
+        *reinterpret_cast<half4*>(op + 16) = w1;
+    }
+    }      // windows of the workgroup
 }
 
 }  // namespace
@@ -420,10 +432,15 @@ int dvid_swin_window_attn_launch(const half_t* qkv, const half_t* qkv_bias16, co
     if (C != nheads * 32) return DVID_ERR_UNSUPPORTED;
     const int nwy = (H + 6) / 7, nwx = (W + 6) / 7;
     static const int head_major = getenv("DVID_SWIN_ATTN_ORDER") ? atoi(getenv("DVID_SWIN_ATTN_ORDER")) : 1;      // 0: A/B measurements
-    const long nblk = (long)batch * nwy * nwx * nheads;
-    if (nblk > 0x7fffffffL) return DVID_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(swin_window_attn_kernel, dim3((unsigned)nblk), dim3(256), 0, s, qkv, qkv_bias16, relbias, out, H, W, C, nheads,
-                       shift, 1.0f / sqrtf(32.f), batch * nwy * nwx, head_major);
+    static const int wpb = getenv("DVID_SWIN_ATTN_WPB") ? atoi(getenv("DVID_SWIN_ATTN_WPB")) : 4;                  // 1: one window per workgroup (A/B)
+    const long nwin = (long)batch * nwy * nwx;
+    if (nwin * nheads > 0x7fffffffL) return DVID_ERR_UNSUPPORTED;
+    if (wpb == 1)
+        hipLaunchKernelGGL(swin_window_attn_kernel<1>, dim3((unsigned)(nwin * nheads)), dim3(256), 0, s, qkv, qkv_bias16, relbias, out, H, W, C,
+                           nheads, shift, 1.0f / sqrtf(32.f), (int)nwin, head_major);
+    else
+        hipLaunchKernelGGL(swin_window_attn_kernel<4>, dim3((unsigned)((nwin + 3) / 4 * nheads)), dim3(256), 0, s, qkv, qkv_bias16, relbias, out,
+                           H, W, C, nheads, shift, 1.0f / sqrtf(32.f), (int)nwin, head_major);
     LAUNCH_CHECK();
     return DVID_OK;
 }

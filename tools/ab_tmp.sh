@@ -1,6 +1,4 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 170 python bench.py --arch swinb --steps 2 --no-side-configs --no-cpu-baseline --no-host-fed > gpurun_out/r02f_bench_swinb.json 2> gpurun_out/r02f_bench_swinb.err
-tail -c 200 gpurun_out/r02f_bench_swinb.json
-timeout 150 python bench.py --sample-step 4 --steps 2 --no-side-configs --no-cpu-baseline --no-host-fed > gpurun_out/r02f_bench_x4.json 2> gpurun_out/r02f_bench_x4.err
-tail -c 200 gpurun_out/r02f_bench_x4.json
+timeout 150 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_e2e.py -m gpu -q -x -k "swin" 2>&1 | grep -v "^$" | tail -3
+for v in 1 4; do DVID_SWIN_ATTN_WPB=$v timeout 60 python tools/bench_launch_order.py swin 32 2>&1 | grep Swin | sed "s/^/WPB=$v /"; done
