@@ -34,9 +34,7 @@ SIGNATURES = {
     "dvid_model_set_tensor": (c_int, [c_void_p, C.c_char_p, c_void_p, C.POINTER(c_int64), c_int]),
     "dvid_model_finalize": (c_int, [c_void_p]),
     "dvid_set_chains": (c_int, [c_void_p, c_int]),
-    "dvid_set_fusion": (c_int, [c_void_p, c_int]),
     "dvid_set_stem_layout": (c_int, [c_void_p, c_int]),
-    "dvid_set_pipeline": (c_int, [c_void_p, c_int, c_int, c_int]),
     "dvid_workspace_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "dvid_backbone_resnet_fpn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvid_backbone_swin_fpn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -56,7 +54,6 @@ SIGNATURES = {
     "dvid_fps_greedy": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dvid_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dvid_conv2d_nhwc_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
-    "dvid_mha_core": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64] * 3 + [c_void_p]),
     "dvid_mha_f16": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_int64] * 3 + [c_void_p]),
     "dvid_dynconv": (c_int, [c_void_p] * 7 + [c_int, c_void_p]),
     "dvid_add_layernorm": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p]),
@@ -74,7 +71,6 @@ SIGNATURES = {
     "dvid_profile_reset": (c_int, []),
     "dvid_profile_dump": (c_int, [C.c_char_p]),
     "dvid_profile_read": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int64)]),
-    "dvid_profile_read_fused": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int64)]),
     "dvid_profile_read_bytes": (c_int, [C.POINTER(C.c_double)]),
 }
 

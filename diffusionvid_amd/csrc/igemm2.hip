@@ -36,7 +36,7 @@ struct Smem2 {
     static constexpr int kStage = (BM + BN) * BKT * 2;
     static constexpr int kCPitch = BN + 4;
     static constexpr int kCHalf = (BM / 2) * kCPitch * 4;
-    static constexpr int kRing = (NSTAGE == 5 || NSTAGE == 7) ? 4 : (NSTAGE == 6 ? 2 : NSTAGE);        // NSTAGE 5 = the anti-phase schedule over a 4-stage ring; 6 = register-staged, 2 stages
+    static constexpr int kRing = NSTAGE == 5 ? 4 : NSTAGE;        // NSTAGE 5 = the anti-phase schedule over a 4-stage ring
     static constexpr int kBytes = (kRing * kStage > kCHalf) ? kRing * kStage : kCHalf;
 };
 
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
     constexpr int KEY_SHIFT = (BKT == 64) ? 1 : 2;  // swizzle key = (row >> KEY_SHIFT) & (CHUNKS - 1)
     constexpr int TM = BM / 64, TN = BN / (32 * WN);   // 32x32 MFMA tiles per wave (waves 2 x WN)
     constexpr int A_IT = BM / RPP / NW, B_IT = BN / RPP / NW;   // DMA pieces per wave per K tile
-    static_assert(NSTAGE >= 2 && NSTAGE <= 7, "ring depth / schedule code");
-    static_assert((NSTAGE != 5 && NSTAGE != 7) || (WN == 4 && AK != 1), "the anti-phase schedule is written for 8 waves");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 5, "ring depth / schedule code");
+    static_assert(NSTAGE != 5 || (WN == 4 && AK != 1), "the anti-phase schedule is written for 8 waves");
     static_assert(A_IT >= 1 && B_IT >= 1 && A_IT * RPP * NW == BM && B_IT * RPP * NW == BN, "tile / wave-count mismatch");
     constexpr int A_BYTES = BM * ROW_BYTES;
     constexpr int STAGE = Smem2<BM, BN, BKT, NSTAGE>::kStage;
@@ -309,63 +309,7 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         }
     };
 
-    if constexpr (NSTAGE == 7) {
-        // The anti-phase schedule of NSTAGE 5 with register-staged operands: the global loads of tile t + 3 are issued between
-        // the MFMAs of M(t) (a few issue cycles each instead of ~100 per DMA piece) and their ds_write_b128 into stage
-        // (t + 3) & 3 happens in the next read slot R(t + 1), the slot that already belongs to LDS traffic; that stage held
-        // tile t - 1, whose last reads were retired two barriers earlier.  One 16-VGPR register set in flight.
-        constexpr int P = A_IT + B_IT, NM = TM * TN * KS;
-        static_assert(NSTAGE != 7 || NM % P == 0, "loads are spread evenly over the MFMAs of a tile");
-        half8 rg[P];
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-            if (d < nk) {
-#pragma unroll
-                for (int i = 0; i < P; ++i) rg[i] = *reinterpret_cast<const half8*>(piece_src(i));
-                advance();
-#pragma unroll
-                for (int i = 0; i < P; ++i) *reinterpret_cast<half8*>(piece_dst(d, i) + lane * 16) = rg[i];
-            }
-        __syncthreads();
-        if (wm == 1) __builtin_amdgcn_s_barrier();                 // wave row 1 runs one slot behind row 0
-        bool pending = false;                                      // rg holds tile t + 2 (fetched in the previous M slot)
-        for (int t = 0; t < nk; ++t) {
-            // ---- R(t)
-            const char* st = smem + (t & 3) * STAGE;
-            half8 fa[TM][KS], fb[TN][KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i][ks] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * ROW_BYTES + choff[ks]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j][ks] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * ROW_BYTES + choff[ks]);
-            }
-            if (pending) {
-#pragma unroll
-                for (int i = 0; i < P; ++i) *reinterpret_cast<half8*>(piece_dst((t + 2) & 3, i) + lane * 16) = rg[i];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- M(t)
-            const bool ld = t + 3 < nk;
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int q = 0; q < NM; ++q) {
-                const int ks = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
-                if (ld && q % (NM / P) == 1) rg[q / (NM / P)] = *reinterpret_cast<const half8*>(piece_src(q / (NM / P)));
-            }
-            if (ld) advance();
-            pending = ld;
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (wm == 0) __builtin_amdgcn_s_barrier();                 // balances the extra barrier of row 1
-        __syncthreads();
-    } else if constexpr (NSTAGE == 5) {
+    if constexpr (NSTAGE == 5) {
         constexpr int P = A_IT + B_IT, NM = TM * TN * KS;
         static_assert(NSTAGE != 5 || NM % P == 0, "DMA pieces are spread evenly over the MFMAs of a tile");
 #pragma unroll
@@ -407,39 +351,6 @@ __global__ __launch_bounds__(128 * WN) void igemm2_kernel(IgemmParams p) {
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();                 // balances the extra barrier of row 1
         __syncthreads();
-    } else if constexpr (NSTAGE == 6) {
-        // Register-staged operands: global_load_dwordx4 -> VGPR -> ds_write_b128 into the same lane-linear, swizzled LDS image
-        // the DMA path builds.  A DMA piece costs its wave 100-185 issue cycles next to MFMAs and fragment reads
-        // (MI355X_MICROARCH.md; profiles/r01_lab_gemm_pingpong.txt), a load + a 16-byte LDS store about 20; the price is 4
-        // VGPRs per piece in flight.  Two register sets: tile kt + 2 is fetched while tile kt is computed, tile kt + 1
-        // (fetched an iteration earlier) is stored to the other stage first -- that stage was last read before the barrier
-        // that ended the previous iteration.  One barrier per K step.
-        constexpr int P = A_IT + B_IT;
-        half8 rg0[P], rg1[P];
-        auto fetch = [&](half8 (&r)[P]) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) r[i] = *reinterpret_cast<const half8*>(piece_src(i));
-            advance();
-        };
-        auto put = [&](const half8 (&r)[P], int stage) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) *reinterpret_cast<half8*>(piece_dst(stage, i) + lane * 16) = r[i];
-        };
-        fetch(rg0);
-        if (nk > 1) fetch(rg1);
-        put(rg0, 0);
-        __syncthreads();
-        auto step = [&](int kt, half8 (&r_next)[P], half8 (&r_free)[P]) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) put(r_next, cur ^ 1);
-            if (kt + 2 < nk) fetch(r_free);
-            compute(cur);
-            __syncthreads();
-        };
-        for (int kt = 0; kt < nk; kt += 2) {
-            step(kt, rg1, rg0);
-            if (kt + 1 < nk) step(kt + 1, rg0, rg1);
-        }
     } else if constexpr (NSTAGE == 2) {
         issue(kt0, 0);
         __syncthreads();
@@ -639,11 +550,9 @@ const TileCfg kCfgs[] = {
     {128, 256, 32, 3, &launch2<128, 256, 32, 3, false, 2>}, {128, 256, 64, 2, &launch2<128, 256, 64, 2, false, 2>},
     // nstage 5: the anti-phase schedule over a 4-stage ring (see igemm2_kernel)
     {256, 256, 32, 5, &launch2<256, 256, 32, 5, false, 4>},
-    // Schedules 6 (register-staged operands over 2 LDS stages) and 7 (the same inside the anti-phase schedule) are compiled on
-    // demand only: measured on the 104-frame shapes (profiles/r02_igemm_register_staging.txt) 256x256x32/6 beats its DMA twin
-    // /2 by 15 % (188 vs 222 us on 252928 x 256 x 1024) but loses to the ring (/3, 180) and the anti-phase DMA schedule (/5,
-    // 166); /7 loses to /5 on every shape (181 vs 166; 354 vs 310 on the 3x3) -- they never win, so they are not in the table.
-    // Nor are 4-wave 256x256 tiles (128x128 per wave, 256 accumulator AGPRs, one wave per SIMD -- the vendor library's shape,
+    // Register-staged operands (global -> VGPR -> ds_write_b128, plain and inside the anti-phase schedule; in this file's history,
+    // profiles/r02_igemm_register_staging.txt) lose to the DMA ring and the anti-phase DMA schedule on every 104-frame shape (188 /
+    // 181 vs 180 / 166 us on 252928 x 256 x 1024).  So do 4-wave 256x256 tiles (128x128 per wave, 256 accumulator AGPRs, one wave per SIMD -- the vendor library's shape,
     // MT256x256x32/64 MIWT8_8): 191-206 us against 168 on 252928 x 256 x 1024, 343 against 311 on the 3x3.
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -700,6 +609,7 @@ std::unordered_map<ShapeKey, int, ShapeHash> g_tuned;
 // DVID_IGEMM_TUNE_CACHE=<file>: winners are appended as they are found and read back at the first launch of the next
 // process, so a deployment (or a profiling run) starts without the timing launches.  One line per shape:
 // M Cout Kpad Cin ntaps stride res_mode flags cfg table_size
+bool g_cache_serving = false;    // a non-empty DVID_IGEMM_TUNE_CACHE was loaded and DVID_IGEMM_TUNE is unset: no timing launches
 void tune_cache_load() {
     const char* path = getenv("DVID_IGEMM_TUNE_CACHE");
     if (!path) return;
@@ -707,9 +617,17 @@ void tune_cache_load() {
     if (!f) return;
     ShapeKey k;
     int cfg, n;
+    size_t loaded = 0;
     while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d", &k.M, &k.Cout, &k.Kpad, &k.Cin, &k.ntaps, &k.stride, &k.res_mode, &k.flags, &cfg, &n) == 10)
-        if (cfg >= 0 && ((k.flags & 4) ? (n == 2 && cfg < 2) : (n == kNumCfg && cfg < kNumCfg))) g_tuned[k] = cfg;
+        if (cfg >= 0 && ((k.flags & 4) ? (n == 2 && cfg < 2) : (n == kNumCfg && cfg < kNumCfg))) {
+            g_tuned[k] = cfg;
+            ++loaded;
+        }
     fclose(f);
+    // A deployment that ships a winners file gets the serving behaviour by default: cached / nearest-bucket winners, the hand
+    // rule for anything unseen, never a stream synchronisation or an allocation on the launch path.  DVID_IGEMM_TUNE=1 (or
+    // dvid_igemm_set_tuning(1)) keeps timing new shape buckets and appending them to the file.
+    g_cache_serving = loaded > 0 && getenv("DVID_IGEMM_TUNE") == nullptr;
 }
 void tune_cache_append(const ShapeKey& k, int cfg, int n) {
     const char* path = getenv("DVID_IGEMM_TUNE_CACHE");
@@ -896,7 +814,7 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
         } else if (int near = nearest_bucket_cfg(key); near >= 0 && cfg_valid(cfgs[near], p)) {
             cfg = near;                          // same layer, row count within a factor of two of a tuned bucket: inherit
             g_tuned.emplace(key, cfg);
-        } else if (g_tune_mode == 0) {
+        } else if (g_tune_mode == 0 || (g_tune_mode < 0 && g_cache_serving)) {
             cfg = fallback;                     // serving mode: no timing launches; the hand rule for unseen buckets
         } else {
             const int rc = tune_shape(p, s, cfgs, ncfg, fallback, &cfg);

@@ -29,22 +29,6 @@ bool dvid_wstat_supported(const IgemmParams& p);
 bool dvid_wstat_preferred(const IgemmParams& p);
 int dvid_wstat_launch(const IgemmParams& p, hipStream_t s);
 
-// c3c1.hip: conv3 (+ residual + ReLU) of one bottleneck fused with conv1 (+ ReLU) of the next; w3f / w1f are the two weight
-// matrices in MFMA B-fragment order (pack_frag_order in model.hip)
-struct C3C1Params {
-    const half_t* a;      // [M][K1]   conv2 output of the block
-    const half_t* w3f;    // conv3 weights [N1][K1], fragment order
-    const float* b3;      // [N1]
-    const half_t* r;      // [M][N1]   residual (block input or shortcut output)
-    half_t* y;            // [M][N1]   block output
-    const half_t* w1f;    // next conv1 weights [N2][N1], fragment order
-    const float* b1;      // [N2]
-    half_t* z;            // [M][N2]   next block's conv1 output
-    long M;
-};
-bool dvid_c3c1_supported(int k1, int n1, int n2);
-int dvid_c3c1_launch(const C3C1Params& p, int k1, int n1, int n2, hipStream_t s);
-
 // elementwise.hip
 int dvid_prep_images_launch(const float* nchw, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
                             hipStream_t s);
@@ -75,12 +59,7 @@ struct RoiLevels {
 int dvid_roialign_launch(const RoiLevels& lv, int channels, const float* boxes, int n_img, int boxes_per_img, half_t* roi_out,
                          float* mean_out, hipStream_t s);
 
-// attention.hip : out[b][q][:] = softmax(Q K^T * scale) V per head; fp32 in/out, row strides given
-int dvid_mha_core_launch(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads,
-                         int head_dim, int q_ld, int kv_ld, int out_ld, long q_bs, long kv_bs, long out_bs, half_t* out16,
-                         hipStream_t s);
-
-// MFMA variant: fp16 q/k/v (head h at columns h*32..), fp16 out; vt_scratch >= batch*nheads*32*(round_up(lk,32)+32) halves
+// attention.hip: out[b][q][:] = softmax(Q K^T * scale) V per head on MFMA: fp16 q/k/v (head h at columns h*32..), fp16 out; vt_scratch >= batch*nheads*32*(round_up(lk,32)+32) halves
 int dvid_mha_mfma_launch(const half_t* q, const half_t* k, const half_t* v, half_t* out, half_t* vt_scratch, int batch, int lq,
                          int lk, int nheads, int q_ld, int kv_ld, int out_ld, long q_bs, long kv_bs, long out_bs, hipStream_t s);
 

@@ -44,7 +44,6 @@ struct ProfRec {
     hipEvent_t a, b;
     double flop, bytes;
     int M, N, K, taps, stride, res_mode;
-    int kind = 0;              // 0: igemm2 launch, 1: fused conv3 -> conv1 launch (c3c1.hip)
 };
 bool g_prof_on = false;
 std::mutex g_prof_mu;                 // models on different host threads may launch concurrently
@@ -71,7 +70,6 @@ int igemm(const IgemmParams& p, hipStream_t s) {
     if (!g_prof_on) return dvid_igemm_launch(p, s);
     ProfRec r;
     if (prof_take(&r) != DVID_OK) return DVID_ERR_HIP;
-    r.kind = 0;
     r.flop = 2.0 * p.M * (double)p.Cout * (double)p.alg_k;
     // algorithmic HBM bytes: every operand touched once (input pixels, packed weights, output, residual)
     const double in_px = (double)p.M * (p.ntaps > 1 ? p.stride * p.stride : 1);
@@ -86,27 +84,6 @@ int igemm(const IgemmParams& p, hipStream_t s) {
     r.res_mode = p.res_mode;
     HIP_TRY(hipEventRecord(r.a, s));
     const int rc = dvid_igemm_launch(p, s);
-    HIP_TRY(hipEventRecord(r.b, s));
-    prof_push(r);
-    return rc;
-}
-
-int c3c1(const C3C1Params& q, int k1, int n1, int n2, hipStream_t s) {
-    if (!g_prof_on) return dvid_c3c1_launch(q, k1, n1, n2, s);
-    ProfRec r;
-    if (prof_take(&r) != DVID_OK) return DVID_ERR_HIP;
-    r.kind = 1;
-    r.flop = 2.0 * q.M * ((double)k1 * n1 + (double)n1 * n2);
-    // algorithmic HBM bytes: A + residual + Y + Z + both weight matrices, each once (Y is not re-read: that is the point)
-    r.bytes = (double)q.M * (k1 + 2.0 * n1 + n2) * 2.0 + ((double)k1 * n1 + (double)n1 * n2) * 2.0;
-    r.M = (int)q.M;
-    r.N = n1;
-    r.K = k1;
-    r.taps = 1;
-    r.stride = n2;
-    r.res_mode = 1;
-    HIP_TRY(hipEventRecord(r.a, s));
-    const int rc = dvid_c3c1_launch(q, k1, n1, n2, s);
     HIP_TRY(hipEventRecord(r.b, s));
     prof_push(r);
     return rc;
@@ -151,7 +128,6 @@ struct ConvW {   // conv or linear weights in MFMA-operand layout
     int cin_real = 0;  // un-padded input channels (algorithmic FLOP count)
     bool same_size = false;    // output spatial size = input size whatever (kh, pad) say (the space-to-depth stem: pad 2 before, 1 after)
     int alg_k = 0;             // algorithmic K for the FLOP count when the packed layout carries structural zeros (0: kh*kw*cin_real)
-    half_t* wfrag = nullptr;   // 1x1 layers of the bottlenecks: the same matrix in MFMA B-fragment order (csrc/c3c1.hip)
 };
 struct LNW {
     float* g = nullptr;
@@ -218,23 +194,12 @@ struct dvid_model {
     DevBuf img8, bufX, bufY, bufT1, bufT2, bufSC, c3, c4, c5, lat[3];
     DevBuf sw_x, sw_x2, sw_ln16, sw_qkv16, sw_attn16, sw_h16;   // Swin token buffers
     DevBuf roi, params, dyn, qkv, attn16, f32a, f32b, f32c, f32d, h16a, h16b, hid16, ss, deltas, kvproj, mem16, splitk, vt;
-    std::map<std::pair<int, std::vector<int64_t>>, DevBuf> ss_tables;   // (head slot, t vector) -> device scale/shift table
-    std::map<std::pair<int, int64_t>, std::vector<float>> ss_rows;     // (head slot, t) -> host row [bt_out]
+    std::map<std::pair<int, int64_t>, DevBuf> ss_rows;     // (head slot, t) -> device scale/shift row [bt_out]
 
-    // conv3 (+ residual) of a bottleneck fused with the next bottleneck's conv1 (csrc/c3c1.hip).  Bit-identical, and OFF by
-    // default: measured at 104 frames it is a wash (38.9 vs 38.1 ms per backbone pass, profiles/r02_c3c1_fusion.txt) -- the
-    // fused launch saves the re-read of the block output but fetches the weights once per 128 rows instead of once per
-    // 256, and its phases are barrier-locked inside one workgroup per CU.  DVID_FUSE_C3C1=1 / dvid_set_fusion turn it on.
-    bool fuse_c3c1 = false;
     int mem_lk = 0;       // rows of the global memory whose K/V projections sit in kvproj (0: none)
 
     // sub-batch chains (see dvid_backbone_resnet_fpn)
     int nchain = 2;
-    // software pipeline of the ResNet backbone (see dvid_backbone_resnet_fpn): sub-batches, and the (stage, block) at which
-    // a sub-batch moves from the front stream to the back stream; pipe_parts <= 1: off
-    int pipe_parts = 0, pipe_stage = 2, pipe_block = 0;
-    std::vector<hipEvent_t> ev_mid, ev_dyn;
-    int dyn_chunks = 1;       // DVID_DYN_CHUNKS: dynamic_layer GEMM / DynamicConv software pipeline over row chunks (1: off)
     hipStream_t cs[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool streams_ready = false;
@@ -323,21 +288,6 @@ int make_conv_bn(dvid_model* m, const std::string& name, int stride, int pad, in
         bb[o] = b->v[o] - mu->v[o] * s[o];
     }
     return make_conv(m, *w, s, bb, stride, pad, cin_pad, nullptr, out);
-}
-
-// [cout][kpad] (K contiguous) -> MFMA B-fragment order for v_mfma_f32_32x32x16_f16: block (n-tile of 32 rows, k-step of 16) is
-// 64 lanes x 8 halves, lane l = row (l & 31), k = 8 * (l >> 5) .. + 8 -- one contiguous 1-KiB wave load per fragment.
-int pack_frag_order(dvid_model* m, ConvW* w) {
-    if (w->kh != 1 || w->kw != 1 || w->cout % 32 || w->kpad % 16 || w->kpad != w->cin) return DVID_OK;
-    std::vector<half_t> src((size_t)w->cout * w->kpad), dst(src.size());
-    HIP_TRY(hipMemcpy(src.data(), w->w, src.size() * sizeof(half_t), hipMemcpyDeviceToHost));
-    const int ks_n = w->kpad / 16;
-    for (int nt = 0; nt < w->cout / 32; ++nt)
-        for (int ks = 0; ks < ks_n; ++ks)
-            for (int l = 0; l < 64; ++l)
-                for (int e = 0; e < 8; ++e)
-                    dst[(((size_t)nt * ks_n + ks) * 64 + l) * 8 + e] = src[(size_t)(nt * 32 + (l & 31)) * w->kpad + ks * 16 + (l >> 5) * 8 + e];
-    return m->upload(dst.data(), dst.size() * sizeof(half_t), reinterpret_cast<void**>(&w->wfrag));
 }
 
 // The 7x7 / stride-2 / pad-3 stem over 3 channels as a 4x4 / stride-1 convolution over the 2x2 space-to-depth image (16 channels:
@@ -522,8 +472,8 @@ int run_fpn(dvid_model* m, int n, const int* sh, const int* sw, void* p3, void* 
 // chain's slice of the [rows, *] buffers, `vt_off` = its offset (halves) in the V^T scratch.
 int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3, const void* p4, const void* p5, int f0, int nf,
                     int height, int width, int M, const float* boxes_all, const float* pro_all, const float* cond_all,
-                    float* logits_all, float* boxes_out_all, float* obj_all, int* bad_box_flag, const float* ss_all, size_t wrow,
-                    size_t vt_off, hipStream_t s) {
+                    float* logits_all, float* boxes_out_all, float* obj_all, int* bad_box_flag, const float* ss_all, int ss_stride,
+                    size_t wrow, size_t vt_off, hipStream_t s) {
     const int d = m->cfg.hidden_dim, R = nf * M;
     const size_t r0 = (size_t)f0 * M;
     const float* boxes = boxes_all + r0 * 4;
@@ -532,8 +482,7 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
     float* logits = logits_all + r0 * m->cfg.num_classes;
     float* boxes_out = boxes_out_all + r0 * 4;
     float* obj_features = obj_all + r0 * d;
-    const int ss_ld = is_cond ? d : 2 * d;
-    const float* ss_dev = ss_all + (size_t)f0 * ss_ld;
+    const float* ss_dev = ss_all + (size_t)f0 * ss_stride;          // ss_stride 0: every frame reads the one (head, t) row
     // workspace slices
     half_t* roi16 = m->roi.as<half_t>() + wrow * 49 * d;
     half_t* dyn16 = m->dyn.as<half_t>() + wrow * 49 * d;
@@ -572,36 +521,9 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
     float* x1 = f32c;
     TRY(dvid_add_layernorm_launch(pro, f32b, hw.norm1.g, hw.norm1.b, x1, h16a, R, d, 0, s));
     // --- DynamicConv ---
-    // dynamic_layer writes 64 KB of parameters per box that DynamicConv reads straight back (csrc/dynconv.hip).  With
-    // dyn_chunks > 1 the rows are cut into chunks: the GEMM of chunk i + 1 (MFMA / epilogue-bound) runs on this stream while
-    // DynamicConv of chunk i (HBM-bound) runs on a helper stream.  Measured (bench.py, one box, A/B): 1 chunk 1740 / 1734
-    // frames/s, 2 chunks 1729, 4 chunks 1717 / 1721, 8 chunks 1703 -- the two kernels do not overlap usefully; off by default.
-    const int nchunk = (m->dyn_chunks > 1 && nf >= 2 * m->dyn_chunks) ? m->dyn_chunks : 1;
-    if (nchunk == 1) {
-        TRY(linear_run(hw.dynamic_layer, h16a, R, params16, 0, 0, s));
-        TRY(dvid_dynconv_launch(roi16, params16, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn16, R, s));
-    } else {
-        TRY(m->ensure_streams());
-        hipStream_t hs = m->cs[3];
-        while ((int)m->ev_dyn.size() < nchunk + 1) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            m->ev_dyn.push_back(e);
-        }
-        const int fper = (nf + nchunk - 1) / nchunk;
-        for (int c = 0; c < nchunk; ++c) {
-            const int fa = c * fper, fb = (fa + fper < nf) ? fa + fper : nf;
-            if (fb <= fa) break;
-            const size_t r0c = (size_t)fa * M, rows = (size_t)(fb - fa) * M;
-            TRY(linear_run(hw.dynamic_layer, h16a + r0c * d, (int)rows, params16 + r0c * 2 * d * m->cfg.dim_dynamic, 0, 0, s));
-            HIP_TRY(hipEventRecord(m->ev_dyn[c], s));
-            HIP_TRY(hipStreamWaitEvent(hs, m->ev_dyn[c], 0));
-            TRY(dvid_dynconv_launch(roi16 + r0c * 49 * d, params16 + r0c * 2 * d * m->cfg.dim_dynamic, hw.dc_norm1.g, hw.dc_norm1.b,
-                                    hw.dc_norm2.g, hw.dc_norm2.b, dyn16 + r0c * 49 * d, (int)rows, hs));
-        }
-        HIP_TRY(hipEventRecord(m->ev_dyn[nchunk], hs));
-        HIP_TRY(hipStreamWaitEvent(s, m->ev_dyn[nchunk], 0));
-    }
+    // dynamic_layer writes 64 KB of parameters per box that DynamicConv reads straight back (csrc/dynconv.hip)
+    TRY(linear_run(hw.dynamic_layer, h16a, R, params16, 0, 0, s));
+    TRY(dvid_dynconv_launch(roi16, params16, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn16, R, s));
     // out_layer: K = 49*d = 12544 on only R x d outputs -> split K over 7 workgroups per tile; the partial slabs
     // and the bias are summed inside the norm3 kernel that consumes them.
     const int osplit = ((hw.out_layer.kpad / 64) % 7 == 0) ? 7 : 1;
@@ -622,11 +544,11 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
     // --- time / cond modulation ---
     half_t* fc16 = h16a;
     if (!is_cond) {
-        TRY(dvid_modulate_launch(obj_features, ss_dev, 2 * d, ss_dev + d, 0, 2 * d, fc16, R, M, d, s));
+        TRY(dvid_modulate_launch(obj_features, ss_dev, ss_stride, ss_dev + d, 0, ss_stride, fc16, R, M, d, s));
     } else {
         TRY(dvid_silu_f16_launch(cond, h16b, (long)R * d, s));
         TRY(linear_run(hw.c_mlp, h16b, R, f32b, 0, 1, s));
-        TRY(dvid_modulate_launch(obj_features, ss_dev, d, f32b, 1, d, fc16, R, M, d, s));
+        TRY(dvid_modulate_launch(obj_features, ss_dev, ss_stride, f32b, 1, d, fc16, R, M, d, s));
     }
     // --- cls tower ---
     const half_t* cur = fc16;
@@ -698,17 +620,7 @@ int dvid_model_create(const dvid_config* cfg, dvid_model** out) {
     dvid_model* m = new dvid_model();
     m->cfg = *cfg;
     if (const char* e = getenv("DVID_CHAINS")) m->nchain = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
-    if (const char* e = getenv("DVID_FUSE_C3C1")) m->fuse_c3c1 = atoi(e) != 0;
     if (const char* e = getenv("DVID_STEM_S2D")) m->use_s2d = atoi(e) != 0;
-    if (const char* e = getenv("DVID_DYN_CHUNKS")) m->dyn_chunks = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
-    if (const char* e = getenv("DVID_PIPE")) m->pipe_parts = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
-    if (const char* e = getenv("DVID_PIPE_SPLIT")) {
-        int st = 2, b = 0;
-        if (sscanf(e, "%d:%d", &st, &b) >= 1 && st >= 0 && st <= 3 && b >= 0) {
-            m->pipe_stage = st;
-            m->pipe_block = b;
-        }
-    }
     *out = m;
     return DVID_OK;
 }
@@ -720,9 +632,7 @@ int dvid_model_destroy(dvid_model* m) {
                       &m->lat[1], &m->lat[2], &m->roi, &m->params, &m->dyn, &m->qkv, &m->attn16, &m->f32a, &m->f32b, &m->f32c,
                       &m->f32d, &m->h16a, &m->h16b, &m->hid16, &m->ss, &m->deltas, &m->kvproj, &m->mem16, &m->splitk, &m->vt};
     for (DevBuf* b : bufs) b->release();
-    for (auto& kv : m->ss_tables) kv.second.release();
-    for (hipEvent_t e : m->ev_mid) (void)hipEventDestroy(e);
-    for (hipEvent_t e : m->ev_dyn) (void)hipEventDestroy(e);
+    for (auto& kv : m->ss_rows) kv.second.release();
     delete m;
     return DVID_OK;
 }
@@ -759,8 +669,6 @@ int dvid_model_finalize(dvid_model* m) {
                 TRY(make_conv_bn(m, p + ".conv3", 1, 0, 0, &blk.c3));
                 blk.has_sc = (b == 0);
                 if (blk.has_sc) TRY(make_conv_bn(m, p + ".shortcut", stride, 0, 0, &blk.sc));
-                TRY(pack_frag_order(m, &blk.c1));
-                TRY(pack_frag_order(m, &blk.c3));
             }
         }
     }
@@ -869,23 +777,6 @@ int dvid_set_stem_layout(dvid_model* m, int space_to_depth) {
     return DVID_OK;
 }
 
-int dvid_set_fusion(dvid_model* m, int conv3_conv1) {
-    g_err[0] = 0;
-    if (!m) FAIL(DVID_ERR_ARG, "null model");
-    m->fuse_c3c1 = conv3_conv1 != 0;
-    return DVID_OK;
-}
-
-int dvid_set_pipeline(dvid_model* m, int parts, int split_stage, int split_block) {
-    g_err[0] = 0;
-    if (!m || parts < 0 || parts > 64 || split_stage < 0 || split_stage > 3 || split_block < 0)
-        FAIL(DVID_ERR_ARG, "parts 0..64, split stage 0..3 (res2..res5), block >= 0");
-    m->pipe_parts = parts;
-    m->pipe_stage = split_stage;
-    m->pipe_block = split_block;
-    return DVID_OK;
-}
-
 int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width, int boxes_per_frame) {
     g_err[0] = 0;
     if (!m || max_frames <= 0 || boxes_per_frame <= 0) FAIL(DVID_ERR_ARG, "bad argument");
@@ -961,34 +852,21 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
     }
     // Frames are independent through the backbone.  They are processed as `nchain` sub-batches on separate HIP
     // streams: a layer of one sub-batch rarely fills 256 CUs evenly (e.g. res4: 304-608 tiles), and with two chains
-    // in flight the blocks of one chain's next kernel start on the CUs the other chain's tail leaves idle.
-    //
-    // Software pipeline (pipe_parts = P > 1, takes precedence): the first layers (stem, res2, res3: short-K 1x1 convolutions
-    // on large maps) are bound by HBM traffic, the later ones (res4, res5, FPN: long-K 3x3 convolutions on small maps) by the
-    // MFMA / operand-staging rate.  The n frames are cut into P sub-batches; a FRONT stream runs the first part of every
-    // sub-batch back to back, a BACK stream the second part, sub-batch p's back part waiting for its front part by an
-    // event -- so the front of sub-batch p + 1 (memory system) runs beside the back of sub-batch p (matrix cores) on the
-    // same chip.  Same kernels, same per-frame arithmetic: results are bit-identical to the sequential schedule.
-    const bool piped = m->pipe_parts > 1 && n >= 2 * m->pipe_parts;
-    const int nchain = piped ? m->pipe_parts : ((m->nchain > 1 && n >= 2 * m->nchain) ? m->nchain : 1);
+    // in flight the blocks of one chain's next kernel start on the CUs the other chain's tail leaves idle.  (A two-stream
+    // front / back software pipeline of HBM-bound early layers beside MFMA-bound late ones measured no gain,
+    // profiles/r02_backbone_pipeline_sweep.txt; it lives in the history of this file.)
+    const int nchain = (m->nchain > 1 && n >= 2 * m->nchain) ? m->nchain : 1;
     if (nchain > 1) TRY(m->ensure_streams());
     const int per = (n + nchain - 1) / nchain;
     const size_t px = (size_t)height * width, px4 = px / 16;
-    if (piped) {
-        while ((int)m->ev_mid.size() < nchain) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            m->ev_mid.push_back(e);
-        }
-    }
     if (nchain > 1) {
         HIP_TRY(hipEventRecord(m->ev_fork, s));
-        for (int c = 0; c < (piped ? 2 : nchain); ++c) HIP_TRY(hipStreamWaitEvent(m->cs[c], m->ev_fork, 0));
+        for (int c = 0; c < nchain; ++c) HIP_TRY(hipStreamWaitEvent(m->cs[c], m->ev_fork, 0));
     }
     for (int c = 0; c < nchain; ++c) {
         const int f0 = c * per, nf = (f0 + per <= n) ? per : n - f0;
         if (nf <= 0) continue;
-        hipStream_t cs = piped ? m->cs[0] : (nchain > 1 ? m->cs[c] : s);
+        hipStream_t cs = nchain > 1 ? m->cs[c] : s;
         // this chain's slice of every workspace buffer starts at its first frame (f0 + nf <= n <= ws_frames for any
         // chain count, so no slice can run past the end)
         const size_t fo = (size_t)f0;
@@ -1020,18 +898,12 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
         w = (w + 2 - 3) / 2 + 1;
         half_t* cur = bx;  // block input
         int sh[4], sw[4];
-        bool c1_done = false;   // this block's conv1 output already sits in t1 (written by the previous block's fused launch)
         for (int st = 0; st < 4; ++st) {
             const int nb = (int)m->blocks[st].size();
             for (int b = 0; b < nb; ++b) {
                 const Block& blk = m->blocks[st][b];
                 int h2 = h, w2 = w;
-                if (piped && st == m->pipe_stage && b == (m->pipe_block < nb ? m->pipe_block : nb - 1)) {
-                    HIP_TRY(hipEventRecord(m->ev_mid[c], cs));           // front part of this sub-batch done
-                    cs = m->cs[1];
-                    HIP_TRY(hipStreamWaitEvent(cs, m->ev_mid[c], 0));
-                }
-                if (!c1_done) TRY(conv_run(blk.c1, cur, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs));
+                TRY(conv_run(blk.c1, cur, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs));
                 TRY(conv_run(blk.c2, t1, nf, h, w, t2, 1, 0, nullptr, 0, 0, cs, &h2, &w2));
                 const half_t* res = cur;
                 if (blk.has_sc) {
@@ -1040,29 +912,7 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
                 }
                 // res3..res5 outputs persist for the FPN; everything else ping-pongs between bufX/bufY
                 half_t* dst = (b == nb - 1 && stage_out[st]) ? stage_out[st] : (cur == bx ? by : bx);
-                // the block that consumes this one's output: its conv1 is a 1x1 / stride-1 layer on exactly the rows written
-                // here, so it rides in the same launch (csrc/c3c1.hip) -- unless a pipeline hand-over sits between the two
-                const Block* nxt = (b + 1 < nb) ? &m->blocks[st][b + 1] : ((st < 3 && !m->blocks[st + 1].empty()) ? &m->blocks[st + 1][0] : nullptr);
-                const bool handover = piped && nxt && ((b + 1 < nb) ? (st == m->pipe_stage && b + 1 == (m->pipe_block < nb ? m->pipe_block : nb - 1))
-                                                                     : (st + 1 == m->pipe_stage && m->pipe_block == 0));
-                const bool fuse = m->fuse_c3c1 && nxt && !handover && blk.c3.wfrag && nxt->c1.wfrag && nxt->c1.cin == blk.c3.cout &&
-                                  dvid_c3c1_supported(blk.c3.cin, blk.c3.cout, nxt->c1.cout);
-                if (fuse) {
-                    C3C1Params q;
-                    q.a = t2;
-                    q.w3f = blk.c3.wfrag;
-                    q.b3 = blk.c3.bias;
-                    q.r = res;
-                    q.y = dst;
-                    q.w1f = nxt->c1.wfrag;
-                    q.b1 = nxt->c1.bias;
-                    q.z = t1;
-                    q.M = (long)nf * h2 * w2;
-                    TRY(c3c1(q, blk.c3.cin, blk.c3.cout, nxt->c1.cout, cs));
-                } else {
-                    TRY(conv_run(blk.c3, t2, nf, h2, w2, dst, 1, 0, res, 1, 0, cs));
-                }
-                c1_done = fuse;
+                TRY(conv_run(blk.c3, t2, nf, h2, w2, dst, 1, 0, res, 1, 0, cs));
                 h = h2;
                 w = w2;
                 cur = dst;
@@ -1079,14 +929,8 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
             TRY(conv_run(m->lateral[l], stage_out[l + 1], nf, sh[l + 1], sw[l + 1], lat[l], 0, 0, res, res ? 2 : 0, 0, cs));
             TRY(conv_run(m->output[l], lat[l], nf, sh[l + 1], sw[l + 1], pout[l], 0, 0, nullptr, 0, 0, cs));
         }
-        if (nchain > 1 && !piped) {
+        if (nchain > 1) {
             HIP_TRY(hipEventRecord(m->ev_join[c], cs));
-            HIP_TRY(hipStreamWaitEvent(s, m->ev_join[c], 0));
-        }
-    }
-    if (piped) {
-        for (int c = 0; c < 2; ++c) {
-            HIP_TRY(hipEventRecord(m->ev_join[c], m->cs[c]));
             HIP_TRY(hipStreamWaitEvent(s, m->ev_join[c], 0));
         }
     }
@@ -1165,43 +1009,49 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int d = m->cfg.hidden_dim, M = boxes_per_frame;
 
-    // --- time conditioning (box_head.py:533-536 / :645): scale/shift rows are a function of (head, t) only; they are
-    // computed once on the host and every distinct (head, t vector) keeps its device table, so the steady state --
-    // including the 4 alternating time steps of the x4 sampler -- does no host math, no upload and no stream sync.
+    // --- time conditioning (box_head.py:533-536 / :645): a scale/shift row is a function of (head, t) only.  Every distinct
+    // (head slot, t value) keeps ONE device row, computed on the host the first time it is seen; a call whose frames share
+    // one t (every call of the reference's sampler) reads that row with frame stride 0, so the steady state -- including the 4
+    // alternating time steps of the x4 sampler and any ragged tail length -- does no host math, no upload and no stream sync.
     const int slot = (is_cond ? m->cfg.num_heads : 0) + head_index;
-    const float* ss_dev = nullptr;
-    {
-        std::pair<int, std::vector<int64_t>> key(slot, std::vector<int64_t>(t, t + n_frames));
-        auto it = m->ss_tables.find(key);
-        if (it == m->ss_tables.end()) {
-            if (m->ss_tables.size() >= 512) {          // unbounded t streams: start over rather than grow for ever
-                HIP_TRY(hipDeviceSynchronize());
-                for (auto& kv : m->ss_tables) kv.second.release();
-                m->ss_tables.clear();
-            }
-            std::vector<float> tab((size_t)n_frames * hw.bt_out);
+    auto ss_row = [&](int64_t tv, const float** dev) -> int {
+        auto key = std::make_pair(slot, tv);
+        auto it = m->ss_rows.find(key);
+        if (it == m->ss_rows.end()) {
             const int td = 4 * d;
-            for (int f = 0; f < n_frames; ++f) {
-                auto& row = m->ss_rows[std::make_pair(slot, t[f])];
-                if (row.empty()) {
-                    const std::vector<float>& te = time_embedding(m, t[f]);
-                    std::vector<float> sl(td);
-                    for (int i = 0; i < td; ++i) sl[i] = te[i] / (1.f + expf(-te[i]));  // SiLU
-                    row.resize(hw.bt_out);
-                    for (int o = 0; o < hw.bt_out; ++o) {
-                        double acc = hw.bt_b[o];
-                        for (int i = 0; i < td; ++i) acc += (double)hw.bt_w[(size_t)o * td + i] * sl[i];
-                        row[o] = (float)acc;
-                    }
-                }
-                memcpy(&tab[(size_t)f * hw.bt_out], row.data(), (size_t)hw.bt_out * sizeof(float));
+            const std::vector<float>& te = time_embedding(m, tv);
+            std::vector<float> sl(td), row(hw.bt_out);
+            for (int i = 0; i < td; ++i) sl[i] = te[i] / (1.f + expf(-te[i]));  // SiLU
+            for (int o = 0; o < hw.bt_out; ++o) {
+                double acc = hw.bt_b[o];
+                for (int i = 0; i < td; ++i) acc += (double)hw.bt_w[(size_t)o * td + i] * sl[i];
+                row[o] = (float)acc;
             }
             DevBuf buf;
-            TRY(buf.ensure(tab.size() * sizeof(float)));
-            HIP_TRY(hipMemcpy(buf.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));   // once per distinct key
-            it = m->ss_tables.emplace(std::move(key), buf).first;
+            TRY(buf.ensure(row.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(buf.p, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice));   // once per distinct (head, t)
+            it = m->ss_rows.emplace(key, buf).first;
         }
-        ss_dev = it->second.as<float>();
+        *dev = it->second.as<float>();
+        return DVID_OK;
+    };
+    const float* ss_dev = nullptr;
+    int ss_stride = 0;              // floats between the rows of consecutive frames (0: one shared row)
+    bool same_t = true;
+    for (int f = 1; f < n_frames; ++f) same_t = same_t && t[f] == t[0];
+    if (same_t) {
+        TRY(ss_row(t[0], &ss_dev));
+    } else {
+        // frames with different time steps (not produced by the reference's sampler): the rows are laid out per frame in
+        // the workspace by device-to-device copies on the launch stream
+        float* tab = m->ss.as<float>() + (size_t)slot * ((size_t)m->ws_frames + 3) / 4 * 4 * 2 * d;
+        for (int f = 0; f < n_frames; ++f) {
+            const float* row = nullptr;
+            TRY(ss_row(t[f], &row));
+            HIP_TRY(hipMemcpyAsync(tab + (size_t)f * hw.bt_out, row, (size_t)hw.bt_out * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        ss_dev = tab;
+        ss_stride = hw.bt_out;
     }
 
     // Frames are independent inside a head (self-attention is per frame): run them as sub-batch chains on separate
@@ -1221,7 +1071,7 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
         const int f0 = c * per, nf = (f0 + per <= n_frames) ? per : n_frames - f0;
         if (nf <= 0) continue;
         TRY(rcnn_head_chain(m, hw, is_cond, p3, p4, p5, f0, nf, height, width, M, boxes, pro_features, cond, logits, boxes_out,
-                            obj_features, bad_box_flag, ss_dev, (size_t)f0 * M, (size_t)f0 * m->cfg.nheads * 32 * lk_pad,
+                            obj_features, bad_box_flag, ss_dev, ss_stride, (size_t)f0 * M, (size_t)f0 * m->cfg.nheads * 32 * lk_pad,
                             nchain > 1 ? m->cs[c] : s));
         if (nchain > 1) {
             HIP_TRY(hipEventRecord(m->ev_join[c], m->cs[c]));
@@ -1365,14 +1215,6 @@ int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const
     return DVID_OK;
 }
 
-int dvid_mha_core(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int head_dim,
-                  int q_ld, int kv_ld, int out_ld, int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream) {
-    g_err[0] = 0;
-    TRY(dvid_mha_core_launch(q, k, v, out, batch, lq, lk, nheads, head_dim, q_ld, kv_ld, out_ld, q_bs, kv_bs, out_bs, nullptr,
-                             reinterpret_cast<hipStream_t>(stream)));
-    return DVID_OK;
-}
-
 int dvid_mha_f16(const void* q, const void* k, const void* v, void* out, void* vt_scratch, int batch, int lq, int lk, int nheads,
                  int q_ld, int kv_ld, int out_ld, int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream) {
     g_err[0] = 0;
@@ -1438,17 +1280,15 @@ int dvid_profile_reset(void) {
 int dvid_profile_read_bytes(double* igemm_alg_bytes) {
     g_err[0] = 0;
     double b = 0;
-    for (auto& r : g_prof)
-        if (r.kind == 0) b += r.bytes;
+    for (auto& r : g_prof) b += r.bytes;
     if (igemm_alg_bytes) *igemm_alg_bytes = b;
     return DVID_OK;
 }
 
-static int profile_sum(int kind, double* ms_out, double* flop_out, double* bytes_out, int64_t* n_out) {
+static int profile_sum(double* ms_out, double* flop_out, double* bytes_out, int64_t* n_out) {
     double ms = 0, fl = 0, by = 0;
     int64_t n = 0;
     for (auto& r : g_prof) {
-        if (r.kind != kind) continue;
         HIP_TRY(hipEventSynchronize(r.b));
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
@@ -1466,12 +1306,7 @@ static int profile_sum(int kind, double* ms_out, double* flop_out, double* bytes
 
 int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches) {
     g_err[0] = 0;
-    return profile_sum(0, igemm_ms, igemm_flop, nullptr, igemm_launches);
-}
-
-int dvid_profile_read_fused(double* ms, double* flop, double* alg_bytes, int64_t* launches) {
-    g_err[0] = 0;
-    return profile_sum(1, ms, flop, alg_bytes, launches);
+    return profile_sum(igemm_ms, igemm_flop, nullptr, igemm_launches);
 }
 
 // one CSV line per recorded igemm launch: M,N,K,taps,stride,res_mode,ms,tflops
@@ -1479,12 +1314,12 @@ int dvid_profile_dump(const char* path) {
     g_err[0] = 0;
     FILE* f = fopen(path, "w");
     if (!f) FAIL(DVID_ERR_ARG, "cannot open %s", path);
-    fprintf(f, "M,N,K,taps,stride,res_mode,ms,tflops,kind\n");
+    fprintf(f, "M,N,K,taps,stride,res_mode,ms,tflops\n");
     for (auto& r : g_prof) {
         HIP_TRY(hipEventSynchronize(r.b));
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
-        fprintf(f, "%d,%d,%d,%d,%d,%d,%.5f,%.2f,%d\n", r.M, r.N, r.K, r.taps, r.stride, r.res_mode, t, r.flop / (t * 1e-3) / 1e12, r.kind);
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%.5f,%.2f\n", r.M, r.N, r.K, r.taps, r.stride, r.res_mode, t, r.flop / (t * 1e-3) / 1e12);
     }
     fclose(f);
     return DVID_OK;

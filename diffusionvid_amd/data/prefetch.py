@@ -124,19 +124,25 @@ class HostFedVideo:
             self._stage(*nxt)
 
     def _frame(self, v, f):
-        g, slot = self._slot_of[v]
-        j = self._ready[slot][2][f]
         h, w = self.ds.height, self.ds.width
-        return ImageList(self._buf[slot][j:j + 1], [torch.Size((h, w))])
+        staged = self._slot_of.get(v)
+        j = None if staged is None else self._ready[staged[1]][2].get(f)
+        if j is None:
+            # a frame outside the staged window (iteration entered mid-group: a sharded rank's leading calls deliver the local
+            # frames of the group that starts `max_offset` calls later): its own synchronous copy, counted like the others
+            src = self._host[v][f:f + 1]
+            self.h2d_bytes += src.numel() * src.element_size()
+            return ImageList(src.to(self.device), [torch.Size((h, w))])
+        return ImageList(self._buf[staged[1]][j:j + 1], [torch.Size((h, w))])
 
     def __getitem__(self, idx):
         ds = self.ds
         v, frame_id = ds.video_of[idx], ds.frame_seg_id[idx]
-        if frame_id % self.unit == 0 and self._slot_of.get(v, (None, None))[0] != frame_id // self.unit:
-            self._enter_group(v, frame_id // self.unit)
-        real_frame = ds.frame
-        ds.frame = self._frame                       # the index protocol stays the dataset's own
-        try:
-            return ds[idx]
-        finally:
-            ds.frame = real_frame
+        # stage / enter whenever the requested (video, group) is not the staged one -- not only at a group's first frame, so
+        # an index range that resumes mid-group works too.  Exception: the last `max_offset` calls of a group that is not
+        # staged (a sharded rank's leading calls, engine.video_shard_plan) only queue frames of the NEXT group; they take the
+        # single-frame path of _frame instead of staging a whole window for nothing.
+        g = frame_id // self.unit
+        if self._slot_of.get(v, (None, None))[0] != g and (frame_id % self.unit == 0 or frame_id % self.unit < self.unit - ds.max_offset):
+            self._enter_group(v, g)
+        return ds.item(idx, frame=self._frame)       # the index protocol stays the dataset's own; nothing of it is patched

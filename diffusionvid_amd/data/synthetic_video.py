@@ -88,12 +88,18 @@ class SyntheticVIDDataset:
             self.frame(self.video_of[idx], self.frame_seg_id[idx])
 
     def __getitem__(self, idx):
+        return self.item(idx)
+
+    def item(self, idx, frame=None):
+        """The item of dataset index `idx`; `frame(video, f)` replaces the dataset's own frame source (data/prefetch.py hands
+        out views of its device staging buffers through it) -- the index protocol stays this class's."""
+        frame = frame or self.frame
         v, frame_id, seg_len = self.video_of[idx], self.frame_seg_id[idx], self.frame_seg_len[idx]
         ref_l, ref_g, ref_id_final = self.ref_ids(idx)
         images = {
-            "cur": self.frame(v, frame_id),
-            "ref_l": [self.frame(v, i) for i in ref_l],
-            "ref_g": [self.frame(v, i) for i in ref_g],
+            "cur": frame(v, frame_id),
+            "ref_l": [frame(v, i) for i in ref_l],
+            "ref_g": [frame(v, i) for i in ref_g],
             "frame_category": 0 if frame_id == 0 else 1,
             "frame_id": frame_id,
             "start_id": 0,
@@ -105,7 +111,7 @@ class SyntheticVIDDataset:
             # INPUT.LOOKAHEAD_BATCHES extension: the 8 frame slots each of the next batches will be built from, i.e.
             # exactly what calls fb-7 .. fb will deliver through `ref_l` (last frame repeated past the end of the video)
             images["ref_ahead"] = {
-                fb: [self.frame(v, min(fb - self.infer_batch + 1 + i + self.max_offset, seg_len - 1)) for i in range(self.infer_batch)]
+                fb: [frame(v, min(fb - self.infer_batch + 1 + i + self.max_offset, seg_len - 1)) for i in range(self.infer_batch)]
                 for fb in range(frame_id + self.infer_batch, min(frame_id + self.infer_batch * self.lookahead, seg_len), self.infer_batch)}
         return images, None, [idx + i for i in range(self.infer_batch)]
 

@@ -126,6 +126,17 @@ class ResizeToTensorDevice:
         self.min_size, self.max_size, self.div = min_size, max_size, size_divisible
         self.size = None
         self._tables = {}
+        self._pinned_ring = {}
+
+    def _pinned(self, shape, depth=4):
+        """next [pinned buffer, event of its last upload] of a ring of `depth` staging buffers for frames of this shape"""
+        ring = self._pinned_ring.setdefault(shape, {"slots": [], "next": 0})
+        if len(ring["slots"]) < depth:
+            ring["slots"].append([torch.empty(shape, dtype=torch.uint8).pin_memory(), None])
+            return ring["slots"][-1]
+        slot = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % depth
+        return slot
 
     def tables(self, in_size, out_size):
         key = (in_size, out_size)
@@ -136,7 +147,20 @@ class ResizeToTensorDevice:
 
     def __call__(self, image, is_current=False):
         from .. import ops
-        src = image if (isinstance(image, torch.Tensor) and image.is_cuda) else torch.from_numpy(_as_u8_hwc(image)).to(self.device, non_blocking=True)
+        if isinstance(image, torch.Tensor) and image.is_cuda:
+            src = image
+        else:
+            # decoded frame -> a pinned, writable staging buffer of its size (kept per size) -> async H2D.  (A from_numpy view
+            # of the decoder's read-only buffer is pageable: its "non_blocking" upload only works because the runtime stages it
+            # synchronously.)  The staging buffer is reused, so the copy engine must have read it before the next frame lands.
+            u8 = _as_u8_hwc(image)
+            slot = self._pinned(u8.shape)
+            if slot[1] is not None:
+                slot[1].synchronize()          # four uploads back: long done in practice
+            slot[0].numpy()[...] = u8
+            src = slot[0].to(self.device, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(torch.cuda.current_stream(self.device))
         h, w = src.shape[:2]
         if is_current or self.size is None:
             self.size = get_size((w, h), self.min_size, self.max_size)

@@ -160,6 +160,7 @@ class DiffusionDet(nn.Module):
         self.memory_on_side_stream = os.environ.get("DVID_MEMORY_SIDE_STREAM", "1") != "0"
         self._mem_stream = None
         self._mem_side_pending = False
+        self._mem_side_inputs = None
         self.debug_taps = None      # dict -> receives intermediates (parity tests)
         # True: a batch's detections come back with ONE device->host copy and the BoxLists hold CPU tensors
         # (what engine/inference.py does next anyway, there with ~3 copies per frame); False: GPU tensors
@@ -172,8 +173,6 @@ class DiffusionDet(nn.Module):
         if self._engine is None:
             d = self.cfg.MODEL.DiffusionDet
             sd = {k: v for k, v in self.state_dict().items()}
-            if self.device.type == "cuda" and self.device.index is not None:
-                torch.cuda.set_device(self.device)        # the library allocates on the current device
             self._engine = ops.Model(
                 sd, hidden_dim=d.HIDDEN_DIM, nheads=d.NHEADS, dim_feedforward=d.DIM_FEEDFORWARD, dim_dynamic=d.DIM_DYNAMIC,
                 num_classes=d.NUM_CLASSES, num_cls=d.NUM_CLS, num_reg=d.NUM_REG, num_heads=d.NUM_HEADS,
@@ -240,6 +239,11 @@ class DiffusionDet(nn.Module):
         images["ref_g"] = [to_image_list(image) for image in images["ref_g"]]
         infos = dict(images)
         infos.pop("cur")
+        if self.device.type == "cuda" and self.device.index is not None:
+            # the library allocates and launches on the current device: scoped to this call, the caller's current device
+            # is restored on return
+            with torch.cuda.device(self.device):
+                return self._forward_test(images["cur"], infos, targets)
         return self._forward_test(images["cur"], infos, targets)
 
     def _reset_video(self):
@@ -247,10 +251,17 @@ class DiffusionDet(nn.Module):
         self._results_ahead = {}
         n = self.all_frame_interval
         self.local_img_queue = []
-        self.head.proposal_feats_global = [None, None]
+        self._set_global_memory([None, None])
         self.head.proposal_feats_local = [None, None]
         self.queue = deque(maxlen=n)      # entries: (split_outputs, frame index inside the split)
         self.video_index += 1
+
+    def _set_global_memory(self, memory):
+        """every assignment of the video's global memory goes through here: the engine's cached K/V projections of the old
+        memory are dropped explicitly"""
+        self.head.proposal_feats_global = list(memory)
+        if self._engine is not None:
+            self._engine.invalidate_memory()
 
     # ---- one video over several ranks (engine/inference.py: compute_on_video_sharded) -------------------------
     def global_memory(self):
@@ -265,7 +276,7 @@ class DiffusionDet(nn.Module):
         """Start a video whose global memory was built by another rank: per-video reset, then the memory as if this
         process had seen the global frames."""
         self._reset_video()
-        self.head.proposal_feats_global = [m.to(self.device, torch.float32) for m in memory]
+        self._set_global_memory([m.to(self.device, torch.float32) for m in memory])
 
     def model_predictions(self, backbone_feats, images_whwh, x, t, box_extract=0):
         """diffusion_det.py:655-677.  images_whwh: (w, h) of the un-padded frame (same for all frames)."""
@@ -326,6 +337,7 @@ class DiffusionDet(nn.Module):
             if self._mem_side_pending:
                 torch.cuda.current_stream().wait_stream(self._mem_stream)
                 self._mem_side_pending = False
+                self._mem_side_inputs = None          # the side stream's reads are ordered before everything queued from here on
             else:
                 self._build_memory(gsplit)
 
@@ -382,7 +394,7 @@ class DiffusionDet(nn.Module):
         frames' split over (-> True when the hook has run, so it runs once)."""
         if done < n_own or done >= total:
             return done >= n_own          # nothing follows: the caller builds the memory in line
-        on_global(take(len_l, n_own))
+        on_global(take(len_l, n_own, keys=("k1", "k2"), with_feats=False))          # the memory build reads k1 / k2 only
         return True
 
     def _build_memory(self, gsplit):
@@ -390,7 +402,7 @@ class DiffusionDet(nn.Module):
         g2 = gsplit["k2"].reshape(-1, self.hidden_dim)
         m0, _ = ops.update_erase_memory(g1, self.head.proposal_feats_global[0], self.mem_management_size_test)
         m1, _ = ops.update_erase_memory(g2, self.head.proposal_feats_global[1], 150)
-        self.head.proposal_feats_global = [m0, m1]
+        self._set_global_memory([m0, m1])
         if self.debug_taps is not None:
             self.debug_taps["memory"] = [m0, m1]
 
@@ -402,6 +414,10 @@ class DiffusionDet(nn.Module):
         if self._mem_stream is None:
             self._mem_stream = torch.cuda.Stream(device=self.device)
         self._mem_stream.wait_stream(torch.cuda.current_stream())
+        # The split may be fresh concatenations allocated on the launch stream (global frames straddling two launch
+        # sequences): they stay referenced until the launch stream has waited for the side stream, so the caching allocator
+        # cannot hand their blocks to the next sequence's allocations while the side stream still reads them.
+        self._mem_side_inputs = gsplit
         with torch.cuda.stream(self._mem_stream):
             self._build_memory(gsplit)
         self._mem_side_pending = True
@@ -434,7 +450,7 @@ class DiffusionDet(nn.Module):
         eng.reserve(min(cap, total.shape[0]), total.shape[-2], total.shape[-1], M)
         per_frame = []          # (launch result dict, index inside the launch) for every frame slot of `total`
 
-        def take(a, b):
+        def take(a, b, keys=("logits", "boxes", "obj", "k1", "k2"), with_feats=True):
             """result slots [a, b) as one split: views when they sit in one launch, else a concatenation"""
             runs = []
             for j in range(a, b):
@@ -443,15 +459,16 @@ class DiffusionDet(nn.Module):
                     runs[-1][2] = i + 1
                 else:
                     runs.append([src, i, i + 1])
-            keys = ("logits", "boxes", "obj", "k1", "k2")
             if len(runs) == 1:
                 src, i0, i1 = runs[0]
                 out = {k: src[k][i0:i1] for k in keys}
-                out["feats"] = [f[i0:i1] for f in src["feats"]]
+                if with_feats:
+                    out["feats"] = [f[i0:i1] for f in src["feats"]]
                 out["_src"], out["_i0"], out["_i1"] = src, i0, i1          # lets neighbouring splits be re-joined as views
                 return out
             out = {k: torch.cat([src[k][i0:i1] for src, i0, i1 in runs]) for k in keys}
-            out["feats"] = [torch.cat([src["feats"][l][i0:i1] for src, i0, i1 in runs]) for l in range(3)]
+            if with_feats:
+                out["feats"] = [torch.cat([src["feats"][l][i0:i1] for src, i0, i1 in runs]) for l in range(3)]
             return out
 
         fired = on_global is None or not ref_g

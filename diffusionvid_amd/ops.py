@@ -87,17 +87,6 @@ def roialign(feats_nhwc, boxes, height, width, want_mean=False):
     return (roi, mean) if want_mean else roi
 
 
-def mha_core(q, k, v, nheads):
-    """q [B, Lq, d], k/v [B, Lk, d] fp32 (already projected) -> [B, Lq, d]."""
-    q, k, v = _cuda(q, torch.float32), _cuda(k, torch.float32), _cuda(v, torch.float32)
-    B, lq, d = q.shape
-    lk = k.shape[1]
-    out = torch.empty_like(q)
-    call("dvid_mha_core", ptr(q), ptr(k), ptr(v), ptr(out), B, lq, lk, nheads, d // nheads, d, d, d, lq * d, lk * d, lq * d,
-         stream_ptr())
-    return out
-
-
 def mha_f16(q, k, v, nheads):
     """MFMA attention: q [B, Lq, d], k/v [B, Lk, d] (fp32 or fp16, rounded to fp16) -> fp16 [B, Lq, d]."""
     def h(t):
@@ -279,14 +268,6 @@ class Model:
         """ResNet stem over the 2x2 space-to-depth image (default) or the NHWC8 image; see dvid_set_stem_layout"""
         call("dvid_set_stem_layout", self.handle, int(bool(space_to_depth)))
 
-    def set_fusion(self, conv3_conv1=True):
-        """ResNet backbone: conv3 (+ residual) -> next conv1 in one launch (csrc/c3c1.hip); same results either way"""
-        call("dvid_set_fusion", self.handle, int(bool(conv3_conv1)))
-
-    def set_pipeline(self, parts, split_stage=2, split_block=0):
-        """ResNet backbone as a two-stream software pipeline over `parts` sub-batches (0 / 1: off); see dvid_set_pipeline"""
-        call("dvid_set_pipeline", self.handle, int(parts), int(split_stage), int(split_block))
-
     def reserve(self, max_frames, height, width, boxes_per_frame):
         """Workspace for up to max_frames frames of height x width with boxes_per_frame boxes; only ever grows."""
         key = (max_frames, height, width, boxes_per_frame)
@@ -331,15 +312,20 @@ class Model:
              ptr(obj), ptr(bad_flag), stream_ptr())
         return logits, boxes_out, obj
 
+    def invalidate_memory(self):
+        """The global memory changed (new video, memory update, adopted memory, or an in-place write through a raw pointer,
+        which no tensor version counter sees): the next global_xattn projects K/V again."""
+        self._kv_src = None
+
     def global_xattn(self, query, memory):
-        """cond = MHA(query, memory, memory).  The K/V projections of `memory` are computed when the tensor object (or its
-        in-place version counter) differs from the one projected last, i.e. once per memory update of a video."""
+        """cond = MHA(query, memory, memory).  The K/V projections of `memory` are kept until `invalidate_memory()` (the
+        detector calls it wherever it assigns the memory) or until another tensor object is passed, i.e. they are computed
+        once per memory update of a video; staleness is never inferred from tensor version counters."""
         query = _cuda(query, torch.float32)
-        key = (memory, memory._version)
-        if self._kv_src is None or self._kv_src[0] is not memory or self._kv_src[1] != memory._version:
+        if self._kv_src is None or self._kv_src is not memory:
             mem = _cuda(memory, torch.float32)
             call("dvid_global_memory_project", self.handle, ptr(mem), mem.shape[0], stream_ptr())
-            self._kv_src = key               # holds the tensor: its storage cannot be recycled under the cache
+            self._kv_src = memory            # holds the tensor: its storage cannot be recycled under the cache
         out = torch.empty_like(query)
         call("dvid_global_xattn", self.handle, ptr(query), query.shape[0], None, memory.shape[0], ptr(out), stream_ptr())
         return out

@@ -91,17 +91,6 @@ int dvid_set_chains(dvid_model* m, int nchain);
  * (16 channels per block, K = 256 packed columns); 0 = over the NHWC8 image (K = 448).  Same products, different summation order. */
 int dvid_set_stem_layout(dvid_model* m, int space_to_depth);
 
-/* ResNet backbone: fuse every bottleneck's conv3 (+ residual + ReLU) with the next bottleneck's conv1 (+ ReLU) into one
- * launch that keeps the block output's fp16 tile in LDS as the second product's operand (csrc/c3c1.hip).  Results are
- * bit-identical either way; off by default (measured no faster than the two tuned launches, profiles/r02_c3c1_fusion.txt). */
-int dvid_set_fusion(dvid_model* m, int conv3_conv1);
-
-/* Software pipeline of the ResNet backbone: `parts` sub-batches; the layers before block `split_block` of stage
- * `split_stage` (0..3 = res2..res5) of every sub-batch run on a front stream, the rest on a back stream one sub-batch
- * behind, so HBM-bound early layers overlap MFMA-bound late layers.  parts <= 1: off (dvid_set_chains applies).  Results
- * do not depend on the schedule. */
-int dvid_set_pipeline(dvid_model* m, int parts, int split_stage, int split_block);
-
 /* ---- stages -------------------------------------------------------------------------------- */
 /* images: fp32 NCHW [n,3,height,width] in [0,1] (zero padded, un-normalised).  Outputs fp16 NHWC
  * p3 [n,h/8,w/8,256], p4 [n,h/16,w/16,256], p5 [n,h/32,w/32,256]. */
@@ -160,8 +149,6 @@ int dvid_gather_rows(const float* x, const int* idx, float* y, int m, int d, voi
 int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const void* residual, void* out, int n, int h,
                          int wd, int cin, int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int out_f32,
                          int residual_mode, void* stream);
-int dvid_mha_core(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int head_dim,
-                  int q_ld, int kv_ld, int out_ld, int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream);
 /* MFMA attention, head_dim 32: fp16 q/k/v with head h at columns [32h, 32h+32) of each row, fp16 out;
  * vt_scratch: >= batch*nheads*32*(round_up(lk,32)+32) halves (receives V transposed per head). */
 int dvid_mha_f16(const void* q, const void* k, const void* v, void* out, void* vt_scratch, int batch, int lq, int lk, int nheads,
@@ -191,7 +178,8 @@ int dvid_igemm_set_config(int cfg);
 /* Per-shape tile tuning: 1 = the first launch of a new (row bucket, N, K, ...) key times every valid configuration on the
  * launch's own stream (stream sync + ~80 launches once per key; keys bucket the row count 8 steps per octave, so ragged
  * video tails do not create new ones); 0 = never time on the calling path: cached winners (DVID_IGEMM_TUNE_CACHE, earlier
- * launches) or the hand rule; -1 = follow the environment (DVID_IGEMM_TUNE, default on). */
+ * launches) or the hand rule; -1 = follow the environment: DVID_IGEMM_TUNE if set, else 0 when DVID_IGEMM_TUNE_CACHE names a
+ * non-empty winners file (a deployment that ships one is in serving mode by default), else 1. */
 int dvid_igemm_set_tuning(int mode);
 /* 3x3 / stride-1 / pad-1 convolutions with Cin % 32 == 0 and Cout % 128 == 0 (the bottleneck conv2 layers of res3-res5, the FPN
  * output convolutions) on the halo-staged kernel (csrc/conv3x3.hip: the 8 x 32 output patch's input pixels are staged once per
@@ -211,8 +199,6 @@ int dvid_igemm_set_wstat(int mode);
 int dvid_profile_enable(int on);
 int dvid_profile_reset(void);
 int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches);
-/* the fused conv3 -> conv1 launches of the same pass (not included in the igemm figures above) */
-int dvid_profile_read_fused(double* ms, double* flop, double* alg_bytes, int64_t* launches);
 /* sum over the recorded launches of the algorithmic HBM bytes (input + weights + output + residual, each touched once) */
 int dvid_profile_read_bytes(double* igemm_alg_bytes);
 /* CSV (M,N,K,taps,stride,res_mode,ms,tflops), one line per recorded igemm launch */

@@ -134,18 +134,6 @@ def test_roialign_multilevel(dv):
     check("roialign_mean", mean, ref.view(n * M, 256, -1).mean(-1), 1e-3, 1e-3)
 
 
-@pytest.mark.parametrize("B,lq,lk", [(2, 300, 300), (1, 777, 900), (1, 64, 37)])
-def test_mha_core(dv, B, lq, lk):
-    g = torch.Generator().manual_seed(5)
-    d, nh = 256, 8
-    q, k, v = (torch.randn(B, l, d, generator=g) for l in (lq, lk, lk))
-    qh = q.view(B, lq, nh, 32).transpose(1, 2) / math.sqrt(32)
-    kh, vh = k.view(B, lk, nh, 32).transpose(1, 2), v.view(B, lk, nh, 32).transpose(1, 2)
-    ref = (torch.softmax(qh @ kh.transpose(-1, -2), dim=-1) @ vh).transpose(1, 2).reshape(B, lq, d)
-    out = dv.mha_core(q.cuda(), k.cuda(), v.cuda(), nh)
-    check(f"mha_core[{B},{lq},{lk}]", out, ref, 1e-3, 1e-3)
-
-
 @pytest.mark.parametrize("B,lq,lk", [(2, 300, 300), (1, 777, 900), (1, 64, 37), (3, 17, 1)])
 def test_mha_mfma(dv, B, lq, lk):
     """MFMA attention: fp16 operands (oracle gets the same rounded q/k/v), fp32 softmax, fp16 output."""
@@ -561,54 +549,6 @@ def test_resize_u8_matches_pillow(dv, hw, mn, mx):
     # a reference frame re-uses the current frame's size (transforms.py:63-65)
     other = rng.randint(0, 256, size=hw + (3,)).astype(np.uint8)
     assert tf(other, False).image_size == (oh, ow)
-
-
-def test_backbone_pipeline_schedule_bit_identical(dv):
-    """dvid_set_pipeline: the two-stream front/back software pipeline of the ResNet backbone (sub-batches, split point inside
-    res4 and at a stage boundary, ragged last sub-batch) must return exactly the sequential schedule's feature maps."""
-    from diffusionvid_amd.utils import synthetic
-    blocks = (1, 2, 3, 1)
-    sd = synthetic.make_state_dict(0, blocks=blocks)
-    g = torch.Generator().manual_seed(21)
-    imgs = torch.rand(11, 3, 96, 160, generator=g).cuda()
-    model = dv.Model(sd, res_blocks=blocks)
-    model.reserve(11, 96, 160, 300)
-    model.set_chains(1)
-    ref = [t.clone() for t in model.backbone(imgs)]
-    for parts, st, blk in ((2, 2, 0), (3, 2, 1), (4, 1, 0), (5, 3, 0), (2, 2, 7)):
-        model.set_pipeline(parts, st, blk)
-        got = model.backbone(imgs)
-        torch.cuda.synchronize()
-        assert all(torch.equal(a, b) for a, b in zip(got, ref)), (parts, st, blk)
-    model.set_pipeline(0)
-    model.close()
-
-
-@pytest.mark.parametrize("blocks,hw,n", [((2, 2, 3, 2), (96, 160), 3), ((3, 4, 5, 3), (64, 96), 5)])
-def test_backbone_conv3_conv1_fusion_bit_identical(dv, blocks, hw, n):
-    """csrc/c3c1.hip: conv3 (+ residual + ReLU) fused with the next bottleneck's conv1 must reproduce the two separate
-    igemm launches bit for bit (same K order, same single fp16 rounding) -- checked on the feature maps of a backbone whose
-    every fusable pair is present (inside res2 / res3 / res4, across the res2->res3 and res3->res4 boundaries, block 0 with
-    its shortcut as the residual), with a row count that is not a multiple of the 64-row tile."""
-    from diffusionvid_amd.utils import synthetic
-    sd = synthetic.make_state_dict(0, blocks=blocks)
-    g = torch.Generator().manual_seed(31)
-    imgs = torch.rand(n, 3, hw[0], hw[1], generator=g).cuda()
-    model = dv.Model(sd, res_blocks=blocks)
-    model.reserve(n, hw[0], hw[1], 300)
-    model.set_chains(1)
-    model.set_fusion(False)
-    ref = [t.clone() for t in model.backbone(imgs)]
-    model.set_fusion(True)
-    got = model.backbone(imgs)
-    torch.cuda.synchronize()
-    for name, a, b in zip(("p3", "p4", "p5"), got, ref):
-        assert torch.equal(a, b), f"{name}: {(a.float() - b.float()).abs().max().item():.3e} max abs difference"
-    model.set_chains(2)
-    got2 = model.backbone(imgs)
-    torch.cuda.synchronize()
-    assert all(torch.equal(a, b) for a, b in zip(got2, ref))
-    model.close()
 
 
 def test_igemm_smallc_16_channels(dv):
