@@ -441,6 +441,65 @@ def g14_vid_dataset_protocol():
     save("g14_vid_dataset_protocol", **arrs)
 
 
+def g16_full_dim_head():
+    """Full-dimension reference modules (HIDDEN_DIM 256, NHEADS 8, DIM_FEEDFORWARD 2048, DIM_DYNAMIC 64, 300 boxes) with the
+    seeded weights of diffusionvid_amd.utils.synthetic.make_head_state_dict(0) loaded into the reference's own DynamicHead --
+    every matrix rounded to an fp16-representable value first, which is what the HIP path holds.  Only inputs and outputs are
+    stored (the weights are regenerated from the seed by the test): `-m gpu` tests feed the same inputs to dvid_rcnn_head /
+    dvid_dynconv and compare with these outputs directly, no oracle in between (box_head.py:495-548, :605-664, :687-711)."""
+    from diffusionvid_amd.utils import synthetic
+    cfg = S.head_cfg()
+    d, M, n, H, W = 256, 300, 1, 96, 160
+    shape = {k: SimpleNamespace(stride=s, channels=d) for k, s in zip(["p3", "p4", "p5"], [8, 16, 32])}
+    h = BH.DynamicHead(cfg, shape).eval()
+    sd = synthetic.make_head_state_dict(0)
+    sd16 = {k[len("head."):]: (v.half().float() if v.dim() > 1 else v.clone()) for k, v in sd.items()}
+    h.load_state_dict(sd16, strict=True)
+    g = torch.Generator().manual_seed(160)
+    r16 = lambda x: x.half().float()
+    feats = [r16(torch.randn(n, d, H // s, W // s, generator=g) * 0.5) for s in (8, 16, 32)]
+    cxcy = torch.rand(n, M, 2, generator=g) * torch.tensor([W, H]) * 1.2 - torch.tensor([W, H]) * 0.1
+    wh = torch.exp(torch.rand(n, M, 2, generator=g) * 5.0 + 0.4)
+    boxes = torch.cat([cxcy - wh / 2, cxcy + wh / 2], dim=-1)
+    boxes[0, 0] = torch.tensor([10.0, 10.0, 10.0, 10.0])            # zero area
+    boxes[0, 1] = torch.tensor([-50.0, -40.0, W + 80.0, H + 60.0])  # larger than the image
+    boxes[0, 2] = torch.tensor([W - 3.0, H - 3.0, W + 40.0, H + 40.0])
+    t = torch.tensor([499], dtype=torch.long)
+    with torch.no_grad():
+        time = h.time_mlp(t)
+        cl0, bx0, of0 = h.head_series[0](feats, boxes, None, h.box_pooler, time)       # pro_features None branch
+        of0 = r16(of0)          # stored as fp16 and handed on as such: both sides start the next head from the same values
+        cl1, bx1, of1 = h.head_series[1](feats, bx0, of0, h.box_pooler, time)
+        of1 = r16(of1)
+        cond = r16(torch.randn(n * M, d, generator=g))
+        cl2, bx2, of2 = h.head_series_cond[0](feats, bx1, of1, h.box_pooler, time, cond)
+        # DynamicConv alone on fp16-representable RoI tiles and parameters: the reference's forward runs with its dynamic_layer
+        # replaced by a module that returns the (rounded) parameters the real layer produced, so the bmm / LayerNorm / ReLU
+        # path sees exactly the operands the HIP kernel is given
+        dc = h.head_series[2].inst_interact
+        R = 4
+        roi = r16(torch.randn(49, R, d, generator=g))
+        pro = r16(torch.randn(1, R, d, generator=g))
+        params = r16(dc.dynamic_layer(pro))                      # [1, R, 2 * 256 * 64]
+        real = dc.dynamic_layer
+
+        class Fixed(torch.nn.Module):
+            def forward(self, x):
+                return params
+
+        mid = {}
+        hook = dc.norm2.register_forward_hook(lambda mod, inp, out: mid.__setitem__("t", out))   # ReLU(inplace) lands in it
+        dc.dynamic_layer = Fixed()
+        dc_out = dc(pro, roi)
+        dc.dynamic_layer = real
+        hook.remove()
+    f16 = lambda x: x.detach().numpy().astype(np.float16)
+    save("g16_full_dim_head", p3=f16(feats[0]), p4=f16(feats[1]), p5=f16(feats[2]), boxes=boxes, t=t, cond=f16(cond),
+         cl0=cl0, bx0=bx0, of0=f16(of0), cl1=cl1, bx1=bx1, of1=f16(of1), cl2=cl2, bx2=bx2, of2=f16(of2),
+         dc_roi=f16(roi), dc_params=f16(params[0]), dc_mid=f16(mid["t"]), dc_out=dc_out,
+         weights_seed=np.array(0), n=np.array(n), M=np.array(M), H=np.array(H), W=np.array(W))
+
+
 if __name__ == "__main__":
     # The reference targets torch 1.8 (INSTALL.md:3-13) where nn.MultiheadAttention.forward IS
     # F.multi_head_attention_forward; keep torch 2.x's fused inference fast path out of the goldens.
@@ -461,3 +520,4 @@ if __name__ == "__main__":
     g13_checkpoint_matching()
     g15_vid_eval_motion()
     g14_vid_dataset_protocol()
+    g16_full_dim_head()

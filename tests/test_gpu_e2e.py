@@ -110,6 +110,131 @@ def _ap50_vs_oracle(ref_out, got_out, size):
     return vid_eval.eval_detection_vid(preds, gts)["map"]
 
 
+def _box_eps(b, px=0.5, rel=0.01):
+    """a box coordinate may differ by max(0.5 px, 1 % of the box size)"""
+    return np.maximum(px, rel * np.maximum(b[..., 2] - b[..., 0], b[..., 3] - b[..., 1]))
+
+
+def _iou_interval(a, ea, b, eb):
+    """[lowest, highest] IoU of boxes a and b (no +1, as batched_nms) when every coordinate of a may move by ea and of b by eb"""
+    iw = min(a[2], b[2]) - max(a[0], b[0])
+    ih = min(a[3], b[3]) - max(a[1], b[1])
+    e = ea + eb
+    inter_hi = max(0.0, iw + e) * max(0.0, ih + e)
+    inter_lo = max(0.0, iw - e) * max(0.0, ih - e)
+
+    def area(x, d):
+        return max(0.0, x[2] - x[0] + 2 * d) * max(0.0, x[3] - x[1] + 2 * d)
+    un_lo = max(area(a, -ea) + area(b, -eb) - inter_hi, inter_hi, 1e-12)
+    un_hi = max(area(a, ea) + area(b, eb) - inter_lo, 1e-12)
+    return inter_lo / un_hi, min(1.0, inter_hi / un_lo)
+
+
+def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h, tol_s=5e-3, iou_thr=0.5):
+    """SURVEY.md 8(d)'s end-to-end criterion on the final stage of one call: "boxes <= 0.5 px or 1e-2 rel, scores <= 5e-3, set-equality
+    of kept detections after excluding candidates within tolerance of a threshold (NMS IoU 0.5, top-300 boundary)".
+    o_* / g_*: [S, n, M, C] logits and [S, n, M, 4] boxes of the oracle and of the GPU path for the same box slots (S ensemble
+    steps).  The GPU side's detections are what its own post-processing kernels (dvid_postproc_topk_nms) return for the GPU
+    logits / boxes; the oracle side's decisions are re-derived here with the tolerance analysis:
+      * a (step, box, class) candidate is NEAR THE TOP-K BOUNDARY if its oracle score is within tol_s of the step's 300th / 301st
+        score gap; such candidates are excluded and, since either side may or may not hold them, they count as possible
+        suppressors in the NMS analysis;
+      * walking the remaining candidates in descending oracle score, a candidate is SUPPRESSED for sure if a surely-kept candidate
+        of its class that is surely ahead of it (score gap > 2 tol_s) overlaps it by more than 0.5 under EVERY box perturbation
+        within the box tolerance; it is UNDECIDED if some kept / undecided / boundary candidate of its class that can be ahead of
+        it (score within 2 tol_s counts) overlaps it by more than 0.5 under SOME perturbation; otherwise it is KEPT for sure.
+    Every surely-kept candidate must be among the GPU detections with |dscore| <= tol_s and box within max(0.5 px, 1 %); no
+    surely-suppressed candidate and no candidate surely outside the top-k may be.  Returns (decided, undecided + boundary)."""
+    from diffusionvid_amd import ops
+    S, n, M, C = o_logits.shape
+    gb, gs, gl, gc = (t.cpu().numpy() for t in ops.postproc_topk_nms(g_logits.cuda().contiguous(), g_boxes.cuda().contiguous(), w, h, iou_thr, True))
+    so = torch.sigmoid(o_logits).reshape(S, n, M * C).numpy()
+    sg = torch.sigmoid(g_logits).reshape(S, n, M * C).numpy()
+    ob = o_boxes.numpy().astype(np.float64)
+    gbx_all = g_boxes.numpy().astype(np.float64)
+    n_decided = n_open = n_dets = 0
+    worst_s = worst_b = 0.0
+    for f in range(n):
+        keys, near = [], set()
+        for st in range(S):
+            order = np.argsort(-so[st, f], kind="stable")
+            gap = 0.5 * (so[st, f][order[M - 1]] + so[st, f][order[M]])
+            inside = set(order[:M].tolist())
+            close = np.nonzero(np.abs(so[st, f] - gap) <= tol_s)[0].tolist()
+            for k in set(close) | inside:
+                keys.append((st, k))
+                if k in close:
+                    near.add((st, k))
+            # the GPU path's own top-k set may differ from the oracle's only by boundary candidates
+            g_inside = set(np.argsort(-sg[st, f], kind="stable")[:M].tolist())
+            assert (g_inside ^ inside) <= set(close), f"{tag} frame {f} step {st}: top-{M} sets differ beyond the score tolerance: {sorted((g_inside ^ inside) - set(close))[:8]}"
+        keys.sort(key=lambda k: -so[k[0], f][k[1]])
+        score = {k: float(so[k[0], f][k[1]]) for k in keys}
+        box = {k: ob[k[0], f, k[1] // C] for k in keys}
+        eps = {k: float(_box_eps(box[k])) for k in keys}
+        label = {k: k[1] % C + 1 for k in keys}
+        status = {}
+        by_label = {}
+        for k in keys:                         # descending oracle score within each class
+            by_label.setdefault(label[k], []).append(k)
+        for same in by_label.values():
+            for b in same:
+                if b in near:
+                    status[b] = "open"
+                    continue
+                sure = maybe = False
+                for a in same:
+                    if a is b or status.get(a, "later") == "suppressed":
+                        continue
+                    if score[a] - score[b] < -2 * tol_s:
+                        break                  # descending score: nothing further down can be ahead of b
+                    lo, hi = _iou_interval(box[a], eps[a], box[b], eps[b])
+                    # "later": not yet classified (its score is within 2 tol_s of b's, below or equal)
+                    if status.get(a, "later") == "kept" and score[a] - score[b] > 2 * tol_s and lo > iou_thr:
+                        sure = True
+                        break
+                    if hi > iou_thr:
+                        maybe = True
+                status[b] = "suppressed" if sure else ("open" if maybe else "kept")
+        # GPU detections of this frame -> candidate keys (same label, same score and clipped box to rounding)
+        det_keys = set()
+        k_cnt = int(gc[f])
+        n_dets += k_cnt
+        for j in range(k_cnt):
+            lab, sc, bx = int(gl[f, j]), float(gs[f, j]), gb[f, j].astype(np.float64)
+            best, best_d = None, 1e9
+            for st in range(S):
+                cand = np.nonzero(np.abs(sg[st, f][lab - 1::C] - sc) <= 2e-6)[0]          # boxes i with class lab-1 at that score
+                for i in cand:
+                    cb = np.clip(gbx_all[st, f, i], 0, [w - 1, h - 1, w - 1, h - 1])
+                    d = np.abs(cb - bx).max()
+                    if d < best_d:
+                        best, best_d = (st, int(i) * C + lab - 1), d
+            assert best is not None and best_d <= 1e-2, f"{tag} frame {f}: GPU detection {j} is not one of the GPU path's own candidates"
+            det_keys.add(best)
+            if best in status and status[best] == "kept":
+                worst_s = max(worst_s, abs(score[best] - sc))
+                ref_box = np.clip(box[best], 0, [w - 1, h - 1, w - 1, h - 1])
+                worst_b = max(worst_b, float(np.abs(ref_box - bx).max() / eps[best]))
+        for k, st_k in status.items():
+            if st_k == "kept":
+                assert k in det_keys, f"{tag} frame {f}: candidate (step {k[0]}, box {k[1] // C}, class {k[1] % C + 1}, score {score[k]:.4f}) is kept by the oracle beyond every tolerance but missing on the GPU"
+            elif st_k == "suppressed":
+                assert k not in det_keys, f"{tag} frame {f}: candidate (step {k[0]}, box {k[1] // C}, class {k[1] % C + 1}) is suppressed by the oracle beyond every tolerance but kept on the GPU"
+        for k in det_keys - set(status):
+            raise AssertionError(f"{tag} frame {f}: GPU keeps (step {k[0]}, box {k[1] // C}, class {k[1] % C + 1}), which is outside the oracle's top-{M} beyond the score tolerance")
+        n_decided += sum(1 for v in status.values() if v != "open")
+        n_open += sum(1 for v in status.values() if v == "open")
+    line = (f"{tag} threshold-aware detection sets: {n_decided} candidates decided beyond tolerance (all agree with the {n_dets} GPU detections), "
+            f"{n_open} excluded as within tolerance of the top-{M} / IoU {iou_thr} thresholds ({n_open / max(1, n_open + n_decided):.1%}); "
+            f"kept pairs: max |dscore| = {worst_s:.2e}, max box error / bound = {worst_b:.2f}")
+    print(line)
+    with open("gpurun_out/parity_report.txt", "a") as fh:
+        fh.write(line + "\n")
+    assert worst_s <= tol_s and worst_b <= 1.0, line
+    return n_decided, n_open
+
+
 def _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, **bounds):
     """Final stage (global attention + conditioned head) of every DDIM step with the ORACLE's memory, and for steps > 0
     the oracle's renewed boxes, injected: logits / boxes per step within the stated bounds."""
@@ -118,7 +243,8 @@ def _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, **bounds)
     model.head.proposal_feats_global = [oracle.mem[0].cuda(), oracle.mem[1].cuda()]
     entries = [model.queue[i] for i in range(L)]
     feats_cur, cached = model._gather_entries(entries)
-    for step, (time, _) in enumerate(model._time_pairs()):
+    ens = {"ol": [], "ob": [], "gl": [], "gb": []}
+    for step, (time, time_next) in enumerate(model._time_pairs()):
         with torch.no_grad():
             t = torch.full((L,), time, dtype=torch.long)
             if sample_step == 1:
@@ -134,6 +260,12 @@ def _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, **bounds)
         ref_cl, ref_bx = oracle.taps[f"final_{step}"]
         _stage_check(f"{tag} final stage, DDIM step {step} (t = {time}; oracle memory"
                      + (", oracle boxes)" if step else ")"), None, None, oc_[-1].cpu(), ref_cl, ob_[-1].cpu(), ref_bx, **bounds)
+        if sample_step == 1 or time_next >= 0:          # the steps that reach the detections (diffusion_det.py:573-575, :598-604)
+            ens["ol"].append(ref_cl); ens["ob"].append(ref_bx); ens["gl"].append(oc_[-1].cpu()); ens["gb"].append(ob_[-1].cpu())
+    # detections of this final stage under SURVEY.md 8(d)'s criterion: decisions beyond the stated tolerances must be identical
+    decided, open_ = _threshold_aware_detections(tag, torch.stack(ens["ol"]), torch.stack(ens["ob"]), torch.stack(ens["gl"]),
+                                                 torch.stack(ens["gb"]), float(W0), float(H0))
+    assert decided >= 0.5 * (decided + open_), f"{tag}: more than half of the candidates sit within tolerance of a threshold ({open_} of {decided + open_})"
 
 
 @pytest.mark.parametrize("sample_step", [1, 4])
@@ -583,8 +715,11 @@ def test_streaming_mode_online_memory_update():
     MAX_OFFSET 0) with GLOBAL.STOP_UPDATE_AFTER_INIT_TEST False, i.e. one frame per call and one new global frame per call
     after the first (vid_mega.py:213-215): every call merges 75 / 25 new rows into the 900 / 150-row memories and prunes
     them back by farthest-point sampling (diffusion_det.py:479-488, :841-896).  Against the CPU oracle running the same
-    protocol: per call, the GPU's pruning on the ORACLE's merged rows returns the oracle's rows exactly (integer work);
-    the free-running GPU memory stays the same point set up to near-ties; detections match."""
+    protocol, compared PER CALL: every call starts from the oracle's memory of the previous call (as _final_stage_vs_oracle
+    injects it), so what is compared is one call's work -- extraction, merge + pruning, final stage, detections -- not the
+    drift two free-running memories accumulate over 30 re-prunings (measured last round: 0.87 -> 0.73 of the rows with a twin,
+    while single calls agree as the other end-to-end tests do).  The GPU's pruning on the ORACLE's merged rows returns the
+    oracle's picks (integer work; cdist differs in the last bits, so exact near-ties may swap)."""
     from diffusionvid_amd import ops
     from diffusionvid_amd.config import get_cfg
     from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
@@ -605,16 +740,21 @@ def test_streaming_mode_online_memory_update():
     ds = SyntheticVIDDataset([L], cfg, height=H0, width=W0, device="cuda", smooth=True)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     oracle = odet.OracleDiffusionDet(sd, odet.DetCfg(blocks=blocks, infer_batch=1, all_frame_interval=1), synthetic.noise_fn)
-    rates, mem_close = [], []
+    rates, mem_close, fin_ok = [], [], []
     for idx in range(L):
         images, oitem, ids = _oracle_items(ds, idx)
         assert len(images["ref_l"]) == 1 and len(images["ref_g"]) == (24 if idx == 0 else 1) and ids == [idx]
         mem_before = None if idx == 0 else [m.clone() for m in oracle.mem]
+        if idx > 0:
+            model._set_global_memory([m.cuda() for m in mem_before])          # this call starts from the oracle's memory
+        model.debug_taps = {}
         with torch.no_grad():
             ref = oracle.forward(oitem)
             got = model(images)
         assert len(ref) == len(got) == 1
         rates.append(_match_rate(ref[0], got[0]))
+        fin_ok.append(_stage_check(f"[streaming] call {idx} final stage", None, None, model.debug_taps["final_0"][0].cpu(), oracle.taps["final_0"][0],
+                                   model.debug_taps["final_0"][1].cpu(), oracle.taps["final_0"][1], frac_ok=0.97))
         if idx > 0:
             # the pruning step alone, on the oracle's own rows: cat(memory 900, new 75) -> cdist -> FPS(900) -> gather
             new = oracle.taps["extract"][2][1:]                 # object features of the call's global frame
@@ -637,10 +777,10 @@ def test_streaming_mode_online_memory_update():
     with open("gpurun_out/parity_report.txt", "a") as f:
         f.write(f"[streaming INFER_BATCH=1, online memory] detections matched min {min(rates):.2f} mean {sum(rates) / len(rates):.3f}; "
                 f"memory twins first {mem_close[0]:.3f} last {mem_close[-1]:.3f}\n")
-    assert min(rates) >= 0.85 and sum(rates) / len(rates) >= 0.95
-    # free-running memories drift apart as a point set (every call re-picks 900 of 975 rows from slightly different features:
-    # measured 0.87 -> 0.73 of the oracle's rows with a GPU row within 0.5 over 30 calls) while the detections stay matched
-    assert min(mem_close) > 0.5
+    assert min(rates) >= 0.9 and sum(rates) / len(rates) >= 0.97
+    # one call's merge + pruning from the same 900 rows: at most the 75 new rows (own fp16-path features) and near-tie picks differ
+    assert min(mem_close[1:]) > 0.9 and mem_close[0] > 0.8
+    assert sum(fin_ok) / len(fin_ok) >= 0.99
 
 
 def test_real_dataset_front_end_device_transform_equals_host_transform(tmp_path):

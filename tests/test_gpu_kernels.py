@@ -252,6 +252,56 @@ def test_rcnn_head(dv, cond):
     model.close()
 
 
+def test_head_kernels_against_full_dimension_reference_fixture(dv):
+    """dvid_rcnn_head and dvid_dynconv against the REFERENCE's own RCNNHead / RCNNHead_cond / DynamicConv at the kernels'
+    dimensions (256 / 8 / 2048 / 64, 300 boxes), no oracle in between: tests/golden/g16_full_dim_head.npz holds inputs and
+    outputs of the reference modules run on synthetic.make_head_state_dict(0) with fp16-representable matrices
+    (make_golden.py: g16_full_dim_head; box_head.py:495-548, :605-664, :687-711).  What separates the two sides is fp16
+    storage of the activations between ~12 chained layers and the fp32 summation order: the bounds are those of
+    test_rcnn_head (2e-2 of the LayerNorm-ed O(1) values; boxes relative to the box size)."""
+    from conftest import golden
+    from diffusionvid_amd.utils import synthetic
+    z = golden("g16_full_dim_head")
+    n, M, H, W = (int(z[k]) for k in ("n", "M", "H", "W"))
+    sd = synthetic.make_head_state_dict(int(z["weights_seed"]))
+    T32 = lambda k: torch.from_numpy(z[k].astype(np.float32))
+    fd = [dv.nhwc_from_nchw(T32(k).cuda()) for k in ("p3", "p4", "p5")]
+    t = torch.from_numpy(z["t"])
+    model = dv.Model(sd, res_blocks=(0, 0, 0, 0))
+    model.reserve(n, H, W, M)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def boxes_close(tag, got, want, inp):
+        bw = (inp[..., 2:] - inp[..., :2]).clamp(min=1.0).max(-1).values
+        err = ((got.cpu() - want).abs().max(-1).values / bw).max().item()
+        print(f"{tag}: boxes rel-to-size err max={err:.3e}")
+        assert err < 3e-2, tag
+
+    stages = (("head_series.0", 0, False, "boxes", None, "0"), ("head_series.1", 1, False, "bx0", "of0", "1"),
+              ("head_series_cond.0", 0, True, "bx1", "of1", "2"))
+    for name, idx, is_cond, kb, kf, o in stages:
+        bin_ = T32(kb)
+        pro = None if kf is None else T32(kf)[0].cuda()
+        gl, gb, go = model.rcnn_head(idx, fd, H, W, bin_.cuda(), pro, t, cond=T32("cond").cuda() if is_cond else None, bad_flag=flag)
+        check(f"reference_fixture[{name}].obj_features", go, T32("of" + o)[0], 2e-2, 2e-2)
+        check(f"reference_fixture[{name}].logits", gl, T32("cl" + o), 2e-2, 2e-2)
+        boxes_close(f"reference_fixture[{name}]", gb, T32("bx" + o), bin_)
+    assert int(flag.item()) == 0
+    model.close()
+
+    # DynamicConv's two per-box products + LayerNorm + ReLU on the fixture's own parameters
+    pfx = "head.head_series.2.inst_interact"
+    R, d, dd = z["dc_params"].shape[0], 256, 64
+    roi = T32("dc_roi").permute(1, 0, 2).contiguous()              # [R, 49, 256]
+    params = T32("dc_params")
+    p1 = params[:, :d * dd].view(R, d, dd)
+    p2 = params[:, d * dd:].view(R, dd, d)
+    packed = torch.cat([p1.transpose(1, 2).reshape(R, -1), p2.transpose(1, 2).reshape(R, -1)], dim=1)   # P1T | P2T (model.hip: make_head)
+    out = dv.dynconv(roi.cuda().half(), packed.cuda().half(), sd[pfx + ".norm1.weight"].cuda(), sd[pfx + ".norm1.bias"].cuda(),
+                     sd[pfx + ".norm2.weight"].cuda(), sd[pfx + ".norm2.bias"].cuda())
+    check("reference_fixture[dynconv]", out, T32("dc_mid"), 4e-3, 4e-3)
+
+
 def test_global_xattn(dv):
     sd, sdo = _head_setup()
     g = torch.Generator().manual_seed(9)

@@ -61,6 +61,32 @@ def test_g4_rcnn_head():
     close(cl2, z["cl2"]); close(bx2, z["bx2"]); close(of2, z["of2"])
 
 
+def _g16_weights():
+    """the fixture's weights: synthetic.make_head_state_dict(seed), matrices rounded to fp16-representable values
+    (tests/golden/make_golden.py: g16_full_dim_head)"""
+    from diffusionvid_amd.utils import synthetic
+    z = golden("g16_full_dim_head")
+    sd = synthetic.make_head_state_dict(int(z["weights_seed"]))
+    return z, {k: (v.half().float() if v.dim() > 1 else v) for k, v in sd.items()}
+
+
+def test_g16_full_dimension_heads():
+    """The oracle at the HIP path's own dimensions (256 / 8 / 2048 / 64, 300 boxes) against the reference's RCNNHead,
+    RCNNHead_cond and DynamicConv run on the same seeded weights -- the full-size anchor SURVEY.md 8(c) asks for."""
+    z, sd = _g16_weights()
+    full = HeadCfg()
+    F32 = lambda k: T(z[k].astype(np.float32))
+    feats = [F32("p3"), F32("p4"), F32("p5")]
+    time = schedule.time_mlp(sd, "head.", T(z["t"]), 256)
+    # feature outputs are stored as fp16 (rounding 5e-4 relative): compared at 1e-3
+    cl0, bx0, of0 = head.rcnn_head(sd, "head.head_series.0", feats, T(z["boxes"]), None, time, full)
+    close(cl0, z["cl0"], atol=2e-4); close(bx0, z["bx0"], rtol=1e-4, atol=1e-2); close(of0, z["of0"].astype(np.float32), rtol=1e-3, atol=1e-3)
+    cl1, bx1, of1 = head.rcnn_head(sd, "head.head_series.1", feats, T(z["bx0"]), F32("of0"), time, full)
+    close(cl1, z["cl1"], atol=2e-4); close(bx1, z["bx1"], rtol=1e-4, atol=1e-2); close(of1, z["of1"].astype(np.float32), rtol=1e-3, atol=1e-3)
+    cl2, bx2, of2 = head.rcnn_head(sd, "head.head_series_cond.0", feats, T(z["bx1"]), F32("of1"), time, full, cond=F32("cond"))
+    close(cl2, z["cl2"], atol=2e-4); close(bx2, z["bx2"], rtol=1e-4, atol=1e-2); close(of2, z["of2"].astype(np.float32), rtol=1e-3, atol=1e-3)
+
+
 def test_g5_dynamic_head_extract_and_final():
     z = golden("g5_dynamic_head")
     sd = golden_sd(z)
