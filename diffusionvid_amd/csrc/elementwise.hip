@@ -9,12 +9,15 @@ namespace {
 
 // fp32 NCHW [n,3,h,w] in [0,1] -> normalised fp16 NHWC8 (channels 3..7 zero).
 // diffusion_det.py:301-303 normalizer fused with the layout change the stem conv wants.
-__global__ void prep_images_kernel(const float* __restrict__ in, half_t* __restrict__ out, long npix, long hw, float m0, float m1,
+// Frames arrive as a table of per-frame pointers (kernel argument, up to FrameTable::kMax frames per launch): the caller's
+// frames need not be one contiguous [n, 3, h, w] tensor -- the reference hands the detector a list of per-frame tensors
+// (diffusion_det.py:418-421 concatenates them; here nothing is copied).
+__global__ void prep_images_kernel(FrameTable in, half_t* __restrict__ out, long npix, long hw, float m0, float m1,
                                    float m2, float s0, float s1, float s2) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const long img = i / hw, pix = i - img * hw;
-    const float* p = in + img * 3 * hw + pix;
+    const float* p = in.p[img] + pix;
     half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     v[0] = (half_t)((p[0] - m0) * s0);
     v[1] = (half_t)((p[hw] - m1) * s1);
@@ -25,7 +28,7 @@ __global__ void prep_images_kernel(const float* __restrict__ in, half_t* __restr
 // The same normaliser with a 2x2 space-to-depth layout: out[n][Y][X][(dy*2 + dx)*3 + c] (12 channels + 4 zero = 32 bytes per
 // 2x2 pixel block).  The 7x7 / stride-2 stem convolution over 3 channels is then a 4x4 / stride-1 convolution over these 16
 // channels (csrc/model.hip: make_stem_s2d): K = 256 instead of 448 padded columns and half the input bytes.
-__global__ void prep_images_s2d_kernel(const float* __restrict__ in, half_t* __restrict__ out, long nblk, int h2, int w2, float m0,
+__global__ void prep_images_s2d_kernel(FrameTable in, half_t* __restrict__ out, long nblk, int h2, int w2, float m0,
                                        float m1, float m2, float s0, float s1, float s2) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk) return;
@@ -33,7 +36,7 @@ __global__ void prep_images_s2d_kernel(const float* __restrict__ in, half_t* __r
     const long img = i / per, b = i - img * per;
     const int Y = (int)(b / w2), X = (int)(b - (long)Y * w2);
     const long w = 2L * w2, hw = 4 * per;
-    const float* p = in + img * 3 * hw + (2L * Y) * w + 2 * X;
+    const float* p = in.p[img] + (2L * Y) * w + 2 * X;
     half8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {0, 0, 0, 0, 0, 0, 0, 0};
     half_t v[12];
 #pragma unroll
@@ -370,22 +373,34 @@ __global__ void modulate_kernel(const float* __restrict__ x, const float* __rest
 
 }  // namespace
 
-int dvid_prep_images_launch(const float* nchw, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
+int dvid_prep_images_launch(const float* const* frames, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
                             hipStream_t s) {
-    const long hw = (long)h * w, npix = hw * n;
-    hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, nchw, nhwc8, npix, hw, mean[0],
-                       mean[1], mean[2], inv_std[0], inv_std[1], inv_std[2]);
-    LAUNCH_CHECK();
+    const long hw = (long)h * w;
+    for (int f0 = 0; f0 < n; f0 += FrameTable::kMax) {
+        const int nf = n - f0 < FrameTable::kMax ? n - f0 : FrameTable::kMax;
+        FrameTable tab;
+        for (int i = 0; i < FrameTable::kMax; ++i) tab.p[i] = frames[f0 + (i < nf ? i : 0)];
+        const long npix = hw * nf;
+        hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, tab, nhwc8 + (long)f0 * hw * 8, npix, hw,
+                           mean[0], mean[1], mean[2], inv_std[0], inv_std[1], inv_std[2]);
+        LAUNCH_CHECK();
+    }
     return DVID_OK;
 }
 
-int dvid_prep_images_s2d_launch(const float* nchw, half_t* s2d16, int n, int h, int w, const float* mean, const float* inv_std,
+int dvid_prep_images_s2d_launch(const float* const* frames, half_t* s2d16, int n, int h, int w, const float* mean, const float* inv_std,
                                 hipStream_t s) {
     if ((h | w) & 1) return DVID_ERR_ARG;
-    const long nblk = (long)n * (h / 2) * (w / 2);
-    hipLaunchKernelGGL(prep_images_s2d_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, nchw, s2d16, nblk, h / 2, w / 2,
-                       mean[0], mean[1], mean[2], inv_std[0], inv_std[1], inv_std[2]);
-    LAUNCH_CHECK();
+    const long per = (long)(h / 2) * (w / 2);
+    for (int f0 = 0; f0 < n; f0 += FrameTable::kMax) {
+        const int nf = n - f0 < FrameTable::kMax ? n - f0 : FrameTable::kMax;
+        FrameTable tab;
+        for (int i = 0; i < FrameTable::kMax; ++i) tab.p[i] = frames[f0 + (i < nf ? i : 0)];
+        const long nblk = per * nf;
+        hipLaunchKernelGGL(prep_images_s2d_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, tab, s2d16 + (long)f0 * per * 16, nblk,
+                           h / 2, w / 2, mean[0], mean[1], mean[2], inv_std[0], inv_std[1], inv_std[2]);
+        LAUNCH_CHECK();
+    }
     return DVID_OK;
 }
 

@@ -30,9 +30,15 @@ bool dvid_wstat_preferred(const IgemmParams& p);
 int dvid_wstat_launch(const IgemmParams& p, hipStream_t s);
 
 // elementwise.hip
-int dvid_prep_images_launch(const float* nchw, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
+// per-frame source pointers of one image-prep launch (passed by value as a kernel argument)
+struct FrameTable {
+    static constexpr int kMax = 32;
+    const float* p[kMax];
+};
+// frames[i]: fp32 CHW [3, h, w] in [0, 1] of frame i (a host array of n device pointers; the frames need not be contiguous)
+int dvid_prep_images_launch(const float* const* frames, half_t* nhwc8, int n, int h, int w, const float* mean, const float* inv_std,
                             hipStream_t s);
-int dvid_prep_images_s2d_launch(const float* nchw, half_t* s2d16, int n, int h, int w, const float* mean, const float* inv_std,
+int dvid_prep_images_s2d_launch(const float* const* frames, half_t* s2d16, int n, int h, int w, const float* mean, const float* inv_std,
                                 hipStream_t s);
 int dvid_maxpool3x3s2_launch(const half_t* in, half_t* out, int n, int h, int w, int c, hipStream_t s);
 int dvid_nchw_from_nhwc_launch(const half_t* in, float* out, int n, int h, int w, int c, hipStream_t s);

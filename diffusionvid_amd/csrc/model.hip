@@ -837,7 +837,19 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
 
 int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
                              void* stream) {
+    if (!images || n <= 0) {
+        g_err[0] = 0;
+        FAIL(DVID_ERR_ARG, "no images");
+    }
+    std::vector<const float*> frames(n);
+    for (int i = 0; i < n; ++i) frames[i] = images + (size_t)i * 3 * height * width;
+    return dvid_backbone_resnet_fpn_frames(m, frames.data(), n, height, width, p3, p4, p5, stream);
+}
+
+int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, int n, int height, int width, void* p3, void* p4, void* p5,
+                                    void* stream) {
     g_err[0] = 0;
+    if (!frames || n <= 0) FAIL(DVID_ERR_ARG, "no frames");
     if (!m || !m->finalized || !m->has_backbone || m->cfg.backbone_type != 0)
         FAIL(DVID_ERR_STATE, "model not finalized or built without a ResNet backbone");
     // capacity, not equality: a set mixes frame sizes (ImageNet-VID has 16:9 and 4:3 videos) and the workspace only grows
@@ -887,10 +899,10 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
         if (m->use_s2d) {
             // normalise + 2x2 space-to-depth (16 halves per block: the same bytes per frame as half an NHWC8 image), then the stem
             // as a 4x4 / stride-1 convolution on the half-resolution grid
-            TRY(dvid_prep_images_s2d_launch(images + (size_t)f0 * 3 * px, img8, nf, height, width, mean, inv_std, cs));
+            TRY(dvid_prep_images_s2d_launch(frames + f0, img8, nf, height, width, mean, inv_std, cs));
             TRY(conv_run(m->stem_s2d, img8, nf, h / 2, w / 2, t1, 1, 0, nullptr, 0, 0, cs, &h, &w));
         } else {
-            TRY(dvid_prep_images_launch(images + (size_t)f0 * 3 * px, img8, nf, height, width, mean, inv_std, cs));
+            TRY(dvid_prep_images_launch(frames + f0, img8, nf, height, width, mean, inv_std, cs));
             TRY(conv_run(m->stem, img8, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs, &h, &w));
         }
         TRY(dvid_maxpool3x3s2_launch(t1, bx, nf, h, w, 64, cs));
@@ -939,7 +951,19 @@ int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int heig
 
 int dvid_backbone_swin_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
                            void* stream) {
+    if (!images || n <= 0) {
+        g_err[0] = 0;
+        FAIL(DVID_ERR_ARG, "no images");
+    }
+    std::vector<const float*> frames(n);
+    for (int i = 0; i < n; ++i) frames[i] = images + (size_t)i * 3 * height * width;
+    return dvid_backbone_swin_fpn_frames(m, frames.data(), n, height, width, p3, p4, p5, stream);
+}
+
+int dvid_backbone_swin_fpn_frames(dvid_model* m, const float* const* frames, int n, int height, int width, void* p3, void* p4, void* p5,
+                                  void* stream) {
     g_err[0] = 0;
+    if (!frames || n <= 0) FAIL(DVID_ERR_ARG, "no frames");
     if (!m || !m->finalized || !m->has_backbone || m->cfg.backbone_type != 1) FAIL(DVID_ERR_STATE, "model has no Swin backbone");
     // capacity, not equality: a set mixes frame sizes (ImageNet-VID has 16:9 and 4:3 videos) and the workspace only grows
     if (n > m->ws_frames || height > m->ws_h || width > m->ws_w || height % 32 || width % 32)
@@ -951,7 +975,7 @@ int dvid_backbone_swin_fpn(dvid_model* m, const float* images, int n, int height
         mean[i] = m->cfg.pixel_mean[i] / 255.f;
         inv_std[i] = 1.f / (m->cfg.pixel_std[i] / 255.f);
     }
-    TRY(dvid_prep_images_launch(images, m->img8.as<half_t>(), n, height, width, mean, inv_std, s));
+    TRY(dvid_prep_images_launch(frames, m->img8.as<half_t>(), n, height, width, mean, inv_std, s));
     // patch embedding: 4x4/4 conv (implicit GEMM on NHWC8) -> fp32 tokens -> LayerNorm  (swintransformer.py:441-458)
     int H = height, W = width;
     float* x = m->sw_x.as<float>();

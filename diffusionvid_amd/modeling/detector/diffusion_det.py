@@ -442,12 +442,19 @@ class DiffusionDet(nn.Module):
             group = [to_image_list(im).tensors for im in ahead[fb]]
             frames += group
             noise.append(self._noise("box_init", fb, 0, 0, (len(group), M, 4)))
-        total = torch.cat(frames).to(self.device, torch.float32)
+        # Frames stay where they are: the backbone reads each through a pointer table (ops.Model.backbone_frames).  Only frames
+        # that are not fp32 device tensors of one size (host tensors of a plain DataLoader, other dtypes) are concatenated and
+        # moved as the reference does (diffusion_det.py:418-421).
+        as_list = os.environ.get("DVID_FRAME_LIST", "1") != "0" and all(f.is_cuda and f.device == self.device and f.dtype == torch.float32 and f.shape[0] == 1 and f.shape == frames[0].shape
+                      for f in frames)
+        total = None if as_list else torch.cat(frames).to(self.device, torch.float32)
+        n_total = len(frames) if as_list else total.shape[0]
+        fh, fw = frames[0].shape[-2:]
         box_init_all = torch.cat(noise)
         # frames per launch sequence: one look-ahead group (taking the first call's 24 global frames into the same sequence --
         # 128 frames instead of 104 + 24 -- measured 1 % slower, A/B on one box)
         cap = self.infer_batch * self.lookahead
-        eng.reserve(min(cap, total.shape[0]), total.shape[-2], total.shape[-1], M)
+        eng.reserve(min(cap, n_total), fh, fw, M)
         per_frame = []          # (launch result dict, index inside the launch) for every frame slot of `total`
 
         def take(a, b, keys=("logits", "boxes", "obj", "k1", "k2"), with_feats=True):
@@ -472,12 +479,11 @@ class DiffusionDet(nn.Module):
             return out
 
         fired = on_global is None or not ref_g
-        for ci, a in enumerate(range(0, total.shape[0], cap)):
-            chunk = total[a:a + cap].contiguous()
-            feats = eng.backbone(chunk)
+        for ci, a in enumerate(range(0, n_total, cap)):
+            feats = eng.backbone_frames(frames[a:a + cap]) if as_list else eng.backbone(total[a:a + cap].contiguous())
             if ci == 0 and self.after_first_launch is not None:
                 self.after_first_launch()          # e.g. the data layer's prefetch of the next group: behind this call's own uploads
-            B = chunk.shape[0]
+            B = feats[0].shape[0]
             if self.skip_unobservable:
                 # x4: of the extraction pass only the backbone features of every frame and the top-k
                 # object features of the GLOBAL frames are ever read -- the 3 heads run on the global frames of this chunk only
@@ -492,7 +498,7 @@ class DiffusionDet(nn.Module):
                     res["k1"][g0:g1] = k1.view(g1 - g0, self.top_k[0], d)
                     res["k2"][g0:g1] = k2.view(g1 - g0, self.top_k[1], d)
                 per_frame += [(res, i) for i in range(B)]
-                fired = fired or self._fire_on_global(on_global, take, len_l, n_own, a + B, total.shape[0])
+                fired = fired or self._fire_on_global(on_global, take, len_l, n_own, a + B, n_total)
                 continue
             t = torch.full((B,), 999, dtype=torch.long)
             (cl, bx, pf), k1, k2 = self.model_predictions(feats, whwh, box_init_all[a:a + B], t, box_extract=ci + 1)
@@ -501,7 +507,7 @@ class DiffusionDet(nn.Module):
             per_frame += [(res, i) for i in range(B)]
             if self.debug_taps is not None:
                 self.debug_taps.setdefault("extract", []).append((cl, bx, pf[0], feats))
-            fired = fired or self._fire_on_global(on_global, take, len_l, n_own, a + B, total.shape[0])
+            fired = fired or self._fire_on_global(on_global, take, len_l, n_own, a + B, n_total)
 
         local = take(0, len_l) if len_l else None
         glob = take(len_l, n_own) if ref_g else None

@@ -291,6 +291,25 @@ class Model:
             call(fn, self.handle, ptr(images[a:b]), b - a, h, w, ptr(outs[0][a:b]), ptr(outs[1][a:b]), ptr(outs[2][a:b]), stream_ptr())
         return outs
 
+    def backbone_frames(self, frames):
+        """The same over a LIST of per-frame tensors, each fp32 [1, 3, H, W] (or [3, H, W]) on the device, all of one size: the
+        kernels read every frame where it lies (a table of pointers), no concatenated copy is made
+        (diffusion_det.py:418-421 concatenates)."""
+        first = frames[0]
+        h, w = first.shape[-2:]
+        keep = []
+        for f in frames:
+            if not f.is_cuda or f.dtype != torch.float32 or f.shape[-2:] != (h, w) or f.shape[-3] != 3 or f.numel() != 3 * h * w:
+                raise _lib.DvidError("backbone_frames: frames must be fp32 [1, 3, H, W] device tensors of one size")
+            keep.append(f if f.is_contiguous() else f.contiguous())
+        n = len(keep)
+        dev = first.device
+        outs = [torch.empty((n, h >> s, w >> s, self.hidden_dim), dtype=torch.float16, device=dev) for s in (3, 4, 5)]
+        table = (C.c_void_p * n)(*[f.data_ptr() for f in keep])
+        fn = "dvid_backbone_swin_fpn_frames" if self.backbone_kind == "swin" else "dvid_backbone_resnet_fpn_frames"
+        call(fn, self.handle, table, n, h, w, ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream_ptr())
+        return outs          # `keep` may die here: the stream-ordered caching allocator re-uses a frame's block only behind this stream's reads
+
     def rcnn_head(self, head_index, feats_nhwc, height, width, boxes, pro_features, t, cond=None, bad_flag=None):
         """One RCNNHead / RCNNHead_cond pass.  boxes [n, M, 4]; pro_features [n*M, d] or None; t: int64 [n] (CPU)."""
         boxes = _cuda(boxes, torch.float32)

@@ -96,11 +96,17 @@ int dvid_set_stem_layout(dvid_model* m, int space_to_depth);
  * p3 [n,h/8,w/8,256], p4 [n,h/16,w/16,256], p5 [n,h/32,w/32,256]. */
 int dvid_backbone_resnet_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
                              void* stream);
+/* The same with the frames as a host array of n device pointers, each an fp32 CHW [3, height, width] frame: the reference hands
+ * the detector a list of per-frame tensors and concatenates them (diffusion_det.py:418-421); here nothing is copied. */
+int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, int n, int height, int width, void* p3, void* p4, void* p5,
+                                    void* stream);
 
 /* Swin-Transformer + FPN (mega_core/modeling/backbone/swintransformer.py:464-751, out_indices (1,2,3)); same
  * inputs/outputs as dvid_backbone_resnet_fpn. */
 int dvid_backbone_swin_fpn(dvid_model* m, const float* images, int n, int height, int width, void* p3, void* p4, void* p5,
                            void* stream);
+int dvid_backbone_swin_fpn_frames(dvid_model* m, const float* const* frames, int n, int height, int width, void* p3, void* p4, void* p5,
+                                  void* stream);
 
 /* One RCNNHead (cond == NULL) or RCNNHead_cond pass.  head_index indexes head_series, or
  * head_series_cond when is_cond.  t: host int64 [n_frames] diffusion timesteps.

