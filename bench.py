@@ -51,7 +51,10 @@ from diffusionvid_amd.engine import inference as engine  # noqa: E402
 from diffusionvid_amd.modeling.detector import build_detection_model  # noqa: E402
 from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
-TRAFFIC_FILE = "r02d_pmc_igemm_traffic.json"
+# measured HBM bytes per implicit-GEMM launch (rocprofv3 --pmc passes of tools/profile_round.sh), one file PER CONFIGURATION: a line
+# only ever carries the traffic collected on its own workload, never another configuration's
+TRAFFIC_FILES = {("r101", 1): "r03_pmc_igemm_traffic_r101_x1.json", ("r101", 4): "r03_pmc_igemm_traffic_r101_x4.json",
+                 ("swinb", 1): "r03_pmc_igemm_traffic_swinb_x1.json"}
 PEAK_FP16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 # algorithmic work per output frame: backbone + heads + global attention, faithful pass counts
@@ -114,6 +117,71 @@ def cpu_baseline(cfg, sd, frames, height, width):
                       "%d threads (fastest of a 16..%d probe on one backbone pass)" % (warm, dt, torch.get_num_threads(), os.cpu_count())}
 
 
+def _decode_u8(path):
+    """what a DataLoader worker of the reference does per frame up to the tensor hand-over: open + decode (PIL, vid.py:96 /
+    vid_mega.py:223-233) -> uint8 HWC array"""
+    import numpy as np
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"))
+
+
+def real_data_feed_rate(device, n_files=48, passes=4):
+    """Can a host keep ONE GPU fed with real frames?  n_files synthetic 1280x720 JPEG files (quality 90, ~ImageNet-VID's 720p
+    snippets) on local disk -> a pool of decode workers (the reference uses 16 PIL workers, configs/vid_R_101_DiffusionVID.yaml:69)
+    -> uint8 [720, 1280, 3] frames -> pinned staging + H2D + the device's Pillow-exact resize / ToTensor / padding
+    (dvid_resize_u8_to_f32).  Reports the decode rate of the pool and the rate of the upload + resize leg alone; the slower of
+    the two is what a host-fed pipeline delivers per GPU (JPEG decode itself stays on the host: SURVEY.md 2, out of scope)."""
+    import multiprocessing as mp
+    import shutil
+    import tempfile
+
+    import numpy as np
+    from PIL import Image
+
+    from diffusionvid_amd.data import transforms as T
+    d = tempfile.mkdtemp(prefix="dvid_feed_")
+    try:
+        rng = np.random.RandomState(0)
+        paths = []
+        for i in range(n_files):
+            yy, xx = np.mgrid[0:720, 0:1280]
+            img = np.stack([(128 + 100 * np.sin(xx / (37.0 + i) + c) * np.cos(yy / (53.0 + 2 * i))) for c in range(3)], -1)
+            img = np.clip(img + rng.randn(720, 1280, 3) * 6, 0, 255).astype(np.uint8)
+            paths.append(os.path.join(d, "%06d.JPEG" % i))
+            Image.fromarray(img).save(paths[-1], format="JPEG", quality=90)
+        workers = max(1, min(16, (os.cpu_count() or 2) - 1))
+        with mp.get_context("fork").Pool(workers) as pool:
+            pool.map(_decode_u8, paths[:workers])                      # start-up
+            t0 = time.perf_counter()
+            n = 0
+            for _ in range(passes):
+                for _arr in pool.imap_unordered(_decode_u8, paths, chunksize=2):
+                    n += 1
+            decode_fps = n / (time.perf_counter() - t0)
+        arrs = [_decode_u8(p) for p in paths[:16]]
+        tf = T.ResizeToTensorDevice(device, 600, 1000, 32)
+        for a in arrs[:4]:
+            tf(a, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m = 0
+        for _ in range(passes * 3):
+            for a in arrs:
+                tf(a, False)
+                m += 1
+        torch.cuda.synchronize()
+        dev_fps = m / (time.perf_counter() - t0)
+        return {"decode_workers": workers, "host_cpus": os.cpu_count(), "decode_frames_per_sec": round(decode_fps, 1),
+                "upload_resize_frames_per_sec": round(dev_fps, 1), "frame": "1280x720 JPEG q90 -> uint8 HWC -> fp32 CHW 576x1000 padded to 576x1024",
+                "delivered_frames_per_sec": round(min(decode_fps, dev_fps), 1),
+                "what": "image files on local disk -> PIL decode in a worker pool (pickled back to the parent, as DataLoader workers hand tensors "
+                        "over) ; then, measured separately, pinned staging + async H2D of the uint8 frame + dvid_resize_u8_to_f32 on one "
+                        "stream from one host thread"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def vidval(args, build, timed, barrier, device, rank, world, H, W):
     """BASELINE.json configs[4]: the VID-val-shaped set (555 videos, 176126 frames, lengths 24..3262) sharded over the ranks
     by frame-count-balanced whole videos, every rank running the reference's per-item loop over its videos,
@@ -137,17 +205,18 @@ def vidval(args, build, timed, barrier, device, rank, world, H, W):
     with torch.no_grad():
         res = run_video(model, ds, device)
     nfr = len(res)
-    merged = engine.gather_predictions({(rank << 32) + k: v.to("cpu") for k, v in res.items()}, device=device) if world > 1 else res
+    grouped = dist.is_available() and dist.is_initialized()
+    merged = engine.gather_predictions({(rank << 32) + k: v.to("cpu") for k, v in res.items()}, device=device, always=True) if grouped else res
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     ff = torch.tensor([nfr], dtype=torch.float64, device=device)
-    if world > 1:
+    if grouped:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(ff, op=dist.ReduceOp.SUM)
     if rank == 0:
         total = int(sum(lens))
-        assert int(ff.item()) == total and (world == 1 or len(merged) == total)
+        assert int(ff.item()) == total and len(merged) == total
         print(json.dumps({
             "metric": "frames/sec (1000x600) DiffusionVID-%s x%d, VID-val-shaped set" % ("R101" if args.arch == "r101" else "SwinB", args.sample_step),
             "value": round(total / float(tt.item()), 2), "unit": "frames/sec", "n_gpus": world, "steps": 1, "warmup": 0,
@@ -156,10 +225,10 @@ def vidval(args, build, timed, barrier, device, rank, world, H, W):
             "config": {"workload": "%d synthetic videos / %d frames shaped like ImageNet-VID val (lengths %d..%d), 1000x600, 300 boxes, "
                                    "frame-count-balanced whole videos per rank; frames drawn from a pool of 128 resident frames"
                                    % (len(lens), total, min(lens), max(lens)),
-                       "lookahead_batches": args.lookahead, "ranks": world,
+                       "lookahead_batches": args.lookahead, "ranks": world, "process_group": ("nccl, %d rank(s)" % dist.get_world_size()) if grouped else "none",
                        "frames_of_heaviest_rank_over_mean": round(max(sum(lens[v] for v in p) for p in balanced_video_partition(lens, world))
                                                                   / (total / world), 5)}}), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return 0
@@ -225,6 +294,7 @@ def main():
                     help="MODEL.DiffusionDet.SKIP_UNOBSERVABLE for the main measurement (x4 only; SURVEY.md Appendix B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned frames, H2D in the timed region) measurement")
+    ap.add_argument("--no-feed-rate", action="store_true", help="skip the real-data feed-rate measurement (image files -> decode workers -> uint8 H2D -> device resize)")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the reference-protocol (look-ahead 1), x4 and Swin-B measurements reported inside the line")
     ap.add_argument("--workload", choices=("video", "vidval"), default="video",
@@ -232,6 +302,9 @@ def main():
                          "BASELINE.json configs[4] -- a 555-video / 176126-frame VID-val-shaped set (data/samplers.vid_val_shaped_lengths) "
                          "sharded over the ranks by balanced_video_partition, strong scaling; one step = the whole set (or --videos K of it)")
     ap.add_argument("--videos", type=int, default=0, help="vidval: use only the first K videos of the set (0 = all 555)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="build the process group even for one rank (env:// rendezvous on 127.0.0.1) so that a single GPU runs the RCCL "
+                         "gather / all-reduce path of the N-rank job (tests/test_gpu_dist.py)")
     ap.add_argument("--dry", action="store_true",
                     help="launcher / collective check without a GPU: every rank fabricates its shard's predictions, the gather to "
                          "rank 0 runs over gloo, and the JSON line reports the ranks seen (tests/test_dist_gloo.py)")
@@ -255,9 +328,18 @@ def main():
         raise SystemExit("rank %d has no GPU: %d visible device(s) for --gpus %d" % (rank, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    grouped = world > 1 or args.force_dist          # a process group exists: collectives run (through RCCL, also for one rank)
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        comm.init_dist("nccl")
+        if world == 1:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            sk.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        comm.init_dist("nccl", force=True)
         assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
 
     headline = args.arch == "r101" and args.sample_step == 1
@@ -267,15 +349,15 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def build(arch, sample_step, lookahead, skip_unobservable=False):
+    def build(arch, sample_step, lookahead, skip_unobservable=False, extra=()):
         yaml = "configs/vid_R_101_DiffusionVID.yaml" if arch == "r101" else "configs/vid_Swin_B_DiffusionVID.yaml"
         cfg = get_cfg(os.path.join(ROOT, yaml), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", lookahead,
                                                  "MODEL.DiffusionDet.SAMPLE_STEP", sample_step,
-                                                 "MODEL.DiffusionDet.SKIP_UNOBSERVABLE", bool(skip_unobservable)],
+                                                 "MODEL.DiffusionDet.SKIP_UNOBSERVABLE", bool(skip_unobservable)] + list(extra),
                       os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
         cfg.freeze()
         model = build_detection_model(cfg).to(device).eval()
@@ -294,21 +376,37 @@ def main():
             t0 = time.perf_counter()
             frames = 0
             results = {}
+            wait0 = model.host_wait_s
             for s in range(steps):
                 if before_step:
                     before_step()
                 r = run_video(model, ds, device)
                 frames += len(r)
                 results.update({k + s * L + rank * steps * L: v.to("cpu") for k, v in r.items()})
-            if gather and world > 1:
-                engine.gather_predictions(results, device=device)
+            tg = time.perf_counter()
+            if gather and grouped:
+                engine.gather_predictions(results, device=device, always=True)
+            gather_s = time.perf_counter() - tg
             barrier()
             dt = time.perf_counter() - t0
+        # host view of this rank: the share of the timed region it spent blocked on its GPU (device->host result copies).  A rank
+        # near 0 is host-bound (its Python loop, uploads, ... pace the GPU); the minimum over ranks is the rank to look at.
+        wait_frac = (model.host_wait_s - wait0) / max(dt, 1e-9)
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         ff = torch.tensor([frames], dtype=torch.float64, device=device)
-        if world > 1:
+        wmin = torch.tensor([wait_frac], dtype=torch.float64, device=device)
+        wmax = wmin.clone()
+        gs = torch.tensor([gather_s], dtype=torch.float64, device=device)
+        if grouped:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+            dist.all_reduce(wmin, op=dist.ReduceOp.MIN)
+            dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(gs, op=dist.ReduceOp.MAX)
+        timed.last = {"host_blocked_on_gpu_frac_min_over_ranks": round(float(wmin.item()), 4),
+                      "host_blocked_on_gpu_frac_max_over_ranks": round(float(wmax.item()), 4),
+                      "gather_ms_max_over_ranks": round(float(gs.item()) * 1e3, 3),
+                      "omp_num_threads": int(os.environ.get("OMP_NUM_THREADS", "0") or 0), "host_cpus": os.cpu_count()}
         return float(tt.item()), float(ff.item())
 
     def release(model):
@@ -327,6 +425,7 @@ def main():
         # configuration on the first launch of each GEMM shape; DVID_IGEMM_TUNE_CACHE makes that persistent)
         run_video(model, ds, device)
     dt, total_frames = timed(model, ds, args.steps, args.warmup, gather=True)
+    host_view = dict(timed.last)
 
     # ---- the same workload fed from the HOST: pinned fp32 frames, double-buffered H2D inside the timed region (what the
     # reference's loop times, mega_core/engine/inference.py:29-40) -------------------------------------------------
@@ -376,8 +475,9 @@ def main():
         lib.dvid_profile_dump(os.environ["DVID_PROFILE_DUMP"].encode())
     lib.dvid_profile_reset()
     traffic = mfma_busy = None
+    TRAFFIC_FILE = TRAFFIC_FILES.get((args.arch, args.sample_step), "")
     tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-    if os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected in-process)
+    if TRAFFIC_FILE and os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS configuration (cannot be collected in-process)
         pmc = json.load(open(tpath))
         traffic = round(pmc["hbm_bytes_per_launch"])
         mfma_busy = pmc.get("mfma_busy_fraction")
@@ -393,8 +493,9 @@ def main():
         roofline = {"bound": "mfma", "kernel": "implicit-GEMM conv/linear kernels, fp16 MFMA (igemm2_kernel; conv3x3_* for the 3x3 / stride-1 layers; wstat_kernel for the short-K / wide-N 1x1 layers)",
                     "achieved": round(tflops, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP16_TFLOPS, 4),
                     "traffic": traffic,
-                    "traffic_source": "profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh on this "
-                                      "workload, bytes per launch; not collected in this run)" % TRAFFIC_FILE,
+                    "traffic_source": ("profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh on this "
+                                       "configuration's workload, bytes per launch; not collected in this run)" % TRAFFIC_FILE) if traffic is not None
+                                      else "no PMC profile of this configuration is committed (tools/profile_round.sh <tag> --arch ... --sample-step ...)",
                     "mfma_busy_pmc": None if mfma_busy is None else round(mfma_busy, 4),
                     "end_to_end_tflops": round(fps / max(world, 1) * ALG_GFLOP_PER_FRAME.get((args.arch, args.sample_step), 0) / 1e3, 1),
                     "end_to_end_frac": round(fps / max(world, 1) * ALG_GFLOP_PER_FRAME.get((args.arch, args.sample_step), 0) / 1e3 / PEAK_FP16_TFLOPS, 4),
@@ -415,27 +516,47 @@ def main():
     del model
     others = {}
 
-    def side(name, arch, sample_step, lookahead, steps, skip_unobservable=False):
+    def side(name, arch, sample_step, lookahead, steps, skip_unobservable=False, extra=(), note=None):
         try:
-            c2, m2 = build(arch, sample_step, lookahead, skip_unobservable)
+            c2, m2 = build(arch, sample_step, lookahead, skip_unobservable, extra)
             d2 = SyntheticVIDDataset([L], c2, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
             d2._cache = ds._cache                  # same frames, already resident
             with torch.no_grad():
                 run_video(m2, d2, device)
             t2, f2 = timed(m2, d2, steps, 1)
             others[name] = {"value": round(f2 / t2, 2), "unit": "frames/sec", "ms_per_step": round(t2 / steps * 1e3, 2),
-                            "lookahead_batches": lookahead, "infer_batch": c2.INPUT.INFER_BATCH, "sample_step": sample_step, "steps": steps}
+                            "lookahead_batches": lookahead, "infer_batch": c2.INPUT.INFER_BATCH, "sample_step": sample_step, "steps": steps,
+                            "host_blocked_on_gpu_frac": timed.last["host_blocked_on_gpu_frac_min_over_ranks"]}
+            if note:
+                others[name]["ms_per_frame"] = round(t2 / max(f2, 1) * world * 1e3, 3)
+                others[name]["what"] = note
             release(m2)
         except Exception as e:                     # a side measurement must never take the headline line down
             others[name] = {"error": repr(e)[:300]}
 
     if not args.no_side_configs:
-        side("reference_protocol_lookahead_1", args.arch, args.sample_step, 1, 2)
+        side("reference_protocol_lookahead_1", args.arch, args.sample_step, 1, 5)
         if headline and world == 1:
-            side("r101_x4", "r101", 4, 38, 2)
+            side("r101_x4", "r101", 4, 38, 5)
             # 12 observable head passes per frame instead of the faithful 19 (same detections)
-            side("r101_x4_observable_passes_only", "r101", 4, 38, 2, skip_unobservable=True)
-            side("swinb_x1", "swinb", 1, 76, 2)
+            side("r101_x4_observable_passes_only", "r101", 4, 38, 5, skip_unobservable=True)
+            side("swinb_x1", "swinb", 1, 76, 5)
+            # the latency-oriented variant of demo/demo.py:60-68 -- one frame per call, one new global frame per
+            # call merged into the memory and pruned back (vid_mega.py:213-215)
+            side("r101_x1_streaming", "r101", 1, 1, 3,
+                 extra=["INPUT.INFER_BATCH", 1, "MODEL.VID.MEGA.MAX_OFFSET", 0, "MODEL.VID.MEGA.MIN_OFFSET", 0,
+                        "MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 1, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 0,
+                        "MODEL.VID.MEGA.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST", False],
+                 note="INFER_BATCH 1, ALL_FRAME_INTERVAL 1, MAX_OFFSET 0, GLOBAL.STOP_UPDATE_AFTER_INIT_TEST False: every call runs the backbone + "
+                      "extraction heads on its own frame and one new global frame, merges 75 / 25 rows into the 900 / 150-row memories, prunes them "
+                      "by farthest-point sampling and finishes the frame; ms_per_frame is the per-call latency")
+
+    feed = None
+    if rank == 0 and headline and not args.no_feed_rate:
+        try:
+            feed = real_data_feed_rate(device)
+        except Exception as e:
+            feed = {"error": repr(e)[:300]}
 
     if rank == 0:
         line = {
@@ -453,18 +574,20 @@ def main():
                                          "(engine.lookahead_items).  other_configs.reference_protocol_lookahead_1 is the same loop without "
                                          "reading ahead",
                        "parallelism": "videos sharded across ranks (one process per GPU, %s)"
-                                      % ("RCCL group of %d ranks: one gather of the predictions to rank 0" % dist.get_world_size()
-                                         if world > 1 else "single rank, no collective"),
+                                      % ("RCCL group of %d rank(s): one gather of the predictions to rank 0" % dist.get_world_size()
+                                         if grouped else "single rank, no collective"),
                        "ranks": world},
             "roofline": roofline,
+            "host_view": host_view,
             "host_fed": host_fed,
+            "real_data_feed": feed,
             "other_configs": others,
         }
         if world == 1 and headline and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, frames8, H, W)
             line["gpu_over_cpu"] = round(line["value"] / max(line["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -184,11 +184,12 @@ def unpack_predictions(ids, counts, dets, sizes):
     return out
 
 
-def gather_predictions(results, max_det=None, device=None):
+def gather_predictions(results, max_det=None, device=None, always=False):
     """Gather every rank's {image_id: BoxList} on rank 0 (returns None elsewhere).  The padded per-frame capacity is
-    the maximum detection count over all ranks (exchanged with the shard sizes) unless `max_det` forces a larger one."""
+    the maximum detection count over all ranks (exchanged with the shard sizes) unless `max_det` forces a larger one.
+    always=True runs the collectives even in a one-rank group (the RCCL path on a single GPU)."""
     world = comm.get_world_size()
-    if world == 1:
+    if world == 1 and not (always and dist.is_available() and dist.is_initialized()):
         return results
     dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
     n_local = torch.tensor([len(results), max_detections(results)], dtype=torch.int64, device=dev)

@@ -14,6 +14,7 @@ shape)` when set (parity/bench), else torch.randn on the device like the referen
 """
 import math
 import os
+import time
 from collections import deque
 
 import torch
@@ -165,6 +166,7 @@ class DiffusionDet(nn.Module):
         # True: a batch's detections come back with ONE device->host copy and the BoxLists hold CPU tensors
         # (what engine/inference.py does next anyway, there with ~3 copies per frame); False: GPU tensors
         self.results_on_host = False
+        self.host_wait_s = 0.0      # seconds this process spent blocked in the per-batch device->host result copy
         self.video_index = 0
         self.demo = False
 
@@ -596,10 +598,12 @@ class DiffusionDet(nn.Module):
 
     def _to_boxlists(self, ob, osc, ol, oc, size_wh):
         flat = getattr(ob, "_dvid_flat", None)
+        t0 = time.perf_counter()
         if self.results_on_host and flat is not None:
             n, cap = osc.shape
             ob, osc, ol, oc = ops.split_detection_buffer(flat.cpu(), n, cap)      # single D2H copy + sync
         counts = oc.tolist()                 # the one host sync of a batch (the caller moves results to CPU anyway)
+        self.host_wait_s += time.perf_counter() - t0          # the host blocked on the GPU: its slack (bench.py reports it per rank)
         self.head.check_boxes_valid()
         results = []
         for b, k in enumerate(counts):

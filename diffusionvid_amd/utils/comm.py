@@ -23,10 +23,11 @@ def synchronize():
         dist.barrier()
 
 
-def init_dist(backend=None):
-    """env:// rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK."""
+def init_dist(backend=None, force=False):
+    """env:// rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK.  A single process normally needs no
+    group; force=True builds a one-rank group anyway (the RCCL path exercised on one GPU: tests, bench.py --force-dist)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 or dist.is_initialized():
+    if (world <= 1 and not force) or dist.is_initialized():
         return
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"

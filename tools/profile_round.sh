@@ -1,30 +1,37 @@
 #!/bin/bash
 # Round profile on the GPU box: per-kernel time (rocprofv3 --kernel-trace --stats) and HBM traffic of the igemm kernel
 # (separate --pmc passes, MI355X_MICROARCH.md HBM section) for the bench.py workload.  Writes gpurun_out/<tag>_*.
-#   gpurun -- 'bash tools/profile_round.sh r01c'
+#   gpurun -- 'bash tools/profile_round.sh r03 [r101|swinb] [sample_step]'
+# The traffic file is per configuration: <tag>_pmc_igemm_traffic_<arch>_x<sample_step>.json (bench.py reads
+# profiles/r03_pmc_igemm_traffic_<arch>_x<ss>.json for the matching line only).
 TAG=${1:-r01}
+ARCH=${2:-r101}
+SS=${3:-1}
+SUF=${ARCH}_x${SS}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export DVID_CHAINS=1            # sequential launches: per-kernel durations are not inflated by overlap
-CMD="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-fed --no-side-configs"
+CMD="python $REPO/bench.py --arch $ARCH --sample-step $SS --steps 1 --warmup 1 --no-cpu-baseline --no-host-fed --no-side-configs --no-feed-rate"
 # tile-tuner timing launches would pollute the statistics: fill the tuning cache in an unprofiled run first
 export DVID_IGEMM_TUNE_CACHE=/tmp/dvid_tune_cache.txt
 rm -f $DVID_IGEMM_TUNE_CACHE
 $CMD > /tmp/prof_pre.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- $CMD > /tmp/prof_stats.log 2>&1
-grep '^{"metric"' /tmp/prof_stats.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
+rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- $CMD > /tmp/prof_stats.log 2>&1
+grep '^{"metric"' /tmp/prof_stats.log | tail -1 > $OUT/${TAG}_bench_under_rocprof_${SUF}.json
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  rm -rf /tmp/prof_$C
   timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -o pmc -- $CMD --warmup 0 > /tmp/prof_$C.log 2>&1
 done
-python - "$TAG" "$OUT" <<'PY'
+python - "$TAG" "$OUT" "$SUF" <<'PY'
 import csv, glob, json, sys
-tag, out = sys.argv[1], sys.argv[2]
+tag, out, suf = sys.argv[1], sys.argv[2], sys.argv[3]
 f = glob.glob("/tmp/prof_stats/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-with open(f"{out}/{tag}_kernel_stats.txt", "w") as o:
+with open(f"{out}/{tag}_kernel_stats_{suf}.txt", "w") as o:
+    o.write("# configuration " + suf + "\n")
     o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-fed --no-side-configs  (DVID_CHAINS=1; 5 videos of 304 frames:\n")
     o.write("# set-up, warm-up, timed step, chains=1 pass and instrumented pass)\n")
     o.write("total kernel time %.1f ms\n" % (tot / 1e6))
@@ -60,6 +67,7 @@ if res["FETCH_SIZE"][1] and res["WRITE_SIZE"][1]:
     write = res["WRITE_SIZE"][0] / res["WRITE_SIZE"][1] * 1024
     same = json.loads([l for l in open("/tmp/prof_FETCH_SIZE.log") if l.startswith('{"metric"')][-1])["roofline"]
     json.dump({"kernel": "implicit-GEMM kernels (igemm2_kernel + conv3x3_* + wstat*_kernel; all instantiations)", "launches": int(res["FETCH_SIZE"][1]),
+               "configuration": suf,
                "alg_bytes_per_launch_same_run": same["layerwise_alg_mbytes_per_launch"] * 1e6,
                "mfma_busy_fraction": mfma_busy,
                "mfma_busy_method": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs over sum(GRBM_GUI_ACTIVE) / 8 XCDs, implicit-GEMM launches only",
@@ -67,7 +75,7 @@ if res["FETCH_SIZE"][1] and res["WRITE_SIZE"][1]:
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 "
                          "--warmup 0 --no-cpu-baseline --no-host-fed --no-side-configs (the bench workload itself, 304-frame videos), DVID_CHAINS=1; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                          "(gfx950 counts 128-B requests at 64 B); WRITE_SIZE uncorrected", "round": int(tag[1:3]) if tag[1:3].isdigit() else None},
-              open(f"{out}/{tag}_pmc_igemm_traffic.json", "w"), indent=1)
+              open(f"{out}/{tag}_pmc_igemm_traffic_{suf}.json", "w"), indent=1)
 else:
-    open(f"{out}/{tag}_pmc_error.txt", "w").write(repr(res) + "\n" + open("/tmp/prof_FETCH_SIZE.log").read()[-3000:])
+    open(f"{out}/{tag}_pmc_error_{suf}.txt", "w").write(repr(res) + "\n" + open("/tmp/prof_FETCH_SIZE.log").read()[-3000:])
 PY
