@@ -867,7 +867,10 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
     // in flight the blocks of one chain's next kernel start on the CUs the other chain's tail leaves idle.  (A two-stream
     // front / back software pipeline of HBM-bound early layers beside MFMA-bound late ones measured no gain,
     // profiles/r02_backbone_pipeline_sweep.txt; it lives in the history of this file.)
-    const int nchain = (m->nchain > 1 && n >= 2 * m->nchain) ? m->nchain : 1;
+    // Small launch sequences stay on one stream: at 8 frames two 4-frame chains are slower than one 8-frame sequence (1250 vs 1273
+    // frames/s with the reference's one-batch-per-call protocol, 980 with four chains; profiles/r03c_chains_at_lookahead1.txt) --
+    // the layers are then bound by how few workgroups a launch has, and halving the rows halves them again.
+    const int nchain = (m->nchain > 1 && n >= 16 * m->nchain) ? m->nchain : 1;
     if (nchain > 1) TRY(m->ensure_streams());
     const int per = (n + nchain - 1) / nchain;
     const size_t px = (size_t)height * width, px4 = px / 16;

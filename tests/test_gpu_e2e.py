@@ -161,17 +161,27 @@ def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h,
     gbx_all = g_boxes.numpy().astype(np.float64)
     n_decided = n_open = n_dets = 0
     worst_s = worst_b = 0.0
-    # continuous part over every candidate either side holds: scores within tol_s, boxes within max(0.5 px, 1 %)
+
+    def g_inside_of(st, f):
+        return set(np.argsort(-sg[st, f], kind="stable")[:M].tolist())
+    # continuous part over every candidate either side holds: scores within tol_s, boxes within max(0.5 px, 1 %).  A box slot whose
+    # RoI sits on a pyramid-level or sample-validity threshold may flip discretely between the fp16 and the fp32 features (the
+    # stage checks allow 1 % of the boxes for that): such OUTLIER slots are counted, bounded by the same 1 %, and their candidates
+    # are excluded from the decided set -- but stay in the analysis as possible suppressors of others.
     in_topk = np.zeros_like(so, dtype=bool)
     for st in range(S):
         for f in range(n):
             in_topk[st, f, np.argsort(-so[st, f], kind="stable")[:M]] = True
             in_topk[st, f, np.argsort(-sg[st, f], kind="stable")[:M]] = True
-    d_s = float(np.abs(so - sg)[in_topk].max())
+    ds_box = np.abs(so - sg).reshape(S, n, M, C).max(-1)                       # per box slot: largest score difference over its classes
+    db_box = np.abs(ob - gbx_all).max(-1) / _box_eps(ob)
+    outlier = (ds_box > tol_s) | (db_box > 1.0)
     box_used = in_topk.reshape(S, n, M, C).any(-1)
-    d_b = float((np.abs(ob - gbx_all).max(-1) / _box_eps(ob))[box_used].max())
-    assert d_s <= tol_s, f"{tag}: candidate scores differ by {d_s:.2e} > {tol_s:.0e}"
-    assert d_b <= 1.0, f"{tag}: candidate boxes differ by {d_b:.2f} x max(0.5 px, 1 %)"
+    n_out = int((outlier & box_used).sum())
+    assert n_out <= 0.01 * max(1, int(box_used.sum())), f"{tag}: {n_out} of {int(box_used.sum())} candidate box slots differ beyond the stated tolerances"
+    ok_box = box_used & ~outlier
+    d_s = float(ds_box[ok_box].max())
+    d_b = float(db_box[ok_box].max())
     band_s = min(tol_s, band_factor * d_s + 1e-6)           # score band of the decision analysis
     band_b = min(1.0, band_factor * d_b + 1e-3)             # box band, as a fraction of max(0.5 px, 1 %)
     spec_tol_s, tol_s = tol_s, band_s
@@ -182,13 +192,18 @@ def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h,
             gap = 0.5 * (so[st, f][order[M - 1]] + so[st, f][order[M]])
             inside = set(order[:M].tolist())
             close = np.nonzero(np.abs(so[st, f] - gap) <= tol_s)[0].tolist()
-            for k in set(close) | inside:
+            wild = set(np.nonzero(np.repeat(outlier[st, f], C))[0].tolist())       # every class of an outlier box slot
+            # an outlier candidate entering / leaving one side's top-k moves that side's boundary by one rank: the ranks next to
+            # the boundary, as many as there are outlier candidates in either top-k, are boundary candidates too
+            nw = len(wild & (inside | g_inside_of(st, f)))
+            close = sorted(set(close) | set(order[max(0, M - nw):M + nw].tolist()))
+            for k in set(close) | inside | (wild & g_inside_of(st, f)):
                 keys.append((st, k))
-                if k in close:
+                if k in close or k in wild:
                     near.add((st, k))
             # the GPU path's own top-k set may differ from the oracle's only by boundary candidates
             g_inside = set(np.argsort(-sg[st, f], kind="stable")[:M].tolist())
-            assert (g_inside ^ inside) <= set(close), f"{tag} frame {f} step {st}: top-{M} sets differ beyond the score tolerance: {sorted((g_inside ^ inside) - set(close))[:8]}"
+            assert (g_inside ^ inside) <= (set(close) | wild), f"{tag} frame {f} step {st}: top-{M} sets differ beyond the score tolerance: {sorted((g_inside ^ inside) - set(close) - wild)[:8]}"
         keys.sort(key=lambda k: -so[k[0], f][k[1]])
         score = {k: float(so[k[0], f][k[1]]) for k in keys}
         box = {k: ob[k[0], f, k[1] // C] for k in keys}
@@ -246,8 +261,8 @@ def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h,
             raise AssertionError(f"{tag} frame {f}: GPU keeps (step {k[0]}, box {k[1] // C}, class {k[1] % C + 1}), which is outside the oracle's top-{M} beyond the score tolerance")
         n_decided += sum(1 for v in status.values() if v != "open")
         n_open += sum(1 for v in status.values() if v == "open")
-    line = (f"{tag} threshold-aware detection sets: all candidates within the stated tolerances (max |dscore| = {d_s:.2e} <= {spec_tol_s:.0e}, max box "
-            f"difference = {d_b:.2f} x max(0.5 px, 1 %)); decision bands {band_factor:g} x observed = {band_s:.2e} on scores, {band_b:.2f} x the box "
+    line = (f"{tag} threshold-aware detection sets: candidates within the stated tolerances (max |dscore| = {d_s:.2e} <= {spec_tol_s:.0e}, max box "
+            f"difference = {d_b:.2f} x max(0.5 px, 1 %); {n_out} of {int(box_used.sum())} box slots flipped discretely and are excluded); decision bands {band_factor:g} x observed = {band_s:.2e} on scores, {band_b:.2f} x the box "
             f"tolerance: {n_decided} candidates decided beyond the bands (all agree with the {n_dets} GPU detections), "
             f"{n_open} excluded as within a band of the top-{M} / IoU {iou_thr} thresholds ({n_open / max(1, n_open + n_decided):.1%}); "
             f"kept pairs: max |dscore| = {worst_s:.2e}, max box error / bound = {worst_b:.2f}")

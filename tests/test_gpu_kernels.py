@@ -257,8 +257,9 @@ def test_head_kernels_against_full_dimension_reference_fixture(dv):
     dimensions (256 / 8 / 2048 / 64, 300 boxes), no oracle in between: tests/golden/g16_full_dim_head.npz holds inputs and
     outputs of the reference modules run on synthetic.make_head_state_dict(0) with fp16-representable matrices
     (make_golden.py: g16_full_dim_head; box_head.py:495-548, :605-664, :687-711).  What separates the two sides is fp16
-    storage of the activations between ~12 chained layers and the fp32 summation order: the bounds are those of
-    test_rcnn_head (2e-2 of the LayerNorm-ed O(1) values; boxes relative to the box size)."""
+    storage of the activations between ~12 chained layers and the fp32 summation order.  Measured: object features within
+    3.4e-3 (LayerNorm-ed O(1) values), logits within 1.9e-3, DynamicConv within 2e-3; bounds 6e-3 / 2e-3 of RMS + relative, boxes
+    1 % of the box size."""
     from conftest import golden
     from diffusionvid_amd.utils import synthetic
     z = golden("g16_full_dim_head")
@@ -275,7 +276,7 @@ def test_head_kernels_against_full_dimension_reference_fixture(dv):
         bw = (inp[..., 2:] - inp[..., :2]).clamp(min=1.0).max(-1).values
         err = ((got.cpu() - want).abs().max(-1).values / bw).max().item()
         print(f"{tag}: boxes rel-to-size err max={err:.3e}")
-        assert err < 3e-2, tag
+        assert err < 1e-2, tag
 
     stages = (("head_series.0", 0, False, "boxes", None, "0"), ("head_series.1", 1, False, "bx0", "of0", "1"),
               ("head_series_cond.0", 0, True, "bx1", "of1", "2"))
@@ -283,8 +284,8 @@ def test_head_kernels_against_full_dimension_reference_fixture(dv):
         bin_ = T32(kb)
         pro = None if kf is None else T32(kf)[0].cuda()
         gl, gb, go = model.rcnn_head(idx, fd, H, W, bin_.cuda(), pro, t, cond=T32("cond").cuda() if is_cond else None, bad_flag=flag)
-        check(f"reference_fixture[{name}].obj_features", go, T32("of" + o)[0], 2e-2, 2e-2)
-        check(f"reference_fixture[{name}].logits", gl, T32("cl" + o), 2e-2, 2e-2)
+        check(f"reference_fixture[{name}].obj_features", go, T32("of" + o)[0], 6e-3, 6e-3)
+        check(f"reference_fixture[{name}].logits", gl, T32("cl" + o), 2e-3, 2e-3)
         boxes_close(f"reference_fixture[{name}]", gb, T32("bx" + o), bin_)
     assert int(flag.item()) == 0
     model.close()
