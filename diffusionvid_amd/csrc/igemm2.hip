@@ -550,6 +550,10 @@ const TileCfg kCfgs[] = {
     {128, 256, 32, 3, &launch2<128, 256, 32, 3, false, 2>}, {128, 256, 64, 2, &launch2<128, 256, 64, 2, false, 2>},
     // nstage 5: the anti-phase schedule over a 4-stage ring (see igemm2_kernel)
     {256, 256, 32, 5, &launch2<256, 256, 32, 5, false, 4>},
+    // small tiles with deep rings for the launches of a one-batch call (8 frames: res4 has 19456 rows): many workgroups per CU, three
+    // K tiles in flight each, instead of one or two workgroups per CU waiting on a 2-stage ring
+    {64, 64, 32, 4, &launch2<64, 64, 32, 4, false>},        {64, 128, 32, 4, &launch2<64, 128, 32, 4, false>},
+    {64, 64, 64, 3, &launch2<64, 64, 64, 3, false>},
     // Register-staged operands (global -> VGPR -> ds_write_b128, plain and inside the anti-phase schedule; in this file's history,
     // profiles/r02_igemm_register_staging.txt) lose to the DMA ring and the anti-phase DMA schedule on every 104-frame shape (188 /
     // 181 vs 180 / 166 us on 252928 x 256 x 1024).  So do 4-wave 256x256 tiles (128x128 per wave, 256 accumulator AGPRs, one wave per SIMD -- the vendor library's shape,

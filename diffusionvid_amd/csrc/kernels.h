@@ -78,6 +78,44 @@ int dvid_patch_merge_ln_launch(const float* x, const float* g, const float* b, h
 int dvid_dynconv_launch(const half_t* roi, const half_t* params, const float* g1, const float* b1, const float* g2,
                         const float* b2, half_t* out, int rows, hipStream_t s);
 
+// headtail.hip: FFN + norm3 + modulation + cls / reg towers + class_logits + bboxes_delta + apply_deltas of one RCNNHead pass as one
+// row-tile kernel.  Every `*f` weight is in MFMA fragment order (model.hip: make_frags): [n-tile of 32 rows][K step of 16][lane][8].
+struct HeadTailParams {
+    const half_t* x16;          // [R, 256] fp16   norm2 output (operand of linear1)
+    const float* obj32;         // [R, 256] fp32   the same rows, the FFN's residual
+    const half_t* w1f;          // linear1 [dff][256]
+    const float* b1;
+    const half_t* w2f;          // linear2 [256][dff]
+    const float* b2;
+    const float* n3g;           // norm3
+    const float* n3b;
+    const float* scale;         // block_time_mlp rows: scale (and, plain head, shift at + 256) of frame f at scale + f * ss_stride
+    int ss_stride, rows_per_frame;
+    const float* cond32;        // [R, 256] fp32 or null (RCNNHead_cond: shift = c_mlp(SiLU(cond)))
+    const half_t* wcf;          // c_mlp.1 [256][256]
+    const float* bc;
+    int num_cls, num_reg, num_classes, dff;
+    const half_t* clsf[4];
+    const float* clsg[4];
+    const float* clsb[4];
+    const half_t* regf[4];
+    const float* regg[4];
+    const float* regb[4];
+    const half_t* wlogf;        // class_logits, rows zero-padded to a multiple of 32
+    const float* blog;
+    const half_t* wdelf;        // bboxes_delta, 4 rows zero-padded to 32
+    const float* bdel;
+    const float* boxes;         // [R, 4] input boxes
+    float* obj_out;             // [R, 256] fp32 obj_features
+    float* logits;              // [R, num_classes]
+    float* boxes_out;           // [R, 4]
+    int* bad_flag;
+    long R;
+    float wx, wy, ww, wh, clamp;
+};
+bool dvid_head_tail_supported(int hidden, int dff, int num_cls, int num_reg, int num_classes);
+int dvid_head_tail_launch(const HeadTailParams& p, hipStream_t s);
+
 // boxes.hip
 int dvid_apply_deltas_launch(const float* deltas, int delta_ld, const float* boxes, float* out, int n, float wx, float wy, float ww,
                              float wh, float clamp, int* bad_flag, hipStream_t s);

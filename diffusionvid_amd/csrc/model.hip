@@ -129,6 +129,13 @@ struct ConvW {   // conv or linear weights in MFMA-operand layout
     bool same_size = false;    // output spatial size = input size whatever (kh, pad) say (the space-to-depth stem: pad 2 before, 1 after)
     int alg_k = 0;             // algorithmic K for the FLOP count when the packed layout carries structural zeros (0: kh*kw*cin_real)
 };
+// fragment-order copies of the head-tail weights (csrc/headtail.hip)
+struct HeadFrags {
+    half_t *w1 = nullptr, *w2 = nullptr, *wc = nullptr, *wlog = nullptr, *wdel = nullptr;
+    half_t* cls[4] = {nullptr, nullptr, nullptr, nullptr};
+    half_t* reg[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = false;
+};
 struct LNW {
     float* g = nullptr;
     float* b = nullptr;
@@ -143,6 +150,7 @@ struct HeadW {
     std::vector<float> bt_w, bt_b;
     int bt_out = 0;
     bool cond = false;
+    HeadFrags frag;
 };
 struct Block {
     ConvW c1, c2, c3, sc;
@@ -365,6 +373,25 @@ int make_ln(dvid_model* m, const std::string& name, LNW* out) {
     return DVID_OK;
 }
 
+// [cout][kpad] (K contiguous, on the device) -> MFMA fragment order for v_mfma_f32_32x32x16_f16 with the weights as first operand:
+// block (n-tile of 32 rows, K step of 16) = 64 lanes x 8 halves, lane l = row (l & 31), k = 8 (l >> 5) .. + 8 -- one contiguous
+// 1-KiB wave load per fragment (csrc/headtail.hip).  Rows are zero-padded to a whole number of tiles.
+int make_frags(dvid_model* m, const ConvW& w, half_t** out) {
+    if (w.kh != 1 || w.kw != 1 || w.kpad % 16) FAIL(DVID_ERR_UNSUPPORTED, "fragment order needs a 1x1 layer with K %% 16 == 0");
+    const int ntile = (w.cout + 31) / 32, ks_n = w.kpad / 16;
+    std::vector<half_t> src((size_t)w.cout * w.kpad), dst((size_t)ntile * 32 * w.kpad, f2h(0.f));
+    HIP_TRY(hipMemcpy(src.data(), w.w, src.size() * sizeof(half_t), hipMemcpyDeviceToHost));
+    for (int nt = 0; nt < ntile; ++nt)
+        for (int ks = 0; ks < ks_n; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                const int row = nt * 32 + (l & 31);
+                if (row >= w.cout) continue;
+                for (int e = 0; e < 8; ++e)
+                    dst[(((size_t)nt * ks_n + ks) * 64 + l) * 8 + e] = src[(size_t)row * w.kpad + ks * 16 + (l >> 5) * 8 + e];
+            }
+    return m->upload(dst.data(), dst.size() * sizeof(half_t), reinterpret_cast<void**>(out));
+}
+
 int make_head(dvid_model* m, const std::string& pfx, bool cond, HeadW* h) {
     const dvid_config& c = m->cfg;
     const int d = c.hidden_dim, dd = c.dim_dynamic;
@@ -409,6 +436,16 @@ int make_head(dvid_model* m, const std::string& pfx, bool cond, HeadW* h) {
     h->bt_out = (int)btw->shape[0];
     if (h->bt_out != (cond ? d : 2 * d)) FAIL(DVID_ERR_ARG, "%s.block_time_mlp.1: unexpected out dim %d", pfx.c_str(), h->bt_out);
     if (cond) TRY(make_linear(m, pfx + ".c_mlp.1", true, &h->c_mlp));
+    if (dvid_head_tail_supported(d, c.dim_feedforward, c.num_cls, c.num_reg, c.num_classes)) {
+        TRY(make_frags(m, h->linear1, &h->frag.w1));
+        TRY(make_frags(m, h->linear2, &h->frag.w2));
+        if (cond) TRY(make_frags(m, h->c_mlp, &h->frag.wc));
+        for (int i = 0; i < c.num_cls; ++i) TRY(make_frags(m, h->cls[i], &h->frag.cls[i]));
+        for (int i = 0; i < c.num_reg; ++i) TRY(make_frags(m, h->reg[i], &h->frag.reg[i]));
+        TRY(make_frags(m, h->class_logits, &h->frag.wlog));
+        TRY(make_frags(m, h->bboxes_delta, &h->frag.wdel));
+        h->frag.ok = true;
+    }
     return DVID_OK;
 }
 
@@ -537,6 +574,57 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
     }
     float* obj = f32d;
     TRY(dvid_add_layernorm_launch(x1, f32b, hw.norm2.g, hw.norm2.b, obj, h16a, R, d, 0, s));
+    // --- FFN + norm3 + modulation + towers + class_logits + bboxes_delta + apply_deltas: one row-tile kernel (csrc/headtail.hip);
+    // DVID_HEAD_TAIL=0 (A/B measurements) or an unsupported shape takes the layer-by-layer launches below
+    static const bool tail_env = !(getenv("DVID_HEAD_TAIL") && atoi(getenv("DVID_HEAD_TAIL")) == 0);
+    if (tail_env && hw.frag.ok) {
+        HeadTailParams q;
+        memset(&q, 0, sizeof(q));
+        q.x16 = h16a;
+        q.obj32 = obj;
+        q.w1f = hw.frag.w1;
+        q.b1 = hw.linear1.bias;
+        q.w2f = hw.frag.w2;
+        q.b2 = hw.linear2.bias;
+        q.n3g = hw.norm3.g;
+        q.n3b = hw.norm3.b;
+        q.scale = ss_dev;
+        q.ss_stride = ss_stride;
+        q.rows_per_frame = M;
+        q.cond32 = is_cond ? cond : nullptr;
+        q.wcf = hw.frag.wc;
+        q.bc = hw.c_mlp.bias;
+        q.num_cls = (int)hw.cls.size();
+        q.num_reg = (int)hw.reg.size();
+        q.num_classes = m->cfg.num_classes;
+        q.dff = m->cfg.dim_feedforward;
+        for (size_t i = 0; i < hw.cls.size(); ++i) {
+            q.clsf[i] = hw.frag.cls[i];
+            q.clsg[i] = hw.cls_ln[i].g;
+            q.clsb[i] = hw.cls_ln[i].b;
+        }
+        for (size_t i = 0; i < hw.reg.size(); ++i) {
+            q.regf[i] = hw.frag.reg[i];
+            q.regg[i] = hw.reg_ln[i].g;
+            q.regb[i] = hw.reg_ln[i].b;
+        }
+        q.wlogf = hw.frag.wlog;
+        q.blog = hw.class_logits.bias;
+        q.wdelf = hw.frag.wdel;
+        q.bdel = hw.bboxes_delta.bias;
+        q.boxes = boxes;
+        q.obj_out = obj_features;
+        q.logits = logits;
+        q.boxes_out = boxes_out;
+        q.bad_flag = bad_box_flag;
+        q.R = R;
+        q.wx = 2.f;
+        q.wy = 2.f;
+        q.ww = 1.f;
+        q.wh = 1.f;
+        q.clamp = logf(100000.f / 16.f);
+        return dvid_head_tail_launch(q, s);
+    }
     // --- FFN + norm3 ---
     TRY(linear_run(hw.linear1, h16a, R, hid16, 1, 0, s));
     TRY(linear_run(hw.linear2, hid16, R, f32b, 0, 1, s));

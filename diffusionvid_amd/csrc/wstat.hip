@@ -71,9 +71,11 @@ struct WsSmem {
 
 // K: reduction length (= Cin = Kpad); D: ring depth (tiles t + 1 .. t + D - 1 in flight while tile t is computed); TN: 32-channel
 // accumulator tiles per wave (a workgroup owns 256 TN channels; the TN chains of a wave share every A fragment read and the A tile's
-// DMA serves TN times the outputs); HAS_RES: same-shape fp16 residual; RELU.  Grid: 256 workgroups x 512 threads.  M % 32 == 0.
-template <int K, int D, int TN, bool HAS_RES, bool RELU>
+// DMA serves TN times the outputs); HAS_RES: same-shape fp16 residual; ACT: 0 none, 1 ReLU, 2 exact GELU (Swin's fc1, no residual: the
+// pair form gelu_erf2 of the igemm2 epilogue on the same fp32 sums, so the same bits).  Grid: 256 workgroups x 512 threads.  M % 32 == 0.
+template <int K, int D, int TN, bool HAS_RES, int ACT>
 __global__ __launch_bounds__(512) void wstat_kernel(IgemmParams p, int nslab) {
+    constexpr bool RELU = ACT == 1;
     constexpr int NW = 8, WPX = 32;
     constexpr int SLAB = 256 * TN;                // output channels per workgroup
     constexpr int CH = K / 8;                     // 16-byte chunks per A row
@@ -234,6 +236,12 @@ __global__ __launch_bounds__(512) void wstat_kernel(IgemmParams p, int nslab) {
                     if (HAS_RES) {
                         const half8 rv = *reinterpret_cast<const half8*>(stg + A_TILE + ((wave * TN + j) * 2 + g) * 1024 + lane * 16);
                         ws_add_res8(lo, hv, rv);
+                    }
+                    if (ACT == 2) {
+                        const float2v g0 = gelu_erf2((float2v){lo[0], lo[1]}), g1 = gelu_erf2((float2v){lo[2], lo[3]});
+                        const float2v g2 = gelu_erf2((float2v){hv[0], hv[1]}), g3 = gelu_erf2((float2v){hv[2], hv[3]});
+                        lo = (float4v){g0[0], g0[1], g1[0], g1[1]};
+                        hv = (float4v){g2[0], g2[1], g3[0], g3[1]};
                     }
                     const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
                     half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -468,7 +476,7 @@ int ws2_launch_v(const IgemmParams& p, hipStream_t s) {
     return relu ? ws2_launch_k<K, D, false, true>(p, s) : ws2_launch_k<K, D, false, false>(p, s);
 }
 
-template <int K, int D, int TN, bool HAS_RES, bool RELU>
+template <int K, int D, int TN, bool HAS_RES, int RELU>
 int ws_launch_k(const IgemmParams& p, hipStream_t s) {
     constexpr int smem = WsSmem<K, D, TN, HAS_RES>::kBytes;
     static_assert(smem <= 160 * 1024, "LDS");
@@ -486,10 +494,11 @@ template <int K, int D, int TN>
 int ws_launch_v(const IgemmParams& p, hipStream_t s) {
     const bool res = p.res_mode == 1, relu = p.relu == 1;
     if constexpr (TN == 1) {          // (64 channels per wave + a residual ring does not fit the LDS; those layers take the row-coalesced kernel anyway)
-        if (res) return relu ? ws_launch_k<K, D, TN, true, true>(p, s) : ws_launch_k<K, D, TN, true, false>(p, s);
+        if (res) return relu ? ws_launch_k<K, D, TN, true, 1>(p, s) : ws_launch_k<K, D, TN, true, 0>(p, s);
     }
     if (res) return DVID_ERR_UNSUPPORTED;
-    return relu ? ws_launch_k<K, D, TN, false, true>(p, s) : ws_launch_k<K, D, TN, false, false>(p, s);
+    if (p.relu == 2) return ws_launch_k<K, D, TN, false, 2>(p, s);
+    return relu ? ws_launch_k<K, D, TN, false, 1>(p, s) : ws_launch_k<K, D, TN, false, 0>(p, s);
 }
 
 }  // namespace
@@ -502,18 +511,23 @@ bool dvid_wstat_supported(const IgemmParams& p) {
     if (p.Cout % 256) return false;
     const int ns = p.Cout / 256;
     if (!(ns <= 32 ? 32 % ns == 0 : ns % 32 == 0)) return false;
-    if (p.out_f32 || p.splitk > 1 || p.relu > 1 || (p.ldc & 7)) return false;
+    if (p.out_f32 || p.splitk > 1 || p.relu > 2 || (p.ldc & 7)) return false;
     if (p.res_mode > 1 || (p.res_mode == 1 && p.res_f32)) return false;
+    if (p.relu == 2 && p.res_mode) return false;          // exact GELU: Swin's fc1, no residual
     return true;
 }
 
-// ... and the launch is large enough for the persistent workgroups: each streams at least 24 row blocks per weight load
+// ... and the launch is large enough for the persistent workgroups: each streams at least kMinBlocks row blocks per weight load.
+// (24 until round 3; the 8-frame launches of a one-batch call -- res4 conv3: 9 blocks per workgroup, dynamic_layer: 9 -- run faster
+// here than on igemm2's small tiles: 1311 vs 1264 frames/s with every supported launch forced onto this kernel,
+// profiles/r03_lookahead1_ab.txt.  DVID_WSTAT_MIN overrides.)
 bool dvid_wstat_preferred(const IgemmParams& p) {
     if (!dvid_wstat_supported(p)) return false;
+    static const int kMinBlocks = getenv("DVID_WSTAT_MIN") ? atoi(getenv("DVID_WSTAT_MIN")) : 8;
     const int ns = p.Cout / 256;
     const long blocks_per_xcd = ((long)p.M + 31) / 32 / 8;
     const long per_wg = ns <= 32 ? blocks_per_xcd / (32 / ns) : blocks_per_xcd;
-    return per_wg >= 24;
+    return per_wg >= kMinBlocks;
 }
 
 static int wstat_launch_rows32(const IgemmParams& p, hipStream_t s);

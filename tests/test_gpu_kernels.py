@@ -303,6 +303,46 @@ def test_head_kernels_against_full_dimension_reference_fixture(dv):
     check("reference_fixture[dynconv]", out, T32("dc_mid"), 4e-3, 4e-3)
 
 
+@pytest.mark.parametrize("cond,n", [(False, 1), (True, 3), (False, 60)])
+def test_head_tail_fused_matches_layerwise(dv, tmp_path, cond, n):
+    """csrc/headtail.hip (FFN + norm3 + modulation + towers + class_logits + bboxes_delta + apply_deltas in one row-tile kernel)
+    against the layer-by-layer launches it replaces, which a child process with DVID_HEAD_TAIL=0 runs on the same inputs: the
+    same fp16 operands and fp32 statistics in another summation order, so logits / object features agree to rounding (3e-3 of
+    the O(1) values) and boxes to 5e-3 of their size.  300 rows (32-row tiles, ragged last tile), 900 rows, 18000 rows (64-row tiles)."""
+    import subprocess
+    import sys
+    sd, _ = _head_setup()
+    g = torch.Generator().manual_seed(80 + n)
+    M, H, W = 300, 96, 160
+    feats = [f * 0.5 for f in _pyramid(g, n, H, W)]
+    boxes = _boxes(g, n, M, H, W)
+    boxes[0, 0] = torch.tensor([10.0, 10.0, 14.0, 13.0])
+    pro = torch.randn(n * M, 256, generator=g)
+    cnd = torch.randn(n * M, 256, generator=g) if cond else None
+    t = torch.full((n,), 499, dtype=torch.long)
+    torch.save({"feats": feats, "boxes": boxes, "pro": pro, "cnd": cnd, "t": t, "n": n, "M": M, "H": H, "W": W, "cond": cond}, tmp_path / "in.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r); from diffusionvid_amd import ops; from diffusionvid_amd.utils import synthetic; "
+            "d = torch.load(%r); m = ops.Model(synthetic.make_head_state_dict(0), res_blocks=(0, 0, 0, 0)); m.reserve(d['n'], d['H'], d['W'], d['M']); "
+            "fd = [ops.nhwc_from_nchw(f.cuda()) for f in d['feats']]; "
+            "o = m.rcnn_head(0 if d['cond'] else 1, fd, d['H'], d['W'], d['boxes'].cuda(), d['pro'].cuda(), d['t'], cond=None if d['cnd'] is None else d['cnd'].cuda()); "
+            "torch.save([x.cpu() for x in o], %r)" % (root, str(tmp_path / "in.pt"), str(tmp_path / "out.pt")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, DVID_HEAD_TAIL="0"), timeout=900)
+    ll, lb, lo = torch.load(tmp_path / "out.pt")
+    model = dv.Model(sd, res_blocks=(0, 0, 0, 0))
+    model.reserve(n, H, W, M)
+    fd = [dv.nhwc_from_nchw(f.cuda()) for f in feats]
+    gl, gb, go = model.rcnn_head(0 if cond else 1, fd, H, W, boxes.cuda(), pro.cuda(), t, cond=None if cnd is None else cnd.cuda())
+    tag = f"head_tail[{'cond' if cond else 'plain'},{n}]"
+    check(tag + ".obj_features", go, lo, 3e-3, 3e-3)
+    check(tag + ".logits", gl, ll, 3e-3, 3e-3)
+    bw = (boxes[..., 2:] - boxes[..., :2]).clamp(min=1.0).max(-1).values
+    err = ((gb.cpu() - lb).abs().max(-1).values / bw).max().item()
+    print(f"{tag}.boxes rel-to-size err max={err:.3e}")
+    assert err < 5e-3          # exp(dw) on boxes near the clamp amplifies a 1e-3 delta difference (measured 2.3e-3)
+    model.close()
+
+
 def test_global_xattn(dv):
     sd, sdo = _head_setup()
     g = torch.Generator().manual_seed(9)
@@ -405,6 +445,25 @@ def test_postproc_x1_exact(dv):
         np.testing.assert_array_equal(ob[b, :k].cpu().numpy(), ref[b]["boxes"])          # selection + clip: exact
         np.testing.assert_allclose(osc[b, :k].cpu().numpy(), ref[b]["scores"], rtol=0, atol=2e-7)
     assert 5 < int(oc.min()) and int(oc.max()) < M      # NMS really suppressed something
+
+
+@pytest.mark.parametrize("levels,M", [(7, 300), (1, 300), (40, 100), (5000, 500)])
+def test_topk_select_with_ties_exact(dv, levels, M):
+    """The radix-select top-k (csrc/postproc.hip: topk_select_kernel) on logits quantised to a few levels: hundreds of exact score
+    ties straddle the top-M boundary (levels = 1: every score equal), which must resolve by ascending flat index exactly as the
+    oracle's stable sort (and the full bitonic sort this kernel replaces) does.  Use NMS off so that the candidate list itself is
+    what is compared."""
+    g = torch.Generator().manual_seed(200 + levels)
+    n, C = 3, 30
+    logits = (torch.randint(0, levels, (n, M, C), generator=g).float() - levels / 2) * (6.0 / max(levels, 2))
+    boxes = _cluster_boxes(g, n, M)
+    ob, osc, ol, oc = dv.postproc_topk_nms(logits.cuda(), boxes.cuda(), 1000.0, 600.0, use_nms=False)
+    for b in range(n):
+        rb, rs, rl, _ = opost.topk_candidates(logits[b], boxes[b], C)
+        assert int(oc[b]) == M
+        np.testing.assert_array_equal(ol[b, :M].cpu().numpy(), rl)
+        np.testing.assert_array_equal(ob[b, :M].cpu().numpy(), opost.clip_to_image(rb, (1000, 600)))
+        np.testing.assert_allclose(osc[b, :M].cpu().numpy(), rs, rtol=0, atol=2e-7)
 
 
 def test_postproc_ensemble_exact(dv):
@@ -713,7 +772,8 @@ def test_conv4x4_s2d_stem_kernel(dv, shape):
 
 @pytest.mark.parametrize("shape", [(8 * 32 * 40 + 13, 256, 1024, True, True), (5000, 128, 512, True, True), (70001, 256, 2048, False, True),
                                    (3000, 256, 8192, False, False), (2400, 256, 32768, False, False), (31, 256, 256, True, False),
-                                   (9000, 128, 256, True, True), (40000, 256, 256, False, True)])
+                                   (9000, 128, 256, True, True), (40000, 256, 256, False, True),
+                                   (38912 + 5, 128, 512, False, 2), (9728, 256, 1024, False, 2)])          # Swin-B fc1 of stages 1 / 2: exact GELU
 def test_wstat_matches_igemm2(dv, shape):
     """csrc/wstat.hip (weights stationary in registers, rows streamed through a DMA ring, epilogue from the accumulator layout)
     against torch on the same fp16-rounded operands and against igemm2 on the same launch -- bit for bit: same MFMA, same K
@@ -731,7 +791,7 @@ def test_wstat_matches_igemm2(dv, shape):
     if res:
         ref = ref + r
     if relu:
-        ref = F.relu(ref)
+        ref = F.gelu(ref) if relu == 2 else F.relu(ref)
     wp, kpad = dv.pack_conv_weight(wt)
     xd = x.to(torch.float16).cuda().view(m, 1, 1, k)
     rd = r.to(torch.float16).cuda().view(m, 1, 1, n) if res else None
