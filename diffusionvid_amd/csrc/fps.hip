@@ -5,6 +5,8 @@
 // distance row of the last pick streams from L2.  Ties are resolved exactly as the reference
 // CUDA kernel does for its block size `bs` (largest power of two <= n, capped at 1024): the
 // candidate with the smallest (bitreverse(k % bs), k / bs) wins -- see oracle/memory.py.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -110,6 +112,60 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ dis
     }
 }
 
+// The same greedy sweep with the running distances in registers (EPT points per thread, 256 threads) and the winner's index decoded
+// from the winning key itself -- prio = bitrev(k % bs) * pmul + k / bs is invertible -- so a step is one row read, one wave
+// reduction, ONE barrier (winner slots double-buffered) instead of two barriers and an owner search through LDS.  Same keys, same
+// maximum: the same picks as fps_kernel (tests/test_gpu_kernels.py compares both with the thread-level emulation of fps.cu).
+template <int EPT>
+__global__ __launch_bounds__(256) void fps_reg_kernel(const float* __restrict__ dist, int n, int m, int bs, int bs_bits,
+                                                       int* __restrict__ idx) {
+    __shared__ u64 wbest[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned pmul = (unsigned)(n / bs + 2);
+    float temp[EPT];
+    unsigned pinv[EPT];
+    int kc[EPT];                             // column of this lane's e-th point; past the end: the last column, result unused
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const unsigned k = (unsigned)(tid + 256 * e);
+        temp[e] = 1e10f;
+        pinv[e] = 0xFFFFFFFFu - (bitrev_n(k & (bs - 1), bs_bits) * pmul + k / bs);
+        kc[e] = (int)k < n ? (int)k : n - 1;
+    }
+    if (tid == 0) idx[0] = 0;
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        const float* row = dist + (long)old * n;
+        u64 best = 0;
+        float v[EPT];
+        // every load of the step is in flight before the first is used (loads under per-point exec masks are issued and waited for one
+        // after the other: 8 dependent memory latencies per step, 6.7 ms for 1800 -> 900 against 3.6 with the LDS kernel)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) v[e] = row[kc[e]];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const float d2 = fminf(v[e], temp[e]);
+            temp[e] = d2;
+            const u64 key = tid + 256 * e < n ? (((u64)__float_as_uint(d2) << 32) | pinv[e]) : 0ull;          // d2 >= 0
+            best = key > best ? key : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u64 other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        if (lane == 0) wbest[j & 1][wave] = best;
+        __syncthreads();
+        u64 b = wbest[j & 1][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) b = wbest[j & 1][w] > b ? wbest[j & 1][w] : b;
+        const unsigned prio = 0xFFFFFFFFu - (unsigned)b;
+        const unsigned br = prio / pmul, q = prio - br * pmul;
+        old = (int)(q * (unsigned)bs + bitrev_n(br, bs_bits));
+        if (tid == 0) idx[j] = old;
+    }
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ idx, float* __restrict__ y, int m, int d) {
     const int dv = d >> 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -138,6 +194,15 @@ int dvid_fps_launch(const float* dist, int n, int m, int bs_emul, int* idx, hipS
     int bits = 0;
     while ((1 << bits) < bs) ++bits;
     if ((1 << bits) != bs) return DVID_ERR_ARG;
+    static const bool lds_form = getenv("DVID_FPS_LDS") && atoi(getenv("DVID_FPS_LDS")) != 0;          // A/B: the round-1 kernel
+    if (!lds_form && n <= 256 * 16) {
+        const int ept = (n + 255) / 256;
+        if (ept <= 4) hipLaunchKernelGGL(fps_reg_kernel<4>, dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
+        else if (ept <= 8) hipLaunchKernelGGL(fps_reg_kernel<8>, dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
+        else hipLaunchKernelGGL(fps_reg_kernel<16>, dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
+        LAUNCH_CHECK();
+        return DVID_OK;
+    }
     const size_t smem = (size_t)n * 4;
     static bool attr = false;
     if (!attr) {

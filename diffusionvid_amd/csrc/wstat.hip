@@ -514,6 +514,8 @@ bool dvid_wstat_supported(const IgemmParams& p) {
     if (p.out_f32 || p.splitk > 1 || p.relu > 2 || (p.ldc & 7)) return false;
     if (p.res_mode > 1 || (p.res_mode == 1 && p.res_f32)) return false;
     if (p.relu == 2 && p.res_mode) return false;          // exact GELU: Swin's fc1, no residual
+    static const bool gelu_ok = !(getenv("DVID_WSTAT_GELU") && atoi(getenv("DVID_WSTAT_GELU")) == 0);          // A/B switch
+    if (p.relu == 2 && !gelu_ok) return false;
     return true;
 }
 

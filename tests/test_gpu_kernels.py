@@ -519,6 +519,10 @@ def test_cdist_fps_gather(dv):
     rng = np.random.RandomState(0)
     Dt = torch.from_numpy(rng.randint(0, 4, size=(600, 600)).astype(np.float32))
     np.testing.assert_array_equal(dv.fps_greedy(Dt.cuda(), 150).cpu().numpy(), omem.fps_kernel_order(Dt.numpy(), 150))
+    # the sizes of the streaming mode (900 + 75 -> 900, 150 + 25 -> 150), a size beyond 2048 points, tie-heavy and not
+    for n, m, ties in ((975, 900, False), (175, 150, True), (3000, 40, True), (975, 900, True)):
+        Dn = torch.from_numpy(rng.randint(0, 5, size=(n, n)).astype(np.float32)) if ties else torch.cdist(x[:n], x[:n], p=2.0)
+        np.testing.assert_array_equal(dv.fps_greedy(Dn.cuda(), m).cpu().numpy(), omem.fps_kernel_order(Dn.numpy(), m))
 
 
 def test_backbone_small(dv):
@@ -807,3 +811,4 @@ def test_wstat_matches_igemm2(dv, shape):
     same = (got == base).float().mean().item()
     print("wstat vs igemm2: identical %.6f, max |diff| %.3e" % (same, (got.float() - base.float()).abs().max().item()))
     assert torch.equal(got, base)
+
