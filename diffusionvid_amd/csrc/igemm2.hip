@@ -554,10 +554,8 @@ const TileCfg kCfgs[] = {
     // K tiles in flight each, instead of one or two workgroups per CU waiting on a 2-stage ring
     {64, 64, 32, 4, &launch2<64, 64, 32, 4, false>},        {64, 128, 32, 4, &launch2<64, 128, 32, 4, false>},
     {64, 64, 64, 3, &launch2<64, 64, 64, 3, false>},
-    // Register-staged operands (global -> VGPR -> ds_write_b128, plain and inside the anti-phase schedule; in this file's history,
-    // profiles/r02_igemm_register_staging.txt) lose to the DMA ring and the anti-phase DMA schedule on every 104-frame shape (188 /
-    // 181 vs 180 / 166 us on 252928 x 256 x 1024).  So do 4-wave 256x256 tiles (128x128 per wave, 256 accumulator AGPRs, one wave per SIMD -- the vendor library's shape,
-    // MT256x256x32/64 MIWT8_8): 191-206 us against 168 on 252928 x 256 x 1024, 343 against 311 on the 3x3.
+    // (whole-line BKT 64 tiles in 3- / 4-stage rings -- 128x256x64/3, 128x128x64/4 -- were timed on the HBM-paced long-K N = 256 layers:
+    // 195 / 247 us against 168 for 256x256x32/5 on res4 conv1; not in the table)
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 const TileCfg kStemCfgs[] = {   // Cin == 8 stem (one filter tap per 16-byte chunk)
