@@ -456,7 +456,13 @@ class DiffusionDet(nn.Module):
         # frames per launch sequence: one look-ahead group (taking the first call's 24 global frames into the same sequence --
         # 128 frames instead of 104 + 24 -- measured 1 % slower, A/B on one box)
         cap = self.infer_batch * self.lookahead
-        eng.reserve(min(cap, n_total), fh, fw, M)
+        # A call whose OWN frames exceed a look-ahead group -- the first call of a video without look-ahead (8 local + 24 global frames
+        # against groups of 8), every call of the streaming mode (1 local + 1 global frame against groups of 1) -- runs them as ONE
+        # launch sequence: the reference's splits of INFER_BATCH (diffusion_det.py:424-476) bound its memory, not its arithmetic; every
+        # stage is per-frame independent and the draws stay keyed by the reference's split index.
+        starts = list(range(0, n_total, cap)) if n_own <= cap else [0] + list(range(n_own, n_total, cap))
+        bounds = list(zip(starts, starts[1:] + [n_total]))
+        eng.reserve(max(b - a for a, b in bounds), fh, fw, M)
         per_frame = []          # (launch result dict, index inside the launch) for every frame slot of `total`
 
         def take(a, b, keys=("logits", "boxes", "obj", "k1", "k2"), with_feats=True):
@@ -481,8 +487,8 @@ class DiffusionDet(nn.Module):
             return out
 
         fired = on_global is None or not ref_g
-        for ci, a in enumerate(range(0, n_total, cap)):
-            feats = eng.backbone_frames(frames[a:a + cap]) if as_list else eng.backbone(total[a:a + cap].contiguous())
+        for ci, (a, a_end) in enumerate(bounds):
+            feats = eng.backbone_frames(frames[a:a_end]) if as_list else eng.backbone(total[a:a_end].contiguous())
             if ci == 0 and self.after_first_launch is not None:
                 self.after_first_launch()          # e.g. the data layer's prefetch of the next group: behind this call's own uploads
             B = feats[0].shape[0]
