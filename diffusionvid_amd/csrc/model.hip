@@ -1159,7 +1159,7 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
     } else {
         // frames with different time steps (not produced by the reference's sampler): the rows are laid out per frame in
         // the workspace by device-to-device copies on the launch stream
-        float* tab = m->ss.as<float>() + (size_t)slot * ((size_t)m->ws_frames + 3) / 4 * 4 * 2 * d;
+        float* tab = m->ss.as<float>() + (size_t)slot * (((size_t)m->ws_frames + 3) / 4 * 4) * 2 * d;          // slot stride of dvid_workspace_reserve
         for (int f = 0; f < n_frames; ++f) {
             const float* row = nullptr;
             TRY(ss_row(t[f], &row));
