@@ -552,7 +552,7 @@ def main():
                       "by farthest-point sampling and finishes the frame; ms_per_frame is the per-call latency")
 
     feed = None
-    if rank == 0 and headline and not args.no_feed_rate:
+    if rank == 0 and headline and not grouped and not args.no_feed_rate:          # (forks decode workers: single-process runs only)
         try:
             feed = real_data_feed_rate(device)
         except Exception as e:
