@@ -29,6 +29,14 @@ bool dvid_wstat_supported(const IgemmParams& p);
 bool dvid_wstat_preferred(const IgemmParams& p);
 int dvid_wstat_launch(const IgemmParams& p, hipStream_t s);
 
+// bneck.hip: the tail of a res2 bottleneck block (conv2 3x3 64 -> 64, conv3 64 -> 256 + residual or shortcut convolution, ReLU and the
+// next block's conv1 256 -> 64) as one launch; bit-identical to the layer-by-layer launches.  ws == null: the residual is `res`
+// [rows][W][256]; else `res` is the 64-channel block input and the residual is its shortcut convolution.  w1n == null: no next conv1.
+bool dvid_bneck64_tail_preferred(int H, int W);
+int dvid_bneck64_tail_launch(const half_t* t1, const half_t* w2, const float* b2, const half_t* w3, const float* b3, const half_t* res,
+                             const half_t* ws, const float* bs, const half_t* w1n, const float* b1n, half_t* out, half_t* t1n, int n, int H,
+                             int W, hipStream_t s);
+
 // elementwise.hip
 // per-frame source pointers of one image-prep launch (passed by value as a kernel argument)
 struct FrameTable {

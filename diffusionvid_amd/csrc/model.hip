@@ -89,6 +89,30 @@ int igemm(const IgemmParams& p, hipStream_t s) {
     return rc;
 }
 
+// The fused tail of a res2 bottleneck block (bneck.hip) as one record of the implicit-GEMM family: its algorithmic work is the sum
+// of the products it computes (conv2 + conv3 [+ shortcut] [+ next conv1]), its bytes what the launch touches once.
+int bneck_tail(const half_t* t1, const half_t* w2, const float* b2, const half_t* w3, const float* b3, const half_t* res, const half_t* ws,
+               const float* bs, const half_t* w1n, const float* b1n, half_t* out, half_t* t1n, int n, int H, int W, hipStream_t s) {
+    if (!g_prof_on) return dvid_bneck64_tail_launch(t1, w2, b2, w3, b3, res, ws, bs, w1n, b1n, out, t1n, n, H, W, s);
+    ProfRec r;
+    if (prof_take(&r) != DVID_OK) return DVID_ERR_HIP;
+    const double M = (double)n * H * W;
+    const int kk = 576 + 256 + (ws ? 256 : 0) + (w1n ? 256 : 0);        // MACs per pixel / 64
+    r.flop = 2.0 * M * 64.0 * kk;
+    r.bytes = M * 2.0 * (64 + (ws ? 64 : 256) + 256 + (w1n ? 64 : 0)) + 2.0 * 64 * kk;
+    r.M = (int)M;
+    r.N = 256;
+    r.K = kk;
+    r.taps = 9;
+    r.stride = 1;
+    r.res_mode = ws ? 4 : 3;                  // CSV marker: 3 = fused block tail, 4 = with the shortcut convolution
+    HIP_TRY(hipEventRecord(r.a, s));
+    const int rc = dvid_bneck64_tail_launch(t1, w2, b2, w3, b3, res, ws, bs, w1n, b1n, out, t1n, n, H, W, s);
+    HIP_TRY(hipEventRecord(r.b, s));
+    prof_push(r);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 struct HostTensor {
     std::vector<float> v;
@@ -447,6 +471,24 @@ int make_head(dvid_model* m, const std::string& pfx, bool cond, HeadW* h) {
         h->frag.ok = true;
     }
     return DVID_OK;
+}
+
+// every block of the stage is a 64-wide stride-1 bottleneck with 256 outputs; block 0 has a shortcut convolution over 64 channels
+// (R-50 / R-101 res2), the others take the block input as the residual
+bool bneck64_stage(const std::vector<Block>& blocks) {
+    if (blocks.empty()) return false;
+    for (size_t b = 0; b < blocks.size(); ++b) {
+        const Block& k = blocks[b];
+        const int cin = b == 0 ? 64 : 256;
+        if (k.c1.kh != 1 || k.c1.stride != 1 || k.c1.cin != cin || k.c1.cout != 64 || k.c1.kpad != cin || !k.c1.bias) return false;
+        if (k.c2.kh != 3 || k.c2.kw != 3 || k.c2.stride != 1 || k.c2.pad != 1 || k.c2.cin != 64 || k.c2.cout != 64 || k.c2.kpad != 576 ||
+            !k.c2.bias)
+            return false;
+        if (k.c3.kh != 1 || k.c3.stride != 1 || k.c3.cin != 64 || k.c3.cout != 256 || k.c3.kpad != 64 || !k.c3.bias) return false;
+        if (k.has_sc != (b == 0)) return false;
+        if (k.has_sc && (k.sc.kh != 1 || k.sc.stride != 1 || k.sc.cin != 64 || k.sc.cout != 256 || k.sc.kpad != 64 || !k.sc.bias)) return false;
+    }
+    return true;
 }
 
 int conv_run(const ConvW& w, const half_t* in, int n, int h, int wd, void* out, int relu, int out_f32, const void* res,
@@ -1003,6 +1045,26 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
         int sh[4], sw[4];
         for (int st = 0; st < 4; ++st) {
             const int nb = (int)m->blocks[st].size();
+            // res2 (64-wide bottlenecks, 256 out): one launch per block for everything behind conv1 -- conv2, conv3 + shortcut / residual
+            // + ReLU and the next block's conv1 (csrc/bneck.hip; bit-identical to the launches below)
+            if (st == 0 && bneck64_stage(m->blocks[0]) && dvid_bneck64_tail_preferred(h, w)) {
+                half_t* ta = t1;
+                half_t* tb = t2;
+                TRY(conv_run(m->blocks[0][0].c1, cur, nf, h, w, ta, 1, 0, nullptr, 0, 0, cs));
+                for (int b = 0; b < nb; ++b) {
+                    const Block& blk = m->blocks[0][b];
+                    const Block* nxt = b + 1 < nb ? &m->blocks[0][b + 1] : nullptr;
+                    half_t* dst = cur == bx ? by : bx;
+                    TRY(bneck_tail(ta, blk.c2.w, blk.c2.bias, blk.c3.w, blk.c3.bias, cur, blk.has_sc ? blk.sc.w : nullptr,
+                                   blk.has_sc ? blk.sc.bias : nullptr, nxt ? nxt->c1.w : nullptr, nxt ? nxt->c1.bias : nullptr, dst,
+                                   nxt ? tb : nullptr, nf, h, w, cs));
+                    std::swap(ta, tb);
+                    cur = dst;
+                }
+                sh[st] = h;
+                sw[st] = w;
+                continue;
+            }
             for (int b = 0; b < nb; ++b) {
                 const Block& blk = m->blocks[st][b];
                 int h2 = h, w2 = w;
@@ -1327,6 +1389,18 @@ int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const
     if (pad < 0 && stride != 1) FAIL(DVID_ERR_ARG, "same-size padding needs stride 1");
     TRY(conv_run(cw, reinterpret_cast<const half_t*>(in), n, h, wd, out, relu, out_f32, residual, residual_mode, 0,
                  reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_bottleneck64_tail_f16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* residual,
+                               const void* w_shortcut, const float* b_shortcut, const void* w1_next, const float* b1_next, void* out,
+                               void* t1_next, int n, int h, int wd, void* stream) {
+    g_err[0] = 0;
+    const int rc = bneck_tail(reinterpret_cast<const half_t*>(t1), reinterpret_cast<const half_t*>(w2), b2, reinterpret_cast<const half_t*>(w3),
+                              b3, reinterpret_cast<const half_t*>(residual), reinterpret_cast<const half_t*>(w_shortcut), b_shortcut,
+                              reinterpret_cast<const half_t*>(w1_next), b1_next, reinterpret_cast<half_t*>(out),
+                              reinterpret_cast<half_t*>(t1_next), n, h, wd, reinterpret_cast<hipStream_t>(stream));
+    if (rc != DVID_OK) FAIL(rc, "bottleneck tail: bad argument (n %d, %d x %d)", n, h, wd);
     return DVID_OK;
 }
 

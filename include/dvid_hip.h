@@ -155,6 +155,15 @@ int dvid_gather_rows(const float* x, const int* idx, float* y, int m, int d, voi
 int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const void* residual, void* out, int n, int h,
                          int wd, int cin, int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int out_f32,
                          int residual_mode, void* stream);
+/* Everything behind conv1 of a res2 bottleneck block (detectron2 BottleneckBlock, widths 64 -> 64 -> 256, stride 1) as one launch:
+ * conv2 3x3 + ReLU, conv3 1x1 + residual + ReLU and -- w1_next != NULL -- the next block's conv1 256 -> 64 + ReLU.  t1 [n,h,wd,64] is
+ * the block's conv1 output; w2 [64][576], w3 [256][64], w1_next [64][256] in dvid_conv2d_nhwc_f16's packing (FrozenBN folded, biases
+ * fp32).  w_shortcut == NULL: `residual` is the block input [n,h,wd,256]; else `residual` is the 64-channel block input [n,h,wd,64]
+ * and the residual is its shortcut convolution w_shortcut [256][64].  out [n,h,wd,256], t1_next [n,h,wd,64] (must not alias t1).
+ * Bit-identical to the same layers run through dvid_conv2d_nhwc_f16 (csrc/bneck.hip). */
+int dvid_bottleneck64_tail_f16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* residual,
+                               const void* w_shortcut, const float* b_shortcut, const void* w1_next, const float* b1_next, void* out,
+                               void* t1_next, int n, int h, int wd, void* stream);
 /* MFMA attention, head_dim 32: fp16 q/k/v with head h at columns [32h, 32h+32) of each row, fp16 out;
  * vt_scratch: >= batch*nheads*32*(round_up(lk,32)+32) halves (receives V transposed per head). */
 int dvid_mha_f16(const void* q, const void* k, const void* v, void* out, void* vt_scratch, int batch, int lq, int lk, int nheads,
@@ -199,6 +208,12 @@ int dvid_igemm_set_conv3x3(int mode);
  * enough for 256 persistent workgroups, 2 = wherever the layer type fits (tests), 0 = off (igemm2), -1 = follow DVID_WSTAT (default 1).
  * Bit-identical to igemm2. */
 int dvid_igemm_set_wstat(int mode);
+
+/* res2 bottleneck blocks behind their conv1 as one launch each (csrc/bneck.hip: dvid_bottleneck64_tail_f16 inside the ResNet
+ * backbone): 1 = where the shape rule of the 3x3 patch kernels holds for the res2 map (a function of the image size only), 2 = whenever
+ * the stage is 64 -> 64 -> 256 bottlenecks (tests), 0 = off (layer-by-layer launches), -1 = follow DVID_BNECK_FUSE (default 1).
+ * Bit-identical to the layer-by-layer launches. */
+int dvid_igemm_set_bottleneck_fusion(int mode);
 
 /* When enabled, every igemm launch is bracketed by HIP events on its stream; dvid_profile_read
  * synchronises those events and returns totals since the last reset. */

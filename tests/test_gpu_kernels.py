@@ -543,6 +543,39 @@ def test_backbone_small(dv):
     model.close()
 
 
+@pytest.mark.parametrize("size", [(128, 192), (256, 512), (608, 1024)])
+def test_backbone_bottleneck_fusion_bit_identical(dv, size):
+    """The ResNet-FPN backbone with res2's blocks as one launch each behind conv1 (csrc/bneck.hip) against the same backbone with
+    layer-by-layer launches: p3 / p4 / p5 bit for bit, at a size the shape rule skips (forced on), a mid size and the bench's frame
+    size; 3 frames, so the patch rows of res2 straddle images.  The fused run is also checked against the CPU oracle at the small size."""
+    from diffusionvid_amd import _lib
+    from diffusionvid_amd.utils import synthetic
+    lib = _lib.load()
+    blocks = (3, 1, 1, 1)
+    sd = synthetic.make_state_dict(3, blocks=blocks)
+    g = torch.Generator().manual_seed(size[0])
+    imgs = torch.rand(3, 3, size[0], size[1], generator=g)
+    model = dv.Model(sd, res_blocks=blocks)
+    model.reserve(3, size[0], size[1], 300)
+    try:
+        _lib.check(lib.dvid_igemm_set_bottleneck_fusion(2), "set_bottleneck_fusion")
+        fused = [t.clone() for t in model.backbone(imgs.cuda())]
+        _lib.check(lib.dvid_igemm_set_bottleneck_fusion(0), "set_bottleneck_fusion")
+        plain = [t.clone() for t in model.backbone(imgs.cuda())]
+    finally:
+        lib.dvid_igemm_set_bottleneck_fusion(-1)
+    torch.cuda.synchronize()
+    for name, a, b in zip(("p3", "p4", "p5"), fused, plain):
+        print("fused vs layer by layer %s: identical %.6f" % (name, (a == b).float().mean().item()))
+        assert torch.equal(a, b), name
+    if size[0] <= 128:
+        cfg_mean, cfg_std = (123.675, 116.280, 103.530), (58.395, 57.120, 57.375)
+        ref = backbone_r101.backbone_r101_fpn(backbone_r101.normalizer(imgs, cfg_mean, cfg_std), sd, "backbone.", blocks)
+        for name, got in zip(("p3", "p4", "p5"), fused):
+            check(f"backbone_fused.{name}", dv.nchw_from_nhwc(got), ref[name], 3e-2, 3e-2)
+    model.close()
+
+
 def test_backbone_swin_small(dv):
     """Swin-Transformer + FPN (same kernels/graph as Swin-B, reduced widths/depths) vs the CPU oracle:
     patch embed, (shifted-)window MFMA attention with padding + relative-position bias + shift mask,
@@ -772,6 +805,58 @@ def test_conv4x4_s2d_stem_kernel(dv, shape):
     check("conv4x4_s2d", dv.nchw_from_nhwc(got), ref, 2e-3, 2e-3)
     check("conv4x4_s2d.igemm2", dv.nchw_from_nhwc(base), ref, 2e-3, 2e-3)
     assert torch.equal(got, base)
+
+
+@pytest.mark.parametrize("geom", [(3, 16, 64), (2, 19, 40), (1, 8, 32), (5, 38, 96), (2, 152, 256), (1, 7, 20)])
+@pytest.mark.parametrize("variant", ["shortcut+next", "identity+next", "identity", "shortcut"])
+def test_bottleneck_tail_matches_layers(dv, geom, variant):
+    """csrc/bneck.hip (conv2 3x3 -> conv3 + shortcut / residual + ReLU -> the next block's conv1 in one launch, intermediates in
+    registers) against the same layers run one by one through dvid_conv2d_nhwc_f16 -- bit for bit -- and against torch on the same
+    fp16-rounded operands.  Geometries: several images per launch (patch rows straddle images), heights that are not a multiple
+    of 8, widths that are not a multiple of 32, a single-patch map, the bench's 152 x 256 map."""
+    n, hh, ww = geom
+    sc, tail = variant.startswith("shortcut"), variant.endswith("next")
+    g = torch.Generator().manual_seed(n * 1000 + hh * 10 + ww + len(variant))
+    cin = 64 if sc else 256
+    x = h16(torch.randn(n, hh, ww, cin, generator=g))                   # block input
+    t1 = h16(torch.randn(n, hh, ww, 64, generator=g).clamp_min(0))      # conv1 output (after ReLU)
+    w2 = h16(torch.randn(64, 64, 3, 3, generator=g) * (1.5 / 576 ** 0.5))
+    w3 = h16(torch.randn(256, 64, generator=g) * (1.5 / 8))
+    wsc = h16(torch.randn(256, 64, generator=g) * (1.5 / 8))
+    w1n = h16(torch.randn(64, 256, generator=g) * (1.5 / 16))
+    b2, b3, bsc, b1n = (torch.randn(c, generator=g) * 0.3 for c in (64, 256, 256, 64))
+    # torch reference on the same operands (fp32), rounding where the layer-by-layer path stores fp16
+    t2 = h16(F.relu(F.conv2d(t1.permute(0, 3, 1, 2), w2, b2, padding=1)))
+    y = F.conv2d(t2, w3[:, :, None, None], b3)
+    res = h16(F.conv2d(x.permute(0, 3, 1, 2), wsc[:, :, None, None], bsc)) if sc else x.permute(0, 3, 1, 2)
+    out_ref = h16(F.relu(y + res))
+    t1n_ref = F.relu(F.conv2d(out_ref, w1n[:, :, None, None], b1n))
+    # layer by layer on the device
+    w2p, k2 = dv.pack_conv_weight(w2)
+    w3p, k3 = dv.pack_conv_weight(w3)
+    wsp, ks = dv.pack_conv_weight(wsc)
+    w1p, k1 = dv.pack_conv_weight(w1n)
+    assert (k2, k3, ks, k1) == (576, 64, 64, 256)
+    xd, t1d = x.to(torch.float16).cuda(), t1.to(torch.float16).cuda()
+    w2d, w3d, wsd, w1d = w2p.cuda(), w3p.cuda(), wsp.cuda(), w1p.cuda()
+    b2d, b3d, bsd, b1d = b2.cuda(), b3.cuda(), bsc.cuda(), b1n.cuda()
+    t2d = dv.conv2d_nhwc(t1d, w2d, k2, b2d, 64, 3, 3, 1, 1, relu=True)
+    resd = dv.conv2d_nhwc(xd, wsd, ks, bsd, 256, 1, 1, 1, 0) if sc else xd
+    out_l = dv.conv2d_nhwc(t2d, w3d, k3, b3d, 256, 1, 1, 1, 0, relu=True, residual=resd, residual_mode=1)
+    t1n_l = dv.conv2d_nhwc(out_l, w1d, k1, b1d, 64, 1, 1, 1, 0, relu=True)
+    # one launch
+    out_f, t1n_f = dv.bottleneck64_tail(t1d, w2d, b2d, w3d, b3d, xd, wsd if sc else None, bsd if sc else None,
+                                        w1d if tail else None, b1d if tail else None)
+    torch.cuda.synchronize()
+    check("bneck out", out_f, out_ref.permute(0, 2, 3, 1), 2e-3, 2e-3)
+    print("bneck vs layers: out identical %.6f" % (out_f == out_l).float().mean().item())
+    assert torch.equal(out_f, out_l)
+    if tail:
+        check("bneck t1_next", t1n_f, t1n_ref.permute(0, 2, 3, 1), 2e-3, 2e-3)
+        print("bneck vs layers: t1_next identical %.6f" % (t1n_f == t1n_l).float().mean().item())
+        assert torch.equal(t1n_f, t1n_l)
+    else:
+        assert t1n_f is None
 
 
 @pytest.mark.parametrize("shape", [(8 * 32 * 40 + 13, 256, 1024, True, True), (5000, 128, 512, True, True), (70001, 256, 2048, False, True),

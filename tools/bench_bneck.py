@@ -1,0 +1,64 @@
+"""Stand-alone timing of the fused res2 block tail (csrc/bneck.hip) against the layer-by-layer launches on the bench's res2 map
+(152 x 256 per 608 x 1024 frame):  python tools/bench_bneck.py [frames]   -> one line per variant, ms per launch (chain) and
+the HBM rate of the bytes each form touches once."""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from diffusionvid_amd import ops as dv  # noqa: E402
+
+
+def timed(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 304
+    hh, ww = 152, 256
+    g = torch.Generator().manual_seed(0)
+    px = n * hh * ww
+    x256 = (torch.randn(px, 256, generator=g, dtype=torch.float16)).cuda().view(n, hh, ww, 256)
+    x64 = x256[..., :64].contiguous()
+    t1 = x256[..., 64:128].clamp_min(0).contiguous()
+    w2 = torch.randn(64, 64, 3, 3, generator=g) * (1.5 / 24)
+    w3, wsc = (torch.randn(256, 64, generator=g) * (1.5 / 8) for _ in range(2))
+    w1n = torch.randn(64, 256, generator=g) * (1.5 / 16)
+    (w2p, k2), (w3p, k3), (wsp, ks), (w1p, k1) = (dv.pack_conv_weight(w) for w in (w2, w3, wsc, w1n))
+    w2d, w3d, wsd, w1d = w2p.cuda(), w3p.cuda(), wsp.cuda(), w1p.cuda()
+    b2, b3, bs, b1 = (torch.randn(c, generator=g).cuda() * 0.3 for c in (64, 256, 256, 64))
+    for sc, tail in ((False, True), (False, False), (True, True)):
+        xin = x64 if sc else x256
+
+        def layers():
+            t2 = dv.conv2d_nhwc(t1, w2d, k2, b2, 64, 3, 3, 1, 1, relu=True)
+            res = dv.conv2d_nhwc(xin, wsd, ks, bs, 256, 1, 1, 1, 0) if sc else xin
+            out = dv.conv2d_nhwc(t2, w3d, k3, b3, 256, 1, 1, 1, 0, relu=True, residual=res, residual_mode=1)
+            return out, (dv.conv2d_nhwc(out, w1d, k1, b1, 64, 1, 1, 1, 0, relu=True) if tail else None)
+
+        def fused():
+            return dv.bottleneck64_tail(t1, w2d, b2, w3d, b3, xin, wsd if sc else None, bs if sc else None, w1d if tail else None,
+                                        b1 if tail else None)
+
+        ol, tl = layers()
+        of, tf = fused()
+        torch.cuda.synchronize()
+        same = torch.equal(ol, of) and (not tail or torch.equal(tl, tf))
+        del ol, tl, of, tf
+        ms_l, ms_f = timed(layers), timed(fused)
+        by_f = px * 2.0 * (64 + (64 if sc else 256) + 256 + (64 if tail else 0))
+        by_l = px * 2.0 * (64 + 64 + 64 + 256 + 256 + (64 + 256 if sc else 256) + ((256 + 64) if tail else 0))
+        print("frames %d shortcut %d next_conv1 %d: layer by layer %.3f ms (%.0f GB/s of its bytes), one launch %.3f ms (%.0f GB/s of its "
+              "bytes), x%.2f, identical %s" % (n, sc, tail, ms_l, by_l / ms_l / 1e6, ms_f, by_f / ms_f / 1e6, ms_l / ms_f, same), flush=True)
+
+
+if __name__ == "__main__":
+    main()
