@@ -14,7 +14,7 @@ rows = list(csv.DictReader(open("$f")))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --arch swinb --no-cpu-baseline --no-host-fed --no-side-configs (DVID_CHAINS=1; 5 videos of 304 frames)")
 print("total kernel time %.1f ms" % (tot / 1e6))
-ig = [r for r in rows if "igemm2_kernel" in r["Name"] or "wstat" in r["Name"] or "conv3x3_" in r["Name"]]
+ig = [r for r in rows if "igemm2_kernel" in r["Name"] or "wstat" in r["Name"] or "bneck64" in r["Name"] or "conv3x3_" in r["Name"]]
 print("implicit-GEMM kernels (all instantiations): calls %d total %.2f ms  %.1f%%" % (sum(int(r["Calls"]) for r in ig), sum(float(r["TotalDurationNs"]) for r in ig) / 1e6, 100 * sum(float(r["TotalDurationNs"]) for r in ig) / tot))
 for r in rows[:30]:
     print("%-100s calls %7s total %9.2f ms avg %9.1f us %5.1f%%" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
