@@ -383,6 +383,321 @@ int bn_launch(const BneckParams& p, hipStream_t s) {
     return DVID_OK;
 }
 
+
+// ---- 128-wide bottlenecks (res3: 128 -> 128 -> 512) ----------------------------------------------------------------------------------
+// The same chain -- conv2 3x3 -> conv3 + residual + ReLU -> the next block's conv1, a wave owning a patch row of 32 pixels from start
+// to finish, products transposed and chained through registers -- but the weights (288 + 128 + 128 KB) no longer fit the LDS: they
+// stream from L2 through a 4-stage ring of 16-KB steps, one barrier and one counted vmcnt per step:
+//   conv2: 18 steps = 9 taps x 2 halves of the input channels, [128 out][64 in] each (16 MFMAs per wave);
+//   conv3 + next conv1: 16 steps = 32 output channels each: the conv3 rows [32][128] and -- TAIL -- the next conv1's columns
+//   [128][32] that multiply exactly those channels (8 + 8 MFMAs per wave), so the block output is consumed as it is produced
+//   and only the next conv1's accumulators (64 registers) live across steps.
+// The residual of a step's 32 channels is requested four steps ahead (by DMA into a per-wave ring in the halo region, which is free
+// after conv2; the first four tiles into registers); loads retire in issue order, so the step's own wait for its weights is also the
+// wait for that residual.  LDS: t1 halo 10 x 34 pixels x 256 B (88 KB) + ring 64 KB
+// + biases 3 KB.  CONV2 = false: the block's conv2 ran as its own launch (res3's first block: 3x3 / stride 2) and `t1` is its output.
+// K order of conv2: tap, then channel (igemm2's; the chunked patch kernel of conv3x3.hip sums channel-chunk-major), so this
+// kernel is bit-identical to the layer-by-layer launches on igemm2 and differs from the patch kernel in fp32 summation order only;
+// which of the two a backbone runs is a function of the image size alone.
+constexpr int H8_PIECES = 88;                  // 1-KiB pieces of 4 pixels: 85 cover the 340 halo pixels; 11 per wave
+constexpr int k8Ring = H8_PIECES * 1024;
+constexpr int k8Stage = 16384;
+constexpr int k8Bias = k8Ring + 4 * k8Stage;   // floats: b3 [512] | b2 [128] | b1n [128]
+constexpr int k8Bytes = k8Bias + 3072;
+
+struct Bneck128Params {
+    const half_t* t1;      // CONV2: [rows][W][128] conv1 output; else the conv2 output t2
+    const half_t* w2;      // [128][1152]
+    const float* b2;
+    const half_t* w3;      // [512][128]
+    const float* b3;
+    const half_t* res;     // [rows][W][512]
+    const half_t* w1n;     // [128][512] (TAIL)
+    const float* b1n;
+    half_t* out;           // [rows][W][512]
+    half_t* t1n;           // [rows][W][128]
+    int H, W, nrows, tiles_x, ntiles;
+};
+
+__device__ __forceinline__ void bn_wait_vmcnt_n(int n) {          // n is a constant after unrolling
+    switch (n) {
+        case 0: bn_wait_vmcnt<0>(); break;
+        case 1: bn_wait_vmcnt<1>(); break;
+        case 2: bn_wait_vmcnt<2>(); break;
+        case 3: bn_wait_vmcnt<3>(); break;
+        case 4: bn_wait_vmcnt<4>(); break;
+        case 5: bn_wait_vmcnt<5>(); break;
+        case 6: bn_wait_vmcnt<6>(); break;
+        case 7: bn_wait_vmcnt<7>(); break;
+        case 8: bn_wait_vmcnt<8>(); break;
+        case 9: bn_wait_vmcnt<9>(); break;
+        default: bn_wait_vmcnt<10>(); break;
+    }
+}
+
+template <bool CONV2, bool TAIL>
+__global__ __launch_bounds__(512) void bneck128_tail_kernel(Bneck128Params p) {
+    constexpr int NC2 = CONV2 ? 18 : 0, NST = NC2 + 16, D3 = TAIL ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, frow = lane & 31;
+    const int lid = igemm_xcd_remap((int)blockIdx.x, p.ntiles);
+    const int tx = lid % p.tiles_x, ty = lid / p.tiles_x;
+    const int r0 = ty * TH, x0 = tx * TW;
+    const char* zero = reinterpret_cast<const char*>(g_zero16_bn);
+    char* const ring = smem + k8Ring;
+
+    // DMA pieces a wave issues for step t (its weights), and the residual loads a wave issues at the end of step u -- both
+    // unconditional, so they can be counted; stores are predicated (a wave may skip them) and are not: the counts are lower bounds
+    // of what was issued after a step's pieces, i.e. the waits err on the early side of the ring only.
+    auto dma_cnt = [](int t) { return (t < 0 || t >= NST) ? 0 : (t < NC2 ? 2 : D3); };
+    // residual: tiles 0-3 are ordinary loads into registers (CONV2: at conv2 steps 2-5, long before their use; else in the prologue),
+    // tiles 4-15 ride a per-wave DMA ring of 5 x 2 KB in the halo region, which is free once conv2 is done: tile jj + 4 is requested
+    // at the start of conv3 step jj.  (Ordinary loads for all of them make the compiler wait vmcnt(0) at every first use while DMA
+    // pieces are in flight -- its scoreboard treats a pending LDS-DMA as out of order.)
+    auto r_cnt = [&](int u) { return ((CONV2 && u >= 2 && u < 6) || (u >= NC2 && u < NC2 + 12)) ? 2 : 0; };
+    auto wait_n = [&](int s) { return dma_cnt(s + 1) + dma_cnt(s + 2) + r_cnt(s - 3) + r_cnt(s - 2) + r_cnt(s - 1); };
+
+    // ---- biases by DMA: b3 (two pieces), b2 | b1n (one piece: lanes 0-31 / 32-63)
+    if (wave < 3) {
+        const float* src = wave < 2 ? p.b3 + wave * 256 + lane * 4 : (lane < 32 ? p.b2 + lane * 4 : (TAIL ? p.b1n + (lane - 32) * 4 : nullptr));
+        bn_glds16(src ? reinterpret_cast<const char*>(src) : zero, smem + k8Bias + wave * 1024);
+    }
+    // ---- this lane's pixel
+    const int gr = r0 + wave, gx = x0 + frow;
+    const bool valid = gr < p.nrows && gx < p.W;
+    const long pix = (long)(gr < p.nrows ? gr : p.nrows - 1) * p.W + (gx < p.W ? gx : p.W - 1);
+    const half_t* const rrow = p.res + pix * 512 + 8 * hi;
+    half8 resr[4][2];
+    half8 t2f[8];
+    char* const rring = smem + wave * (5 * 2048);
+    auto issue_res = [&](int jn) {             // tile jn's two pieces: every lane fetches the 16 bytes it will add, and reads them back lane-linearly
+#pragma unroll
+        for (int g = 0; g < 2; ++g) bn_glds16(reinterpret_cast<const char*>(rrow + 32 * jn + 16 * g), rring + (jn % 5) * 2048 + g * 1024);
+    };
+    if (CONV2) {
+        // t1 halo: piece q = wave + 8 i covers halo pixels [4 q, 4 q + 4); lane -> (pixel, 16-byte slot holding chunk slot ^ (hx & 15))
+#pragma unroll
+        for (int i = 0; i < H8_PIECES / 8; ++i) {
+            const int q = wave + 8 * i;
+            const int pidx = 4 * q + (lane >> 4);
+            const int hy = pidx / HW, hx = pidx - hy * HW;
+            const int hgr = r0 - 1 + hy, hgx = x0 - 1 + hx;
+            const bool ok = pidx < HH * HW && (unsigned)hgr < (unsigned)p.nrows && (unsigned)hgx < (unsigned)p.W;
+            const int lch = (lane & 15) ^ (hx & 15);
+            bn_glds16(ok ? reinterpret_cast<const char*>(p.t1 + ((long)hgr * p.W + hgx) * 128 + lch * 8) : zero, smem + q * 1024);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t2f[k] = *reinterpret_cast<const half8*>(p.t1 + pix * 128 + 16 * k + 8 * hi);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) resr[jj][g] = *reinterpret_cast<const half8*>(rrow + 32 * jj + 16 * g);
+    }
+    asm volatile("" ::: "memory");
+
+    // ---- weight pieces of step t into stage t & 3
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int wrow = 8 * wave + prow;                                   // conv2: rows wrow and wrow + 64 of the [128][64] tile
+    const char* const w2src = CONV2 ? reinterpret_cast<const char*>(p.w2 + (long)wrow * 1152 + (pslot ^ ((wrow >> 1) & 7)) * 8) : zero;
+    const int q3 = wave & 3, kh3 = wave >> 2, row3 = 8 * q3 + prow;       // conv3: rows row3 of the [32][128] tile, K half kh3
+    const char* const w3src = reinterpret_cast<const char*>(p.w3 + (long)row3 * 128 + kh3 * 64 + (pslot ^ ((row3 >> 1) & 7)) * 8);
+    const int rown = 16 * wave + (lane >> 2);                            // next conv1: rows rown of the [128][32] column slice
+    const char* const w1src = TAIL ? reinterpret_cast<const char*>(p.w1n + (long)rown * 512 + ((lane & 3) ^ ((rown >> 2) & 3)) * 8) : zero;
+    auto issue_step = [&](int t) {
+        if (t >= NST) return;
+        char* const stg = ring + (t & 3) * k8Stage;
+        if (t < NC2) {
+            const int koff = ((t >> 1) * 128 + (t & 1) * 64) * 2;
+            bn_glds16(w2src + koff, stg + wave * 1024);
+            bn_glds16(w2src + koff + 64 * 1152 * 2, stg + (wave + 8) * 1024);
+        } else {
+            const int jj = t - NC2;
+            bn_glds16(w3src + (long)jj * (32 * 128 * 2), stg + kh3 * 4096 + q3 * 1024);
+            if (TAIL) bn_glds16(w1src + jj * 64, stg + 8192 + wave * 1024);
+        }
+    };
+    issue_step(0);
+    issue_step(1);
+    issue_step(2);
+    asm volatile("" ::: "memory");
+
+    int b_off[4];                              // row frow (+ 32 j) of a 128-byte-pitch weight tile, K step ks
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b_off[ks] = frow * PXB + (((2 * ks + hi) ^ ((frow >> 1) & 7)) << 4);
+    const float* const bl = reinterpret_cast<const float*>(smem + k8Bias);
+
+    if (CONV2) {
+        const int yimg = (r0 + wave) % p.H;
+        const bool up_ok = yimg > 0, down_ok = yimg < p.H - 1;
+        int a_base[3], a_key[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            a_base[dx] = (dx + frow) * 256;
+            a_key[dx] = (dx + frow) & 15;
+        }
+        float16v acc2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NC2; ++s) {
+            bn_wait_vmcnt_n(wait_n(s));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_step(s + 3);
+            const int tap = s >> 1, kh = s & 1, dy = tap / 3, dx = tap % 3;
+            if (!((dy == 0 && !up_ok) || (dy == 2 && !down_ok))) {
+                const char* stg = ring + (s & 3) * k8Stage;
+                const char* hrow = smem + (wave + dy) * (HW * 256) + a_base[dx];
+                half8 fp[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fp[ks] = *reinterpret_cast<const half8*>(hrow + (((2 * (4 * kh + ks) + hi) ^ a_key[dx]) << 4));
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    half8 fw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const half8*>(stg + j * 4096 + b_off[ks]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fp[ks], acc2[j], 0, 0, 0);
+                }
+            }
+            if (s >= 2 && s < 6) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) resr[s - 2][g] = *reinterpret_cast<const half8*>(rrow + 32 * (s - 2) + 16 * g);
+            }
+            asm volatile("" ::: "memory");
+        }
+        // conv2 epilogue: + bias, round, ReLU -> the eight K-step fragments of conv3's second operand
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int u[16];
+            bn_swap(acc2[j], u);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4v blo = *reinterpret_cast<const float4v*>(bl + 512 + 32 * j + 16 * g + 8 * hi);
+                const float4v bhi = *reinterpret_cast<const float4v*>(bl + 512 + 32 * j + 16 * g + 8 * hi + 4);
+                float4v lo, hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = __uint_as_float(u[8 * g + e]) + blo[e];
+                    hv[e] = __uint_as_float(u[8 * g + 4 + e]) + bhi[e];
+                }
+                const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
+                half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                t2f[2 * j + g] = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
+            }
+        }
+    }
+
+    // ---- conv3 + residual + ReLU, 32 channels per step, each step's output feeding the next conv1's accumulators
+    float16v acc1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+    half_t* const orow = p.out + ((long)gr * p.W + gx) * 512 + 8 * hi;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int s = NC2 + jj;
+        bn_wait_vmcnt_n(wait_n(s));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_step(s + 3);
+        if (jj < 12) issue_res(jj + 4);
+        asm volatile("" ::: "memory");
+        const char* stg = ring + (s & 3) * k8Stage;
+        float16v acc3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const half8 fw = *reinterpret_cast<const half8*>(stg + (kk >> 2) * 4096 + b_off[kk & 3]);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, t2f[kk], acc3, 0, 0, 0);
+        }
+        unsigned int u[16];
+        bn_swap(acc3, u);
+        half8 outf[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int c0 = 32 * jj + 16 * g + 8 * hi;
+            const float4v blo = *reinterpret_cast<const float4v*>(bl + c0);
+            const float4v bhi = *reinterpret_cast<const float4v*>(bl + c0 + 4);
+            float4v lo, hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = __uint_as_float(u[8 * g + e]) + blo[e];
+                hv[e] = __uint_as_float(u[8 * g + 4 + e]) + bhi[e];
+            }
+            const uint4v rr = jj < 4 ? __builtin_bit_cast(uint4v, resr[jj & 3][g])
+                                     : *reinterpret_cast<const uint4v*>(rring + (jj % 5) * 2048 + g * 1024 + lane * 16);
+            lo[0] = bn_mix_add_lo(rr[0], lo[0]);
+            lo[1] = bn_mix_add_hi(rr[0], lo[1]);
+            lo[2] = bn_mix_add_lo(rr[1], lo[2]);
+            lo[3] = bn_mix_add_hi(rr[1], lo[3]);
+            hv[0] = bn_mix_add_lo(rr[2], hv[0]);
+            hv[1] = bn_mix_add_hi(rr[2], hv[1]);
+            hv[2] = bn_mix_add_lo(rr[3], hv[2]);
+            hv[3] = bn_mix_add_hi(rr[3], hv[3]);
+            const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
+            half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+            o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
+            outf[g] = o;
+            if (valid) *reinterpret_cast<half8*>(orow + 32 * jj + 16 * g) = o;
+        }
+        if (TAIL) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const half8 fw = *reinterpret_cast<const half8*>(stg + 8192 + j * 2048 + frow * 64 + (((2 * g + hi) ^ ((frow >> 2) & 3)) << 4));
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, outf[g], acc1[j], 0, 0, 0);
+                }
+        }
+        asm volatile("" ::: "memory");
+    }
+
+    if (TAIL) {
+        half_t* const trow = p.t1n + ((long)gr * p.W + gx) * 128 + 8 * hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int u[16];
+            bn_swap(acc1[j], u);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4v blo = *reinterpret_cast<const float4v*>(bl + 640 + 32 * j + 16 * g + 8 * hi);
+                const float4v bhi = *reinterpret_cast<const float4v*>(bl + 640 + 32 * j + 16 * g + 8 * hi + 4);
+                float4v lo, hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = __uint_as_float(u[8 * g + e]) + blo[e];
+                    hv[e] = __uint_as_float(u[8 * g + 4 + e]) + bhi[e];
+                }
+                const half4 hlo = __builtin_convertvector(lo, half4), hhi = __builtin_convertvector(hv, half4);
+                half8 o = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
+                if (valid) *reinterpret_cast<half8*>(trow + 32 * j + 16 * g) = o;
+            }
+        }
+    }
+}
+
+template <bool CONV2, bool TAIL>
+int bn128_launch(const Bneck128Params& p, hipStream_t s) {
+    static_assert(k8Bytes <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck128_tail_kernel<CONV2, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, k8Bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((bneck128_tail_kernel<CONV2, TAIL>), dim3(p.ntiles), dim3(512), k8Bytes, s, p);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
 }  // namespace
 
 // The shape rule: the map is at least as large as conv3x3.hip asks for its patch kernels (W within 1/8 of a multiple of 32, 512
@@ -426,4 +741,29 @@ int dvid_bneck64_tail_launch(const half_t* t1, const half_t* w2, const float* b2
     p.ntiles = p.tiles_x * ceil_div(p.nrows, TH);
     if (ws) return w1n ? bn_launch<true, true>(p, s) : bn_launch<true, false>(p, s);
     return w1n ? bn_launch<false, true>(p, s) : bn_launch<false, false>(p, s);
+}
+
+// 128-wide blocks (res3).  w2 == null: `t1` is the conv2 output (the block's conv2 ran as its own launch); w1n == null: no next conv1.
+int dvid_bneck128_tail_launch(const half_t* t1, const half_t* w2, const float* b2, const half_t* w3, const float* b3, const half_t* res,
+                              const half_t* w1n, const float* b1n, half_t* out, half_t* t1n, int n, int H, int W, hipStream_t s) {
+    if (!t1 || !w3 || !b3 || !res || !out || n <= 0 || H <= 0 || W <= 0) return DVID_ERR_ARG;
+    if ((w2 && !b2) || (w1n && (!b1n || !t1n))) return DVID_ERR_ARG;
+    Bneck128Params p;
+    p.t1 = t1;
+    p.w2 = w2;
+    p.b2 = b2 ? b2 : b3;          // (the bias piece is fetched either way)
+    p.w3 = w3;
+    p.b3 = b3;
+    p.res = res;
+    p.w1n = w1n;
+    p.b1n = b1n;
+    p.out = out;
+    p.t1n = t1n;
+    p.H = H;
+    p.W = W;
+    p.nrows = n * H;
+    p.tiles_x = ceil_div(W, TW);
+    p.ntiles = p.tiles_x * ceil_div(p.nrows, TH);
+    if (w2) return w1n ? bn128_launch<true, true>(p, s) : bn128_launch<true, false>(p, s);
+    return w1n ? bn128_launch<false, true>(p, s) : bn128_launch<false, false>(p, s);
 }

@@ -113,6 +113,28 @@ int bneck_tail(const half_t* t1, const half_t* w2, const float* b2, const half_t
     return rc;
 }
 
+int bneck128_tail(const half_t* t1, const half_t* w2, const float* b2, const half_t* w3, const float* b3, const half_t* res, const half_t* w1n,
+                  const float* b1n, half_t* out, half_t* t1n, int n, int H, int W, hipStream_t s) {
+    if (!g_prof_on) return dvid_bneck128_tail_launch(t1, w2, b2, w3, b3, res, w1n, b1n, out, t1n, n, H, W, s);
+    ProfRec r;
+    if (prof_take(&r) != DVID_OK) return DVID_ERR_HIP;
+    const double M = (double)n * H * W;
+    const int kk = (w2 ? 1152 : 0) + 512 + (w1n ? 512 : 0);            // MACs per pixel / 128
+    r.flop = 2.0 * M * 128.0 * kk;
+    r.bytes = M * 2.0 * (128 + 512 + 512 + (w1n ? 128 : 0)) + 2.0 * 128 * kk;
+    r.M = (int)M;
+    r.N = 512;
+    r.K = kk;
+    r.taps = w2 ? 9 : 1;
+    r.stride = 1;
+    r.res_mode = 3;
+    HIP_TRY(hipEventRecord(r.a, s));
+    const int rc = dvid_bneck128_tail_launch(t1, w2, b2, w3, b3, res, w1n, b1n, out, t1n, n, H, W, s);
+    HIP_TRY(hipEventRecord(r.b, s));
+    prof_push(r);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 struct HostTensor {
     std::vector<float> v;
@@ -487,6 +509,25 @@ bool bneck64_stage(const std::vector<Block>& blocks) {
         if (k.c3.kh != 1 || k.c3.stride != 1 || k.c3.cin != 64 || k.c3.cout != 256 || k.c3.kpad != 64 || !k.c3.bias) return false;
         if (k.has_sc != (b == 0)) return false;
         if (k.has_sc && (k.sc.kh != 1 || k.sc.stride != 1 || k.sc.cin != 64 || k.sc.cout != 256 || k.sc.kpad != 64 || !k.sc.bias)) return false;
+    }
+    return true;
+}
+
+// res3 of R-50 / R-101: 128-wide bottlenecks with 512 outputs; the first block has the stride and a shortcut convolution, the others
+// are stride-1 identity blocks
+bool bneck128_stage(const std::vector<Block>& blocks) {
+    if (blocks.size() < 2) return false;
+    for (size_t b = 0; b < blocks.size(); ++b) {
+        const Block& k = blocks[b];
+        if (k.c3.kh != 1 || k.c3.stride != 1 || k.c3.cin != 128 || k.c3.cout != 512 || k.c3.kpad != 128 || !k.c3.bias) return false;
+        if (k.c2.kh != 3 || k.c2.kw != 3 || k.c2.pad != 1 || k.c2.cin != 128 || k.c2.cout != 128 || k.c2.kpad != 1152 || !k.c2.bias) return false;
+        if (k.has_sc != (b == 0)) return false;
+        if (b == 0) {
+            if (k.sc.cout != 512) return false;
+            continue;
+        }
+        if (k.c1.kh != 1 || k.c1.stride != 1 || k.c1.cin != 512 || k.c1.cout != 128 || k.c1.kpad != 512 || !k.c1.bias) return false;
+        if (k.c2.stride != 1) return false;
     }
     return true;
 }
@@ -1065,6 +1106,39 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
                 sw[st] = w;
                 continue;
             }
+            // res3 (128-wide): the first block's conv1 / strided conv2 / shortcut as their own launches, then one launch per block for
+            // conv3 + residual + ReLU + the next block's conv1 (+ the next block's conv2 in front of them)
+            if (st == 1 && bneck128_stage(m->blocks[1])) {
+                const Block& b0 = m->blocks[1][0];
+                auto osz = [](const ConvW& c, int v) { return (v + 2 * c.pad - c.kh) / c.stride + 1; };
+                if (dvid_bneck64_tail_preferred(osz(b0.c2, osz(b0.c1, h)), osz(b0.c2, osz(b0.c1, w)))) {
+                    int h2 = h, w2 = w;
+                    TRY(conv_run(b0.c1, cur, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs, &h2, &w2));
+                    const int h1 = h2, w1 = w2;
+                    TRY(conv_run(b0.c2, t1, nf, h1, w1, t2, 1, 0, nullptr, 0, 0, cs, &h2, &w2));
+                    TRY(conv_run(b0.sc, cur, nf, h, w, sc, 0, 0, nullptr, 0, 0, cs));
+                    h = h2;
+                    w = w2;
+                    half_t* ta = t1;                      // free again: conv2 has consumed it
+                    half_t* tb = t2;
+                    half_t* dst = cur == bx ? by : bx;
+                    TRY(bneck128_tail(t2, nullptr, nullptr, b0.c3.w, b0.c3.bias, sc, m->blocks[1][1].c1.w, m->blocks[1][1].c1.bias, dst, ta, nf, h,
+                                      w, cs));
+                    cur = dst;
+                    for (int b = 1; b < nb; ++b) {
+                        const Block& blk = m->blocks[1][b];
+                        const Block* nxt = b + 1 < nb ? &m->blocks[1][b + 1] : nullptr;
+                        dst = (b == nb - 1 && stage_out[st]) ? stage_out[st] : (cur == bx ? by : bx);
+                        TRY(bneck128_tail(ta, blk.c2.w, blk.c2.bias, blk.c3.w, blk.c3.bias, cur, nxt ? nxt->c1.w : nullptr,
+                                          nxt ? nxt->c1.bias : nullptr, dst, nxt ? tb : nullptr, nf, h, w, cs));
+                        std::swap(ta, tb);
+                        cur = dst;
+                    }
+                    sh[st] = h;
+                    sw[st] = w;
+                    continue;
+                }
+            }
             for (int b = 0; b < nb; ++b) {
                 const Block& blk = m->blocks[st][b];
                 int h2 = h, w2 = w;
@@ -1401,6 +1475,17 @@ int dvid_bottleneck64_tail_f16(const void* t1, const void* w2, const float* b2, 
                               reinterpret_cast<const half_t*>(w1_next), b1_next, reinterpret_cast<half_t*>(out),
                               reinterpret_cast<half_t*>(t1_next), n, h, wd, reinterpret_cast<hipStream_t>(stream));
     if (rc != DVID_OK) FAIL(rc, "bottleneck tail: bad argument (n %d, %d x %d)", n, h, wd);
+    return DVID_OK;
+}
+
+int dvid_bottleneck128_tail_f16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* residual,
+                                const void* w1_next, const float* b1_next, void* out, void* t1_next, int n, int h, int wd, void* stream) {
+    g_err[0] = 0;
+    const int rc = bneck128_tail(reinterpret_cast<const half_t*>(t1), reinterpret_cast<const half_t*>(w2), b2, reinterpret_cast<const half_t*>(w3),
+                                 b3, reinterpret_cast<const half_t*>(residual), reinterpret_cast<const half_t*>(w1_next), b1_next,
+                                 reinterpret_cast<half_t*>(out), reinterpret_cast<half_t*>(t1_next), n, h, wd,
+                                 reinterpret_cast<hipStream_t>(stream));
+    if (rc != DVID_OK) FAIL(rc, "bottleneck tail (128): bad argument (n %d, %d x %d)", n, h, wd);
     return DVID_OK;
 }
 

@@ -81,6 +81,18 @@ def bottleneck64_tail(t1, w2, b2, w3, b3, residual, w_sc=None, b_sc=None, w1n=No
     return out, t1n
 
 
+def bottleneck128_tail(t1, w2, b2, w3, b3, residual, w1n=None, b1n=None):
+    """The 128-wide form (res3; csrc/bneck.hip): t1 fp16 [n,h,w,128] (w2 None: already the conv2 output); packed w2 [128,1152],
+    w3 [512,128], optional next conv1 [128,512]; residual [n,h,w,512].  Returns (out [n,h,w,512], t1_next [n,h,w,128] or None)."""
+    t1 = _cuda(t1, torch.float16)
+    n, h, wd, _ = t1.shape
+    out = torch.empty((n, h, wd, 512), dtype=torch.float16, device=t1.device)
+    t1n = torch.empty((n, h, wd, 128), dtype=torch.float16, device=t1.device) if w1n is not None else None
+    call("dvid_bottleneck128_tail_f16", ptr(t1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(residual), ptr(w1n), ptr(b1n), ptr(out),
+         ptr(t1n), n, h, wd, stream_ptr())
+    return out, t1n
+
+
 def linear(x16, w_packed, kpad, bias, relu=False, out_f32=True):
     rows, k = x16.shape
     y = conv2d_nhwc(x16.view(rows, 1, 1, k), w_packed, kpad, bias, w_packed.shape[0], 1, 1, 1, 0, relu=relu, out_f32=out_f32)

@@ -164,6 +164,13 @@ int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const
 int dvid_bottleneck64_tail_f16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* residual,
                                const void* w_shortcut, const float* b_shortcut, const void* w1_next, const float* b1_next, void* out,
                                void* t1_next, int n, int h, int wd, void* stream);
+/* The same for the 128-wide blocks of res3 (128 -> 128 -> 512; the weights stream through an LDS ring): t1 [n,h,wd,128], w2 [128][1152],
+ * w3 [512][128], residual [n,h,wd,512] (the block input, or the first block's shortcut output), w1_next [128][512], out [n,h,wd,512],
+ * t1_next [n,h,wd,128].  w2 == NULL: `t1` is already the block's conv2 output (res3's first block: its 3x3 / stride-2 conv2 runs through
+ * dvid_conv2d_nhwc_f16).  Bit-identical to the layer-by-layer launches on the igemm2 kernel (dvid_igemm_set_conv3x3(0)); the chunked 3x3
+ * patch kernel sums conv2 in another order. */
+int dvid_bottleneck128_tail_f16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* residual,
+                                const void* w1_next, const float* b1_next, void* out, void* t1_next, int n, int h, int wd, void* stream);
 /* MFMA attention, head_dim 32: fp16 q/k/v with head h at columns [32h, 32h+32) of each row, fp16 out;
  * vt_scratch: >= batch*nheads*32*(round_up(lk,32)+32) halves (receives V transposed per head). */
 int dvid_mha_f16(const void* q, const void* k, const void* v, void* out, void* vt_scratch, int batch, int lq, int lk, int nheads,
@@ -209,10 +216,10 @@ int dvid_igemm_set_conv3x3(int mode);
  * Bit-identical to igemm2. */
 int dvid_igemm_set_wstat(int mode);
 
-/* res2 bottleneck blocks behind their conv1 as one launch each (csrc/bneck.hip: dvid_bottleneck64_tail_f16 inside the ResNet
- * backbone): 1 = where the shape rule of the 3x3 patch kernels holds for the res2 map (a function of the image size only), 2 = whenever
- * the stage is 64 -> 64 -> 256 bottlenecks (tests), 0 = off (layer-by-layer launches), -1 = follow DVID_BNECK_FUSE (default 1).
- * Bit-identical to the layer-by-layer launches. */
+/* res2 / res3 bottleneck blocks behind their conv1 as one launch each (csrc/bneck.hip: dvid_bottleneck64_tail_f16 /
+ * dvid_bottleneck128_tail_f16 inside the ResNet backbone): 1 = where the shape rule of the 3x3 patch kernels holds for the stage's map
+ * (a function of the image size only), 2 = whenever the stage is made of such bottlenecks (tests), 0 = off (layer-by-layer launches),
+ * -1 = follow DVID_BNECK_FUSE (default 1).  res2: bit-identical to the layer-by-layer launches; res3: to those on igemm2 (see above). */
 int dvid_igemm_set_bottleneck_fusion(int mode);
 
 /* When enabled, every igemm launch is bracketed by HIP events on its stream; dvid_profile_read

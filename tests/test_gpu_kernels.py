@@ -543,27 +543,76 @@ def test_backbone_small(dv):
     model.close()
 
 
+@pytest.mark.parametrize("geom", [(3, 16, 64), (2, 19, 40), (1, 8, 32), (5, 38, 96), (2, 76, 128), (1, 7, 20)])
+@pytest.mark.parametrize("variant", ["conv2+next", "conv2", "next", "plain"])
+def test_bottleneck128_tail_matches_layers(dv, geom, variant):
+    """The 128-wide form (res3): conv2 3x3 -> conv3 + residual + ReLU -> the next block's conv1 in one launch with the weights
+    streamed through an LDS ring, against the same layers run one by one on the igemm2 kernel (the chunked 3x3 patch kernel sums in
+    another order) -- bit for bit -- and against torch on the same fp16-rounded operands.  Variants: with / without the block's conv2
+    in the launch (res3's first block hands in its strided conv2's output), with / without the next conv1."""
+    from diffusionvid_amd import _lib
+    lib = _lib.load()
+    n, hh, ww = geom
+    c2, tail = variant.startswith("conv2"), variant.endswith("next")
+    g = torch.Generator().manual_seed(n * 1000 + hh * 10 + ww + len(variant))
+    res = h16(torch.randn(n, hh, ww, 512, generator=g))
+    t1 = h16(torch.randn(n, hh, ww, 128, generator=g).clamp_min(0))      # conv1 output (or, without conv2, the conv2 output)
+    w2 = h16(torch.randn(128, 128, 3, 3, generator=g) * (1.5 / 1152 ** 0.5))
+    w3 = h16(torch.randn(512, 128, generator=g) * (1.5 / 128 ** 0.5))
+    w1n = h16(torch.randn(128, 512, generator=g) * (1.5 / 512 ** 0.5))
+    b2, b3, b1n = (torch.randn(c, generator=g) * 0.3 for c in (128, 512, 128))
+    t2 = h16(F.relu(F.conv2d(t1.permute(0, 3, 1, 2), w2, b2, padding=1))) if c2 else t1.permute(0, 3, 1, 2)
+    out_ref = h16(F.relu(F.conv2d(t2, w3[:, :, None, None], b3) + res.permute(0, 3, 1, 2)))
+    t1n_ref = F.relu(F.conv2d(out_ref, w1n[:, :, None, None], b1n))
+    (w2p, k2), (w3p, k3), (w1p, k1) = (dv.pack_conv_weight(w) for w in (w2, w3, w1n))
+    assert (k2, k3, k1) == (1152, 128, 512)
+    resd, t1d = res.to(torch.float16).cuda(), t1.to(torch.float16).cuda()
+    w2d, w3d, w1d, b2d, b3d, b1d = w2p.cuda(), w3p.cuda(), w1p.cuda(), b2.cuda(), b3.cuda(), b1n.cuda()
+    try:
+        _lib.check(lib.dvid_igemm_set_conv3x3(0), "set_conv3x3")
+        t2d = dv.conv2d_nhwc(t1d, w2d, k2, b2d, 128, 3, 3, 1, 1, relu=True) if c2 else t1d
+    finally:
+        lib.dvid_igemm_set_conv3x3(-1)
+    out_l = dv.conv2d_nhwc(t2d, w3d, k3, b3d, 512, 1, 1, 1, 0, relu=True, residual=resd, residual_mode=1)
+    t1n_l = dv.conv2d_nhwc(out_l, w1d, k1, b1d, 128, 1, 1, 1, 0, relu=True)
+    out_f, t1n_f = dv.bottleneck128_tail(t1d, w2d if c2 else None, b2d if c2 else None, w3d, b3d, resd, w1d if tail else None,
+                                         b1d if tail else None)
+    torch.cuda.synchronize()
+    check("bneck128 out", out_f, out_ref.permute(0, 2, 3, 1), 2e-3, 2e-3)
+    print("bneck128 vs layers: out identical %.6f" % (out_f == out_l).float().mean().item())
+    assert torch.equal(out_f, out_l)
+    if tail:
+        check("bneck128 t1_next", t1n_f, t1n_ref.permute(0, 2, 3, 1), 2e-3, 2e-3)
+        print("bneck128 vs layers: t1_next identical %.6f" % (t1n_f == t1n_l).float().mean().item())
+        assert torch.equal(t1n_f, t1n_l)
+    else:
+        assert t1n_f is None
+
+
 @pytest.mark.parametrize("size", [(128, 192), (256, 512), (608, 1024)])
 def test_backbone_bottleneck_fusion_bit_identical(dv, size):
-    """The ResNet-FPN backbone with res2's blocks as one launch each behind conv1 (csrc/bneck.hip) against the same backbone with
+    """The ResNet-FPN backbone with res2's and res3's blocks as one launch each behind conv1 (csrc/bneck.hip) against the same backbone with
     layer-by-layer launches: p3 / p4 / p5 bit for bit, at a size the shape rule skips (forced on), a mid size and the bench's frame
     size; 3 frames, so the patch rows of res2 straddle images.  The fused run is also checked against the CPU oracle at the small size."""
     from diffusionvid_amd import _lib
     from diffusionvid_amd.utils import synthetic
     lib = _lib.load()
-    blocks = (3, 1, 1, 1)
+    blocks = (3, 4, 1, 1)
     sd = synthetic.make_state_dict(3, blocks=blocks)
     g = torch.Generator().manual_seed(size[0])
     imgs = torch.rand(3, 3, size[0], size[1], generator=g)
     model = dv.Model(sd, res_blocks=blocks)
     model.reserve(3, size[0], size[1], 300)
     try:
+        # the 3x3 layers on igemm2 in both runs: the fused res3 blocks sum their conv2 in igemm2's order, the patch kernel in another
+        _lib.check(lib.dvid_igemm_set_conv3x3(0), "set_conv3x3")
         _lib.check(lib.dvid_igemm_set_bottleneck_fusion(2), "set_bottleneck_fusion")
         fused = [t.clone() for t in model.backbone(imgs.cuda())]
         _lib.check(lib.dvid_igemm_set_bottleneck_fusion(0), "set_bottleneck_fusion")
         plain = [t.clone() for t in model.backbone(imgs.cuda())]
     finally:
         lib.dvid_igemm_set_bottleneck_fusion(-1)
+        lib.dvid_igemm_set_conv3x3(-1)
     torch.cuda.synchronize()
     for name, a, b in zip(("p3", "p4", "p5"), fused, plain):
         print("fused vs layer by layer %s: identical %.6f" % (name, (a == b).float().mean().item()))
