@@ -66,7 +66,7 @@ if res["FETCH_SIZE"][1] and res["WRITE_SIZE"][1]:
     fetch = res["FETCH_SIZE"][0] / res["FETCH_SIZE"][1] * 1024 * 2       # KiB units; gfx950 counts 128-B requests at 64 B
     write = res["WRITE_SIZE"][0] / res["WRITE_SIZE"][1] * 1024
     same = json.loads([l for l in open("/tmp/prof_FETCH_SIZE.log") if l.startswith('{"metric"')][-1])["roofline"]
-    json.dump({"kernel": "implicit-GEMM kernels (igemm2_kernel + conv3x3_* + wstat*_kernel; all instantiations)", "launches": int(res["FETCH_SIZE"][1]),
+    json.dump({"kernel": "implicit-GEMM kernels (igemm2_kernel + conv3x3_* + wstat*_kernel + bneck*_tail_kernel; all instantiations)", "launches": int(res["FETCH_SIZE"][1]),
                "configuration": suf,
                "alg_bytes_per_launch_same_run": same["layerwise_alg_mbytes_per_launch"] * 1e6,
                "mfma_busy_fraction": mfma_busy,
