@@ -56,7 +56,7 @@ SIGNATURES = {
     "dvid_fps_greedy": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dvid_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dvid_conv2d_nhwc_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
-    "dvid_bottleneck64_tail_f16": (c_int, [c_void_p] * 12 + [c_int] * 3 + [c_void_p]),
+    "dvid_bottleneck64_tail_f16": (c_int, [c_void_p] * 10 + [c_int] + [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "dvid_bottleneck128_tail_f16": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "dvid_mha_f16": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_int64] * 3 + [c_void_p]),
     "dvid_dynconv": (c_int, [c_void_p] * 7 + [c_int, c_void_p]),

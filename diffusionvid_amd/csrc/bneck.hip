@@ -19,7 +19,8 @@
 // of the wave's row (16 KB) is requested in the prologue and lands while conv2 runs.
 //
 // LDS (156 KB, one workgroup per CU): t1 halo 10 x 34 pixels x 128 B (48 KB with padding; after conv2 the next conv1's weights) |
-// conv2 weights, 9 taps x [64][64] (72 KB; after conv2 the shortcut weights) | conv3 weights [256][64] (32 KB) | biases (4 KB).
+// conv2 weights, 9 taps x [64][64] (72 KB; after conv2 the shortcut weights, or a 128-channel next conv1's 64 KB) | conv3 weights
+// [256][64] (32 KB) | biases (4 KB).
 //
 // Same MFMA, same K order (tap, then channel, 16 per instruction; transposing a product does not change its sums) and the same
 // epilogue arithmetic (fp32 + bias [+ fp16 residual], round to fp16, ReLU) as the layer-by-layer kernels: bit-identical to them
@@ -76,10 +77,10 @@ struct BneckParams {
     const half_t* res;     // identity block: the block input [rows][W][256]; shortcut block: the block input [rows][W][64]
     const half_t* ws;      // [256][64] shortcut weights (SC)
     const float* bs;
-    const half_t* w1n;     // [64][256] the next block's conv1 (TAIL)
+    const half_t* w1n;     // [TN][256] the next block's conv1
     const float* b1n;
     half_t* out;           // [rows][W][256]
-    half_t* t1n;           // [rows][W][64]
+    half_t* t1n;           // [rows][W][TN]
     int H, W, nrows, tiles_x, ntiles;
 };
 
@@ -102,9 +103,14 @@ __device__ __forceinline__ void bn_swap(const float16v& acc, unsigned int (&u)[1
 }
 
 // SC: the residual is the block's shortcut convolution (1x1, 64 -> 256, no ReLU) of the 64-channel block input, computed here and
-// rounded to fp16 as the layer-by-layer path stores it; TAIL: the next block's conv1 is computed from the block output.
-template <bool SC, bool TAIL>
+// rounded to fp16 as the layer-by-layer path stores it; TN > 0: the next block's conv1 (TN = 64 output channels: the next res2 block;
+// 128: res3's first block, whose 1x1 / stride-1 conv1 reads res2's output) is computed from the block output.
+template <bool SC, int TN>
 __global__ __launch_bounds__(512) void bneck64_tail_kernel(BneckParams p) {
+    constexpr bool TAIL = TN > 0;
+    constexpr int NT1 = TN > 0 ? TN / 32 : 1;  // accumulator tiles of the next conv1
+    constexpr int kW1 = TN == 128 ? kW2 : kHalo;          // its weights: 4 K chunks of [TN][64]; 64 KB go where the conv2 taps were
+    static_assert(TN == 0 || TN == 64 || (TN == 128 && !SC), "next conv1: 64 channels, or 128 without a shortcut in the same launch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(512) void bneck64_tail_kernel(BneckParams p) {
     // loads included): waves 0-3 fetch b2 / b3 / b1n / bs into 1-KiB slots (lanes past an array's end read the zero page)
     if (wave < 4) {
         const float* src = wave == 0 ? p.b2 : wave == 1 ? p.b3 : wave == 2 ? (TAIL ? p.b1n : nullptr) : (SC ? p.bs : nullptr);
-        const int n16 = (wave & 1) ? 64 : 16;          // float4s in the array
+        const int n16 = (wave & 1) ? 64 : (wave == 2 ? TN / 4 : 16);          // float4s in the array
         bn_glds16(src && lane < n16 ? reinterpret_cast<const char*>(src + lane * 4) : zero, smem + kBias + wave * 1024);
     }
     // ---- DMA group A: the t1 halo (6 pieces per wave) and the conv2 weights of taps 0-2; group B: taps 3-8 and the conv3 weights
@@ -222,7 +228,10 @@ __global__ __launch_bounds__(512) void bneck64_tail_kernel(BneckParams p) {
     if (TAIL) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            bn_glds16(reinterpret_cast<const char*>(p.w1n + (long)wrow * 256 + c * 64 + wlch * 8), smem + kHalo + c * 8192 + wave * 1024);
+#pragma unroll
+            for (int i = 0; i < TN / 64; ++i)
+                bn_glds16(reinterpret_cast<const char*>(p.w1n + (long)(64 * i + wrow) * 256 + c * 64 + wlch * 8),
+                          smem + kW1 + c * (TN * 128) + (8 * i + wave) * 1024);
     }
     if (SC) {
 #pragma unroll
@@ -332,23 +341,23 @@ __global__ __launch_bounds__(512) void bneck64_tail_kernel(BneckParams p) {
 
     // ---- the next block's conv1: K = 256 over the block output held in registers
     if (TAIL) {
-        float16v acc1[2];
+        float16v acc1[NT1];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT1; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const char* wt = smem + kHalo + (k >> 2) * 8192 + b_off[k & 3];
+            const char* wt = smem + kW1 + (k >> 2) * (TN * 128) + b_off[k & 3];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NT1; ++j) {
                 const half8 fw = *reinterpret_cast<const half8*>(wt + j * 4096);
                 acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, outf[k], acc1[j], 0, 0, 0);
             }
         }
-        half_t* const trow = p.t1n + ((long)gr * p.W + gx) * 64 + 8 * hi;
+        half_t* const trow = p.t1n + ((long)gr * p.W + gx) * TN + 8 * hi;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NT1; ++j) {
             unsigned int u[16];
             bn_swap(acc1[j], u);
 #pragma unroll
@@ -370,15 +379,15 @@ __global__ __launch_bounds__(512) void bneck64_tail_kernel(BneckParams p) {
     }
 }
 
-template <bool SC, bool TAIL>
+template <bool SC, int TN>
 int bn_launch(const BneckParams& p, hipStream_t s) {
     static_assert(kBytes <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck64_tail_kernel<SC, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck64_tail_kernel<SC, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((bneck64_tail_kernel<SC, TAIL>), dim3(p.ntiles), dim3(512), kBytes, s, p);
+    hipLaunchKernelGGL((bneck64_tail_kernel<SC, TN>), dim3(p.ntiles), dim3(512), kBytes, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
 }
@@ -717,10 +726,11 @@ bool dvid_bneck64_tail_preferred(int H, int W) {
 }
 
 int dvid_bneck64_tail_launch(const half_t* t1, const half_t* w2, const float* b2, const half_t* w3, const float* b3, const half_t* res,
-                             const half_t* ws, const float* bs, const half_t* w1n, const float* b1n, half_t* out, half_t* t1n, int n, int H,
-                             int W, hipStream_t s) {
+                             const half_t* ws, const float* bs, const half_t* w1n, const float* b1n, int n_next, half_t* out, half_t* t1n,
+                             int n, int H, int W, hipStream_t s) {
     if (!t1 || !w2 || !b2 || !w3 || !b3 || !res || !out || n <= 0 || H <= 0 || W <= 0) return DVID_ERR_ARG;
     if ((ws && !bs) || (w1n && (!b1n || !t1n))) return DVID_ERR_ARG;
+    if (w1n && n_next != 64 && !(n_next == 128 && !ws)) return DVID_ERR_UNSUPPORTED;
     BneckParams p;
     p.t1 = t1;
     p.w2 = w2;
@@ -739,8 +749,9 @@ int dvid_bneck64_tail_launch(const half_t* t1, const half_t* w2, const float* b2
     p.nrows = n * H;
     p.tiles_x = ceil_div(W, TW);
     p.ntiles = p.tiles_x * ceil_div(p.nrows, TH);
-    if (ws) return w1n ? bn_launch<true, true>(p, s) : bn_launch<true, false>(p, s);
-    return w1n ? bn_launch<false, true>(p, s) : bn_launch<false, false>(p, s);
+    if (ws) return w1n ? bn_launch<true, 64>(p, s) : bn_launch<true, 0>(p, s);
+    if (!w1n) return bn_launch<false, 0>(p, s);
+    return n_next == 128 ? bn_launch<false, 128>(p, s) : bn_launch<false, 64>(p, s);
 }
 
 // 128-wide blocks (res3).  w2 == null: `t1` is the conv2 output (the block's conv2 ran as its own launch); w1n == null: no next conv1.

@@ -39,8 +39,8 @@ bool dvid_bneck64_tail_preferred(int H, int W);     // the shape rule (a functio
 int dvid_bneck128_tail_launch(const half_t* t1, const half_t* w2, const float* b2, const half_t* w3, const float* b3, const half_t* res,
                               const half_t* w1n, const float* b1n, half_t* out, half_t* t1n, int n, int H, int W, hipStream_t s);
 int dvid_bneck64_tail_launch(const half_t* t1, const half_t* w2, const float* b2, const half_t* w3, const float* b3, const half_t* res,
-                             const half_t* ws, const float* bs, const half_t* w1n, const float* b1n, half_t* out, half_t* t1n, int n, int H,
-                             int W, hipStream_t s);
+                             const half_t* ws, const float* bs, const half_t* w1n, const float* b1n, int n_next, half_t* out, half_t* t1n,
+                             int n, int H, int W, hipStream_t s);      // n_next: rows of w1n (64; 128 without a shortcut)
 
 // elementwise.hip
 // per-frame source pointers of one image-prep launch (passed by value as a kernel argument)

@@ -92,14 +92,15 @@ int igemm(const IgemmParams& p, hipStream_t s) {
 // The fused tail of a res2 bottleneck block (bneck.hip) as one record of the implicit-GEMM family: its algorithmic work is the sum
 // of the products it computes (conv2 + conv3 [+ shortcut] [+ next conv1]), its bytes what the launch touches once.
 int bneck_tail(const half_t* t1, const half_t* w2, const float* b2, const half_t* w3, const float* b3, const half_t* res, const half_t* ws,
-               const float* bs, const half_t* w1n, const float* b1n, half_t* out, half_t* t1n, int n, int H, int W, hipStream_t s) {
-    if (!g_prof_on) return dvid_bneck64_tail_launch(t1, w2, b2, w3, b3, res, ws, bs, w1n, b1n, out, t1n, n, H, W, s);
+               const float* bs, const half_t* w1n, const float* b1n, int n_next, half_t* out, half_t* t1n, int n, int H, int W, hipStream_t s) {
+    if (!g_prof_on) return dvid_bneck64_tail_launch(t1, w2, b2, w3, b3, res, ws, bs, w1n, b1n, n_next, out, t1n, n, H, W, s);
     ProfRec r;
     if (prof_take(&r) != DVID_OK) return DVID_ERR_HIP;
     const double M = (double)n * H * W;
-    const int kk = 576 + 256 + (ws ? 256 : 0) + (w1n ? 256 : 0);        // MACs per pixel / 64
+    const int nn = w1n ? n_next : 0;
+    const int kk = 576 + 256 + (ws ? 256 : 0) + 4 * nn;               // MACs per pixel / 64
     r.flop = 2.0 * M * 64.0 * kk;
-    r.bytes = M * 2.0 * (64 + (ws ? 64 : 256) + 256 + (w1n ? 64 : 0)) + 2.0 * 64 * kk;
+    r.bytes = M * 2.0 * (64 + (ws ? 64 : 256) + 256 + nn) + 2.0 * 64 * kk;
     r.M = (int)M;
     r.N = 256;
     r.K = kk;
@@ -107,7 +108,7 @@ int bneck_tail(const half_t* t1, const half_t* w2, const float* b2, const half_t
     r.stride = 1;
     r.res_mode = ws ? 4 : 3;                  // CSV marker: 3 = fused block tail, 4 = with the shortcut convolution
     HIP_TRY(hipEventRecord(r.a, s));
-    const int rc = dvid_bneck64_tail_launch(t1, w2, b2, w3, b3, res, ws, bs, w1n, b1n, out, t1n, n, H, W, s);
+    const int rc = dvid_bneck64_tail_launch(t1, w2, b2, w3, b3, res, ws, bs, w1n, b1n, n_next, out, t1n, n, H, W, s);
     HIP_TRY(hipEventRecord(r.b, s));
     prof_push(r);
     return rc;
@@ -1083,6 +1084,7 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
         h = (h + 2 - 3) / 2 + 1;
         w = (w + 2 - 3) / 2 + 1;
         half_t* cur = bx;  // block input
+        half_t* res3_t1 = nullptr;
         int sh[4], sw[4];
         for (int st = 0; st < 4; ++st) {
             const int nb = (int)m->blocks[st].size();
@@ -1092,16 +1094,27 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
                 half_t* ta = t1;
                 half_t* tb = t2;
                 TRY(conv_run(m->blocks[0][0].c1, cur, nf, h, w, ta, 1, 0, nullptr, 0, 0, cs));
+                // the last block's launch also computes res3's first conv1 (1x1 / stride 1 over this stage's output, 256 -> 128) when
+                // res3 takes the fused path too: that layer alone re-read the 512 B per pixel this launch has in registers
+                const Block* r3 = nullptr;
+                if (nb > 1 && bneck128_stage(m->blocks[1])) {
+                    const Block& b0 = m->blocks[1][0];
+                    auto osz = [](const ConvW& c, int v) { return (v + 2 * c.pad - c.kh) / c.stride + 1; };
+                    if (b0.c1.kh == 1 && b0.c1.stride == 1 && b0.c1.pad == 0 && b0.c1.cin == 256 && b0.c1.cout == 128 && b0.c1.kpad == 256 &&
+                        b0.c1.bias && dvid_bneck64_tail_preferred(osz(b0.c2, h), osz(b0.c2, w)))
+                        r3 = &b0;
+                }
                 for (int b = 0; b < nb; ++b) {
                     const Block& blk = m->blocks[0][b];
-                    const Block* nxt = b + 1 < nb ? &m->blocks[0][b + 1] : nullptr;
+                    const Block* nxt = b + 1 < nb ? &m->blocks[0][b + 1] : r3;
                     half_t* dst = cur == bx ? by : bx;
                     TRY(bneck_tail(ta, blk.c2.w, blk.c2.bias, blk.c3.w, blk.c3.bias, cur, blk.has_sc ? blk.sc.w : nullptr,
-                                   blk.has_sc ? blk.sc.bias : nullptr, nxt ? nxt->c1.w : nullptr, nxt ? nxt->c1.bias : nullptr, dst,
-                                   nxt ? tb : nullptr, nf, h, w, cs));
+                                   blk.has_sc ? blk.sc.bias : nullptr, nxt ? nxt->c1.w : nullptr, nxt ? nxt->c1.bias : nullptr,
+                                   nxt ? nxt->c1.cout : 0, dst, nxt ? tb : nullptr, nf, h, w, cs));
                     std::swap(ta, tb);
                     cur = dst;
                 }
+                if (r3) res3_t1 = ta;                     // res3's first conv1 output, already computed
                 sh[st] = h;
                 sw[st] = w;
                 continue;
@@ -1113,16 +1126,18 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
                 auto osz = [](const ConvW& c, int v) { return (v + 2 * c.pad - c.kh) / c.stride + 1; };
                 if (dvid_bneck64_tail_preferred(osz(b0.c2, osz(b0.c1, h)), osz(b0.c2, osz(b0.c1, w)))) {
                     int h2 = h, w2 = w;
-                    TRY(conv_run(b0.c1, cur, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs, &h2, &w2));
+                    half_t* c1out = res3_t1 ? res3_t1 : t1;           // (res2's last launch may have computed it)
+                    half_t* c2out = c1out == t1 ? t2 : t1;
+                    if (!res3_t1) TRY(conv_run(b0.c1, cur, nf, h, w, c1out, 1, 0, nullptr, 0, 0, cs, &h2, &w2));
                     const int h1 = h2, w1 = w2;
-                    TRY(conv_run(b0.c2, t1, nf, h1, w1, t2, 1, 0, nullptr, 0, 0, cs, &h2, &w2));
+                    TRY(conv_run(b0.c2, c1out, nf, h1, w1, c2out, 1, 0, nullptr, 0, 0, cs, &h2, &w2));
                     TRY(conv_run(b0.sc, cur, nf, h, w, sc, 0, 0, nullptr, 0, 0, cs));
                     h = h2;
                     w = w2;
-                    half_t* ta = t1;                      // free again: conv2 has consumed it
-                    half_t* tb = t2;
+                    half_t* ta = c1out;                   // free again: conv2 has consumed it
+                    half_t* tb = c2out;
                     half_t* dst = cur == bx ? by : bx;
-                    TRY(bneck128_tail(t2, nullptr, nullptr, b0.c3.w, b0.c3.bias, sc, m->blocks[1][1].c1.w, m->blocks[1][1].c1.bias, dst, ta, nf, h,
+                    TRY(bneck128_tail(c2out, nullptr, nullptr, b0.c3.w, b0.c3.bias, sc, m->blocks[1][1].c1.w, m->blocks[1][1].c1.bias, dst, ta, nf, h,
                                       w, cs));
                     cur = dst;
                     for (int b = 1; b < nb; ++b) {
@@ -1467,14 +1482,14 @@ int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const
 }
 
 int dvid_bottleneck64_tail_f16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* residual,
-                               const void* w_shortcut, const float* b_shortcut, const void* w1_next, const float* b1_next, void* out,
-                               void* t1_next, int n, int h, int wd, void* stream) {
+                               const void* w_shortcut, const float* b_shortcut, const void* w1_next, const float* b1_next, int next_channels,
+                               void* out, void* t1_next, int n, int h, int wd, void* stream) {
     g_err[0] = 0;
     const int rc = bneck_tail(reinterpret_cast<const half_t*>(t1), reinterpret_cast<const half_t*>(w2), b2, reinterpret_cast<const half_t*>(w3),
                               b3, reinterpret_cast<const half_t*>(residual), reinterpret_cast<const half_t*>(w_shortcut), b_shortcut,
-                              reinterpret_cast<const half_t*>(w1_next), b1_next, reinterpret_cast<half_t*>(out),
+                              reinterpret_cast<const half_t*>(w1_next), b1_next, next_channels, reinterpret_cast<half_t*>(out),
                               reinterpret_cast<half_t*>(t1_next), n, h, wd, reinterpret_cast<hipStream_t>(stream));
-    if (rc != DVID_OK) FAIL(rc, "bottleneck tail: bad argument (n %d, %d x %d)", n, h, wd);
+    if (rc != DVID_OK) FAIL(rc, "bottleneck tail: bad argument (n %d, %d x %d, next conv1 with %d channels)", n, h, wd, next_channels);
     return DVID_OK;
 }
 

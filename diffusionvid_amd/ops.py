@@ -70,14 +70,15 @@ def conv2d_nhwc(x, w_packed, kpad, bias, cout, kh, kw, stride, pad, relu=False, 
 
 def bottleneck64_tail(t1, w2, b2, w3, b3, residual, w_sc=None, b_sc=None, w1n=None, b1n=None):
     """Everything behind conv1 of a res2 bottleneck block as one launch (csrc/bneck.hip): t1 fp16 [n,h,w,64]; packed weights w2
-    [64,576], w3 [256,64], optional shortcut [256,64] (then `residual` is the 64-channel block input) and next conv1 [64,256].
-    Returns (out [n,h,w,256], t1_next [n,h,w,64] or None)."""
+    [64,576], w3 [256,64], optional shortcut [256,64] (then `residual` is the 64-channel block input) and next conv1 [64 or 128, 256].
+    Returns (out [n,h,w,256], t1_next [n,h,w,64 or 128] or None)."""
     t1 = _cuda(t1, torch.float16)
     n, h, wd, _ = t1.shape
+    nn = int(w1n.shape[0]) if w1n is not None else 0
     out = torch.empty((n, h, wd, 256), dtype=torch.float16, device=t1.device)
-    t1n = torch.empty((n, h, wd, 64), dtype=torch.float16, device=t1.device) if w1n is not None else None
+    t1n = torch.empty((n, h, wd, nn), dtype=torch.float16, device=t1.device) if w1n is not None else None
     call("dvid_bottleneck64_tail_f16", ptr(t1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(residual), ptr(w_sc), ptr(b_sc), ptr(w1n),
-         ptr(b1n), ptr(out), ptr(t1n), n, h, wd, stream_ptr())
+         ptr(b1n), nn, ptr(out), ptr(t1n), n, h, wd, stream_ptr())
     return out, t1n
 
 

@@ -156,14 +156,15 @@ int dvid_conv2d_nhwc_f16(const void* in, const void* w, const float* bias, const
                          int wd, int cin, int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int out_f32,
                          int residual_mode, void* stream);
 /* Everything behind conv1 of a res2 bottleneck block (detectron2 BottleneckBlock, widths 64 -> 64 -> 256, stride 1) as one launch:
- * conv2 3x3 + ReLU, conv3 1x1 + residual + ReLU and -- w1_next != NULL -- the next block's conv1 256 -> 64 + ReLU.  t1 [n,h,wd,64] is
- * the block's conv1 output; w2 [64][576], w3 [256][64], w1_next [64][256] in dvid_conv2d_nhwc_f16's packing (FrozenBN folded, biases
- * fp32).  w_shortcut == NULL: `residual` is the block input [n,h,wd,256]; else `residual` is the 64-channel block input [n,h,wd,64]
- * and the residual is its shortcut convolution w_shortcut [256][64].  out [n,h,wd,256], t1_next [n,h,wd,64] (must not alias t1).
- * Bit-identical to the same layers run through dvid_conv2d_nhwc_f16 (csrc/bneck.hip). */
+ * conv2 3x3 + ReLU, conv3 1x1 + residual + ReLU and -- w1_next != NULL -- the next block's conv1 256 -> next_channels + ReLU
+ * (next_channels 64: the next res2 block; 128, without a shortcut in the same launch: res3's first block).  t1 [n,h,wd,64] is the
+ * block's conv1 output; w2 [64][576], w3 [256][64], w1_next [next_channels][256] in dvid_conv2d_nhwc_f16's packing (FrozenBN folded,
+ * biases fp32).  w_shortcut == NULL: `residual` is the block input [n,h,wd,256]; else `residual` is the 64-channel block input
+ * [n,h,wd,64] and the residual is its shortcut convolution w_shortcut [256][64].  out [n,h,wd,256], t1_next [n,h,wd,next_channels]
+ * (must not alias t1).  Bit-identical to the same layers run through dvid_conv2d_nhwc_f16 (csrc/bneck.hip). */
 int dvid_bottleneck64_tail_f16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* residual,
-                               const void* w_shortcut, const float* b_shortcut, const void* w1_next, const float* b1_next, void* out,
-                               void* t1_next, int n, int h, int wd, void* stream);
+                               const void* w_shortcut, const float* b_shortcut, const void* w1_next, const float* b1_next, int next_channels,
+                               void* out, void* t1_next, int n, int h, int wd, void* stream);
 /* The same for the 128-wide blocks of res3 (128 -> 128 -> 512; the weights stream through an LDS ring): t1 [n,h,wd,128], w2 [128][1152],
  * w3 [512][128], residual [n,h,wd,512] (the block input, or the first block's shortcut output), w1_next [128][512], out [n,h,wd,512],
  * t1_next [n,h,wd,128].  w2 == NULL: `t1` is already the block's conv2 output (res3's first block: its 3x3 / stride-2 conv2 runs through

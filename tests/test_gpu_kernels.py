@@ -857,14 +857,15 @@ def test_conv4x4_s2d_stem_kernel(dv, shape):
 
 
 @pytest.mark.parametrize("geom", [(3, 16, 64), (2, 19, 40), (1, 8, 32), (5, 38, 96), (2, 152, 256), (1, 7, 20)])
-@pytest.mark.parametrize("variant", ["shortcut+next", "identity+next", "identity", "shortcut"])
+@pytest.mark.parametrize("variant", ["shortcut+next", "identity+next", "identity", "shortcut", "identity+next128"])
 def test_bottleneck_tail_matches_layers(dv, geom, variant):
     """csrc/bneck.hip (conv2 3x3 -> conv3 + shortcut / residual + ReLU -> the next block's conv1 in one launch, intermediates in
     registers) against the same layers run one by one through dvid_conv2d_nhwc_f16 -- bit for bit -- and against torch on the same
     fp16-rounded operands.  Geometries: several images per launch (patch rows straddle images), heights that are not a multiple
     of 8, widths that are not a multiple of 32, a single-patch map, the bench's 152 x 256 map."""
     n, hh, ww = geom
-    sc, tail = variant.startswith("shortcut"), variant.endswith("next")
+    sc, tail = variant.startswith("shortcut"), "next" in variant
+    nn = 128 if variant.endswith("128") else 64          # next conv1: a res2 block's (64) or res3's first (128)
     g = torch.Generator().manual_seed(n * 1000 + hh * 10 + ww + len(variant))
     cin = 64 if sc else 256
     x = h16(torch.randn(n, hh, ww, cin, generator=g))                   # block input
@@ -872,8 +873,8 @@ def test_bottleneck_tail_matches_layers(dv, geom, variant):
     w2 = h16(torch.randn(64, 64, 3, 3, generator=g) * (1.5 / 576 ** 0.5))
     w3 = h16(torch.randn(256, 64, generator=g) * (1.5 / 8))
     wsc = h16(torch.randn(256, 64, generator=g) * (1.5 / 8))
-    w1n = h16(torch.randn(64, 256, generator=g) * (1.5 / 16))
-    b2, b3, bsc, b1n = (torch.randn(c, generator=g) * 0.3 for c in (64, 256, 256, 64))
+    w1n = h16(torch.randn(nn, 256, generator=g) * (1.5 / 16))
+    b2, b3, bsc, b1n = (torch.randn(c, generator=g) * 0.3 for c in (64, 256, 256, nn))
     # torch reference on the same operands (fp32), rounding where the layer-by-layer path stores fp16
     t2 = h16(F.relu(F.conv2d(t1.permute(0, 3, 1, 2), w2, b2, padding=1)))
     y = F.conv2d(t2, w3[:, :, None, None], b3)
@@ -892,7 +893,7 @@ def test_bottleneck_tail_matches_layers(dv, geom, variant):
     t2d = dv.conv2d_nhwc(t1d, w2d, k2, b2d, 64, 3, 3, 1, 1, relu=True)
     resd = dv.conv2d_nhwc(xd, wsd, ks, bsd, 256, 1, 1, 1, 0) if sc else xd
     out_l = dv.conv2d_nhwc(t2d, w3d, k3, b3d, 256, 1, 1, 1, 0, relu=True, residual=resd, residual_mode=1)
-    t1n_l = dv.conv2d_nhwc(out_l, w1d, k1, b1d, 64, 1, 1, 1, 0, relu=True)
+    t1n_l = dv.conv2d_nhwc(out_l, w1d, k1, b1d, nn, 1, 1, 1, 0, relu=True)
     # one launch
     out_f, t1n_f = dv.bottleneck64_tail(t1d, w2d, b2d, w3d, b3d, xd, wsd if sc else None, bsd if sc else None,
                                         w1d if tail else None, b1d if tail else None)

@@ -35,14 +35,19 @@ def main():
     (w2p, k2), (w3p, k3), (wsp, ks), (w1p, k1) = (dv.pack_conv_weight(w) for w in (w2, w3, wsc, w1n))
     w2d, w3d, wsd, w1d = w2p.cuda(), w3p.cuda(), wsp.cuda(), w1p.cuda()
     b2, b3, bs, b1 = (torch.randn(c, generator=g).cuda() * 0.3 for c in (64, 256, 256, 64))
-    for sc, tail in ((False, True), (False, False), (True, True)):
+    w1n128 = torch.randn(128, 256, generator=g) * (1.5 / 16)
+    w1p128, k1b = dv.pack_conv_weight(w1n128)
+    w1d128, b1128 = w1p128.cuda(), torch.randn(128, generator=g).cuda() * 0.3
+    for sc, tail in ((False, True), (False, False), (True, True), (False, 128)):
         xin = x64 if sc else x256
+        if tail == 128:
+            w1d, b1, k1 = w1d128, b1128, k1b
 
         def layers():
             t2 = dv.conv2d_nhwc(t1, w2d, k2, b2, 64, 3, 3, 1, 1, relu=True)
             res = dv.conv2d_nhwc(xin, wsd, ks, bs, 256, 1, 1, 1, 0) if sc else xin
             out = dv.conv2d_nhwc(t2, w3d, k3, b3, 256, 1, 1, 1, 0, relu=True, residual=res, residual_mode=1)
-            return out, (dv.conv2d_nhwc(out, w1d, k1, b1, 64, 1, 1, 1, 0, relu=True) if tail else None)
+            return out, (dv.conv2d_nhwc(out, w1d, k1, b1, int(w1d.shape[0]), 1, 1, 1, 0, relu=True) if tail else None)
 
         def fused():
             return dv.bottleneck64_tail(t1, w2d, b2, w3d, b3, xin, wsd if sc else None, bs if sc else None, w1d if tail else None,
@@ -54,9 +59,10 @@ def main():
         same = torch.equal(ol, of) and (not tail or torch.equal(tl, tf))
         del ol, tl, of, tf
         ms_l, ms_f = timed(layers), timed(fused)
-        by_f = px * 2.0 * (64 + (64 if sc else 256) + 256 + (64 if tail else 0))
-        by_l = px * 2.0 * (64 + 64 + 64 + 256 + 256 + (64 + 256 if sc else 256) + ((256 + 64) if tail else 0))
-        print("frames %d shortcut %d next_conv1 %d: layer by layer %.3f ms (%.0f GB/s of its bytes), one launch %.3f ms (%.0f GB/s of its "
+        nn = int(w1d.shape[0]) if tail else 0
+        by_f = px * 2.0 * (64 + (64 if sc else 256) + 256 + nn)
+        by_l = px * 2.0 * (64 + 64 + 64 + 256 + 256 + (64 + 256 if sc else 256) + ((256 + nn) if tail else 0))
+        print("res2 frames %d shortcut %d next_conv1 %d: layer by layer %.3f ms (%.0f GB/s of its bytes), one launch %.3f ms (%.0f GB/s of its "
               "bytes), x%.2f, identical %s" % (n, sc, tail, ms_l, by_l / ms_l / 1e6, ms_f, by_f / ms_f / 1e6, ms_l / ms_f, same), flush=True)
 
 
