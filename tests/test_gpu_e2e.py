@@ -504,6 +504,20 @@ def test_lookahead_invariance_full_size(arch, sample_step, groups, frames):
         torch.cuda.empty_cache()
     for la in groups:
         worst = 0.0
+        # which frames differ and by how much, before any assertion stops the comparison (a failure names the frames: a launch
+        # group, a video boundary, a single frame each point at different stages)
+        off = []
+        for f, (a, b) in enumerate(zip(outs[1], outs[la])):
+            if len(a) != len(b):
+                off.append((f, "count %d / %d" % (len(a), len(b))))
+            elif not torch.equal(a.get_field("labels"), b.get_field("labels")) or not torch.equal(a.bbox, b.bbox) or \
+                    not torch.equal(a.get_field("scores"), b.get_field("scores")):
+                off.append((f, "labels differ at %d slots, max |dscore| %.3e, max |dbox| %.3e (boxes sorted by score)" % (
+                    int((a.get_field("labels") != b.get_field("labels")).sum()),
+                    (a.get_field("scores") - b.get_field("scores")).abs().max().item() if len(a) else 0.0,
+                    (a.bbox - b.bbox).abs().max().item() if len(a) else 0.0)))
+        if off:
+            print(f"{arch} x{sample_step}: look-ahead {la} vs 1: {len(off)} of {frames} frames differ: {off[:12]}")
         for a, b in zip(outs[1], outs[la]):
             assert len(a) == len(b)
             assert torch.equal(a.get_field("labels"), b.get_field("labels"))
