@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvid_hip.so")
+LIB_PATH = os.environ.get("DVID_LIB") or os.path.join(_HERE, "libdvid_hip.so")          # DVID_LIB: another build of the library (A/B timing)
 
 c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 c_float_p = C.POINTER(C.c_float)

@@ -157,6 +157,10 @@ struct DevBuf {
         bytes = 0;
         HIP_TRY(hipMalloc(&p, n));
         bytes = n;
+        // DVID_POISON_WORKSPACE=1 (diagnostics): fresh workspace starts as 0xFF bytes (NaN as fp16 / fp32), so a kernel that reads
+        // workspace nothing has written shows up in the results instead of depending on what the allocation held before
+        static const bool poison = getenv("DVID_POISON_WORKSPACE") && atoi(getenv("DVID_POISON_WORKSPACE")) != 0;
+        if (poison) HIP_TRY(hipMemset(p, 0xFF, n));
         return DVID_OK;
     }
     void release() {

@@ -1,10 +1,16 @@
 """Run-to-run determinism of the whole detector on one 120-frame video at INPUT.LOOKAHEAD_BATCHES 15 (the schedule of
 tests/test_gpu_e2e.py::test_lookahead_invariance_full_size): K fresh models, detections compared with the first run's."""
+import os
 import sys
 
 import torch
 
 sys.path.insert(0, ".")
+
+
+if os.environ.get("DVID_POISON_TORCH"):          # torch.empty() tensors start as NaN / max int: reads of memory nothing wrote show up
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
 
 
 def run(la, frames=120):
@@ -81,7 +87,14 @@ def per_config():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "seq":
+    if len(sys.argv) > 1 and sys.argv[1] == "save":          # detections of one look-ahead-13 run to a file (compare across environments)
+        out = run(int(sys.argv[3]) if len(sys.argv) > 3 else 13)
+        torch.save([(o.bbox, o.get_field("scores"), o.get_field("labels")) for o in out], sys.argv[2])
+    elif len(sys.argv) > 1 and sys.argv[1] == "cmp":
+        a, b = torch.load(sys.argv[2]), torch.load(sys.argv[3])
+        bad = [f for f, (x, y) in enumerate(zip(a, b)) if any(p.shape != q.shape or not torch.equal(p, q) for p, q in zip(x, y))]
+        print("%s vs %s: %d of %d frames differ %s" % (sys.argv[2], sys.argv[3], len(bad), len(a), bad[:20]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "seq":
         sequence()
     elif len(sys.argv) > 1 and sys.argv[1] == "cfg":
         per_config()
