@@ -18,7 +18,7 @@
 // trip, no barrier after conv2, residual and outputs move as 16-byte pieces straight from / to the accumulator layout.  The residual
 // of the wave's row (16 KB) is requested in the prologue and lands while conv2 runs.
 //
-// LDS (156 KB, one workgroup per CU): t1 halo 10 x 34 pixels x 128 B (48 KB with padding; after conv2 the next conv1's weights) |
+// LDS (156 KB used, the whole 160 KB requested; one workgroup per CU): t1 halo 10 x 34 pixels x 128 B (48 KB with padding; after conv2 the next conv1's weights) |
 // conv2 weights, 9 taps x [64][64] (72 KB; after conv2 the shortcut weights, or a 128-channel next conv1's 64 KB) | conv3 weights
 // [256][64] (32 KB) | biases (4 KB).
 //
@@ -66,7 +66,13 @@ constexpr int kHalo = 0;                       // ... later the next conv1's wei
 constexpr int kW2 = A_PIECES * 1024;           // 9 taps x [64 out][64 in]; later the shortcut's [256][64]
 constexpr int kW3 = kW2 + 9 * 8192;            // [256][64]
 constexpr int kBias = kW3 + 32768;             // four 1-KiB slots of floats: b2 [64] | b3 [256] | b1n [64] | bs [256]
-constexpr int kBytes = kBias + 4096;
+// The launch asks for ALL of the CU's LDS although kBias + 4096 bytes are used.  With 155 KB a workgroup could share its CU with a small
+// workgroup of another stream's kernel (the farthest-point sweep of the global-memory build is one long-lived workgroup with a few hundred
+// bytes of LDS), i.e. run with a non-zero, non-KiB-aligned LDS base -- and in that situation, and only in it, single patch rows came out
+// wrong about once in ten 24-frame launch sequences (tools/diag_chain_contention.py reproduces it stage by stage; 0 of 420 with the full
+// allocation, which keeps every other LDS-using workgroup off the CU and the base at 0).  The mechanism behind it (LDS-DMA pieces against a
+// misaligned base) was not isolated; the older DMA kernels share CUs only with workgroups of their own launch, at KiB-aligned bases.
+constexpr int kBytes = 160 * 1024;
 
 struct BneckParams {
     const half_t* t1;      // [rows][W][64]   conv1 output (ReLU applied)
@@ -412,7 +418,7 @@ constexpr int H8_PIECES = 88;                  // 1-KiB pieces of 4 pixels: 85 c
 constexpr int k8Ring = H8_PIECES * 1024;
 constexpr int k8Stage = 16384;
 constexpr int k8Bias = k8Ring + 4 * k8Stage;   // floats: b3 [512] | b2 [128] | b1n [128]
-constexpr int k8Bytes = k8Bias + 3072;
+constexpr int k8Bytes = 160 * 1024;           // all of the CU's LDS (k8Bias + 3072 are used): see kBytes
 
 struct Bneck128Params {
     const half_t* t1;      // CONV2: [rows][W][128] conv1 output; else the conv2 output t2
@@ -716,6 +722,11 @@ int dvid_igemm_set_bottleneck_fusion(int mode) {
     if (mode < -1 || mode > 2) return DVID_ERR_ARG;
     g_bneck_mode = mode;
     return DVID_OK;
+}
+// DVID_BNECK_STAGES (diagnostics): bit 0 = res2, bit 1 = res3 take the fused path (default 3)
+bool dvid_bneck_stage_enabled(int stage) {
+    static const int mask = getenv("DVID_BNECK_STAGES") ? atoi(getenv("DVID_BNECK_STAGES")) : 3;
+    return (mask >> stage) & 1;
 }
 bool dvid_bneck64_tail_preferred(int H, int W) {
     static const int env = getenv("DVID_BNECK_FUSE") ? atoi(getenv("DVID_BNECK_FUSE")) : 1;

@@ -1094,14 +1094,14 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
             const int nb = (int)m->blocks[st].size();
             // res2 (64-wide bottlenecks, 256 out): one launch per block for everything behind conv1 -- conv2, conv3 + shortcut / residual
             // + ReLU and the next block's conv1 (csrc/bneck.hip; bit-identical to the launches below)
-            if (st == 0 && bneck64_stage(m->blocks[0]) && dvid_bneck64_tail_preferred(h, w)) {
+            if (st == 0 && dvid_bneck_stage_enabled(0) && bneck64_stage(m->blocks[0]) && dvid_bneck64_tail_preferred(h, w)) {
                 half_t* ta = t1;
                 half_t* tb = t2;
                 TRY(conv_run(m->blocks[0][0].c1, cur, nf, h, w, ta, 1, 0, nullptr, 0, 0, cs));
                 // the last block's launch also computes res3's first conv1 (1x1 / stride 1 over this stage's output, 256 -> 128) when
                 // res3 takes the fused path too: that layer alone re-read the 512 B per pixel this launch has in registers
                 const Block* r3 = nullptr;
-                if (nb > 1 && bneck128_stage(m->blocks[1])) {
+                if (nb > 1 && dvid_bneck_stage_enabled(1) && bneck128_stage(m->blocks[1])) {
                     const Block& b0 = m->blocks[1][0];
                     auto osz = [](const ConvW& c, int v) { return (v + 2 * c.pad - c.kh) / c.stride + 1; };
                     if (b0.c1.kh == 1 && b0.c1.stride == 1 && b0.c1.pad == 0 && b0.c1.cin == 256 && b0.c1.cout == 128 && b0.c1.kpad == 256 &&
@@ -1125,7 +1125,7 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
             }
             // res3 (128-wide): the first block's conv1 / strided conv2 / shortcut as their own launches, then one launch per block for
             // conv3 + residual + ReLU + the next block's conv1 (+ the next block's conv2 in front of them)
-            if (st == 1 && bneck128_stage(m->blocks[1])) {
+            if (st == 1 && dvid_bneck_stage_enabled(1) && bneck128_stage(m->blocks[1])) {
                 const Block& b0 = m->blocks[1][0];
                 auto osz = [](const ConvW& c, int v) { return (v + 2 * c.pad - c.kh) / c.stride + 1; };
                 if (dvid_bneck64_tail_preferred(osz(b0.c2, osz(b0.c1, h)), osz(b0.c2, osz(b0.c1, w)))) {

@@ -1,0 +1,69 @@
+"""The res2 -> res3 hand-over as stand-alone launches (last res2 block with the 128-channel next conv1 -> res3's strided conv2 and shortcut
+-> res3's first fused tail -> a res3 identity block), repeated while a second stream runs farthest-point sweeps: every stage's output
+against the first repetition, bit for bit -- names the first stage that is not reproducible."""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from diffusionvid_amd import ops as dv  # noqa: E402
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    n, hh, ww = 24, 152, 256
+    g = torch.Generator().manual_seed(0)
+    mk = lambda *s, sc=0.1: torch.randn(*s, generator=g) * sc
+    x256 = torch.randn(n, hh, ww, 256, generator=g, dtype=torch.float16).cuda()
+    t1 = x256[..., 64:128].clamp_min(0).contiguous()
+    P = lambda w: (lambda wp_k: (wp_k[0].cuda(), wp_k[1]))(dv.pack_conv_weight(w))
+    (w2d, _), (w3d, _), (w1d128, _) = P(mk(64, 64, 3, 3)), P(mk(256, 64)), P(mk(128, 256))
+    b2, b3, b1128 = (mk(c, sc=0.3).cuda() for c in (64, 256, 128))
+    (c2w, c2k), (scw, sck), (c3w, _), (n1w, _) = P(mk(128, 128, 3, 3, sc=0.05)), P(mk(512, 256, sc=0.08)), P(mk(512, 128)), P(mk(128, 512, sc=0.06))
+    c2b, scb, c3b, n1b = (mk(c, sc=0.3).cuda() for c in (128, 512, 512, 128))
+    (i2w, _), (i3w, _) = P(mk(128, 128, 3, 3, sc=0.05)), P(mk(512, 128))
+    i2b, i3b = (mk(c, sc=0.3).cuda() for c in (128, 512))
+    mem = torch.randn(1800, 256, generator=g).cuda()
+    d0 = dv.cdist(mem)
+    side = torch.cuda.Stream()
+
+    def chain():
+        out2, t1n = dv.bottleneck64_tail(t1, w2d, b2, w3d, b3, x256, None, None, w1d128, b1128)          # res2 last block + res3.0 conv1
+        t2 = dv.conv2d_nhwc(t1n, c2w, c2k, c2b, 128, 3, 3, 2, 1, relu=True)                               # res3.0 conv2 (stride 2)
+        sc = dv.conv2d_nhwc(out2, scw, sck, scb, 512, 1, 1, 2, 0)                                         # res3.0 shortcut (stride 2)
+        out3, t1b = dv.bottleneck128_tail(t2, None, None, c3w, c3b, sc, n1w, n1b)                         # res3.0 tail + res3.1 conv1
+        out4, _ = dv.bottleneck128_tail(t1b, i2w, i2b, i3w, i3b, out3)                                    # a res3 identity block
+        return [out2, t1n, t2, sc, out3, t1b, out4]
+
+    names = ("res2 out", "res3.0 conv1", "res3.0 conv2", "res3.0 shortcut", "res3.0 out", "res3.1 conv1", "res3.1 out")
+    base = [o.clone() for o in chain()]
+    torch.cuda.synchronize()
+    bad = 0
+    for r in range(reps):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dv.fps_greedy(d0, 900)
+        outs = [[o.clone() for o in chain()] for _ in range(3)]
+        torch.cuda.synchronize()
+        for k, got in enumerate(outs):
+            first = True
+            for nm, a, b in zip(names, got, base):
+                if not torch.equal(a, b):
+                    bad += 1
+                    if first:
+                        d = a != b
+                        fr = d.reshape(n, -1).any(dim=1).nonzero().flatten().tolist()
+                        print("run %d.%d: first stage that differs: %s, %d values (max %.3e), frames %s" % (r, k, nm, int(d.sum()), (a.float() - b.float()).abs().max().item(), fr[:8]), flush=True)
+                        dd = d.reshape(-1, d.shape[2], d.shape[3])          # [batch rows, columns, channels]
+                        rows = dd.any(dim=2).any(dim=1).nonzero().flatten().tolist()
+                        cols = dd.any(dim=2).any(dim=0).nonzero().flatten().tolist()
+                        chans = dd.any(dim=1).any(dim=0).nonzero().flatten().tolist()
+                        print("    batch rows %s  columns %s  channels %d (%s ...)" % (rows, cols, len(chans), chans[:6]), flush=True)
+                        per_px = dd.sum(dim=2)
+                        print("    differing channels per pixel, by row: %s" % {rw: per_px[rw][per_px[rw] > 0].tolist() for rw in rows[:4]}, flush=True)
+                        first = False
+    print("%d x 3 chains, %d differing stage outputs" % (reps, bad), flush=True)
+
+
+if __name__ == "__main__":
+    main()
