@@ -589,6 +589,49 @@ def test_bottleneck128_tail_matches_layers(dv, geom, variant):
         assert t1n_f is None
 
 
+def test_fused_blocks_reproducible_beside_another_stream(dv):
+    """The fused block kernels repeated while a second stream runs the global-memory build's farthest-point sweep (one long-lived small
+    workgroup that shares a CU with whatever else is scheduled there -- the situation of a video's first call): every repetition must
+    reproduce the first bit for bit.  With 155 KB of LDS instead of the CU's whole 160 KB single patch rows came out wrong about once in
+    ten 24-frame launches (csrc/bneck.hip, note at kBytes)."""
+    n, hh, ww = 24, 76, 128
+    g = torch.Generator().manual_seed(21)
+    mk = lambda *s, sc=0.1: torch.randn(*s, generator=g) * sc
+    res = torch.randn(n, hh, ww, 512, generator=g, dtype=torch.float16).cuda()
+    t1 = res[..., :128].clamp_min(0).contiguous()
+    (w2p, _), (w3p, _), (w1p, _) = (dv.pack_conv_weight(w) for w in (mk(128, 128, 3, 3, sc=0.05), mk(512, 128), mk(128, 512, sc=0.06)))
+    w2d, w3d, w1d = w2p.cuda(), w3p.cuda(), w1p.cuda()
+    b2, b3, b1 = (mk(c, sc=0.3).cuda() for c in (128, 512, 128))
+    x256 = torch.randn(n, 2 * hh, 2 * ww, 256, generator=g, dtype=torch.float16).cuda()
+    u1 = x256[..., 64:128].clamp_min(0).contiguous()
+    (v2p, _), (v3p, _), (v1p, _) = (dv.pack_conv_weight(w) for w in (mk(64, 64, 3, 3), mk(256, 64), mk(128, 256)))
+    v2d, v3d, v1d = v2p.cuda(), v3p.cuda(), v1p.cuda()
+    c2, c3, c1 = (mk(c, sc=0.3).cuda() for c in (64, 256, 128))
+    d0 = dv.cdist(torch.randn(1800, 256, generator=g).cuda())
+    side = torch.cuda.Stream()
+
+    def launches():
+        a, _ = dv.bottleneck128_tail(t1, w2d, b2, w3d, b3, res)                      # res3 identity block, no next conv1 (where it showed)
+        b, bt = dv.bottleneck128_tail(t1, w2d, b2, w3d, b3, res, w1d, b1)
+        c, ct = dv.bottleneck64_tail(u1, v2d, c2, v3d, c3, x256, None, None, v1d, c1)
+        return [a, b, bt, c, ct]
+
+    base = [o.clone() for o in launches()]
+    torch.cuda.synchronize()
+    bad = []
+    for r in range(40):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dv.fps_greedy(d0, 900)
+        outs = [[o.clone() for o in launches()] for _ in range(2)]
+        torch.cuda.synchronize()
+        for k, got in enumerate(outs):
+            for i, (x, y) in enumerate(zip(got, base)):
+                if not torch.equal(x, y):
+                    bad.append((r, k, i, int((x != y).sum())))
+    assert not bad, f"launches beside the other stream differ from the first run: {bad[:8]}"
+
+
 @pytest.mark.parametrize("size", [(128, 192), (256, 512), (608, 1024)])
 def test_backbone_bottleneck_fusion_bit_identical(dv, size):
     """The ResNet-FPN backbone with res2's and res3's blocks as one launch each behind conv1 (csrc/bneck.hip) against the same backbone with
