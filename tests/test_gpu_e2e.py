@@ -979,15 +979,18 @@ def test_host_fed_prefetch_equals_resident_frames():
 
 
 @pytest.mark.gpu
-def test_memory_build_on_side_stream_is_identical():
+@pytest.mark.parametrize("lookahead", [4, 2])
+def test_memory_build_on_side_stream_is_identical(lookahead):
     """The first call of a video queues the global-memory build (cdist + two farthest-point passes + gathers) on a second stream
-    when more launch sequences follow the one that held the global frames (look-ahead 4: 8 + 24 + 24 frames in groups of 32).
-    Same kernels on the same inputs: memory and detections must equal the in-line build bit for bit, video after video."""
+    when more launch sequences follow the one that held the global frames (look-ahead 4: 8 + 24 + 24 frames in groups of 32;
+    look-ahead 2: the call's own 8 + 24 frames as one sequence and a single 8-frame sequence beside the build -- the smallest launch
+    that can share the GPU with the farthest-point sweep).  Same kernels on the same inputs: memory and detections must equal the in-line
+    build bit for bit, video after video."""
     from diffusionvid_amd.config import get_cfg
     from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
     from diffusionvid_amd.modeling.detector import build_detection_model
     from diffusionvid_amd.utils import synthetic
-    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["INPUT.LOOKAHEAD_BATCHES", 4], "configs/BASE_RCNN_1gpu.yaml")
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["INPUT.LOOKAHEAD_BATCHES", lookahead], "configs/BASE_RCNN_1gpu.yaml")
     cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
     cfg.freeze()
     model = build_detection_model(cfg)
