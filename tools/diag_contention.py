@@ -34,12 +34,19 @@ def main():
 
     def one():
         feats = model.backbone(imgs)
-        out = model.rcnn_head(0, feats, 608, 1024, boxes, None, t)
-        return [f.clone() for f in feats] + [o.clone() for o in out[:3]]
+        outs = []
+        pro = None
+        for hi in range(3):          # the three extraction heads, each fed by the previous one, then the conditioned head
+            lg, bx, obj = model.rcnn_head(hi, feats, 608, 1024, boxes if hi == 0 else bx.view(n, M, 4), pro, t)[:3]
+            pro = obj
+            outs += [lg, bx, obj]
+        lg, bx, obj = model.rcnn_head(0, feats, 608, 1024, bx.view(n, M, 4), pro, t, cond=pro)[:3]
+        outs += [lg, bx, obj]
+        return [f.clone() for f in feats] + [o.clone() for o in outs]
 
     base = one()
     torch.cuda.synchronize()
-    names = ("p3", "p4", "p5", "logits", "boxes", "obj")
+    names = ("p3", "p4", "p5") + tuple("%s.%s" % (h, x) for h in ("head0", "head1", "head2", "cond") for x in ("logits", "boxes", "obj"))
     bad = 0
     for r in range(reps):
         if contend:
