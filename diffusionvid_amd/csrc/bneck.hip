@@ -16,7 +16,7 @@
 // and after one v_permlane32_swap per register pair with 2 x 8 consecutive channels -- which is exactly the second-operand fragment
 // of the next product's K step.  So conv2's result feeds conv3 and conv3's result feeds the next conv1 from registers: no LDS round
 // trip, no barrier after conv2, residual and outputs move as 16-byte pieces straight from / to the accumulator layout.  The residual
-// of the wave's row (16 KB) is requested in the prologue and lands while conv2 runs.
+// of the wave's row (16 KB) is requested once every DMA piece of the prologue has landed (behind taps 0-2) and lands while taps 3-8 run.
 //
 // LDS (156 KB used, the whole 160 KB requested; one workgroup per CU): t1 halo 10 x 34 pixels x 128 B (48 KB with padding; after conv2 the next conv1's weights) |
 // conv2 weights, 9 taps x [64][64] (72 KB; after conv2 the shortcut weights, or a 128-channel next conv1's 64 KB) | conv3 weights
@@ -66,12 +66,13 @@ constexpr int kHalo = 0;                       // ... later the next conv1's wei
 constexpr int kW2 = A_PIECES * 1024;           // 9 taps x [64 out][64 in]; later the shortcut's [256][64]
 constexpr int kW3 = kW2 + 9 * 8192;            // [256][64]
 constexpr int kBias = kW3 + 32768;             // four 1-KiB slots of floats: b2 [64] | b3 [256] | b1n [64] | bs [256]
-// The launch asks for ALL of the CU's LDS although kBias + 4096 bytes are used.  With 155 KB a workgroup could share its CU with a small
-// workgroup of another stream's kernel (the farthest-point sweep of the global-memory build is one long-lived workgroup with a few hundred
-// bytes of LDS), i.e. run with a non-zero, non-KiB-aligned LDS base -- and in that situation, and only in it, single patch rows came out
-// wrong about once in ten 24-frame launch sequences (tools/diag_chain_contention.py reproduces it stage by stage; 0 of 420 with the full
-// allocation, which keeps every other LDS-using workgroup off the CU and the base at 0).  The mechanism behind it (LDS-DMA pieces against a
-// misaligned base) was not isolated; the older DMA kernels share CUs only with workgroups of their own launch, at KiB-aligned bases.
+// The launch asks for ALL of the CU's LDS although kBias + 4096 bytes are used: nothing else with LDS then shares the CU.  History: the
+// first build (155 KB) could sit beside a small workgroup of another stream's kernel -- the farthest-point sweep of the global-memory build
+// -- and then, about once in ten 24-frame launch sequences, single patch rows came out wrong.  Cause (found with tools/lab/spin_kernel.hip
+// as the neighbour: barriers alone are harmless, LDS traffic is not): ORDINARY LOADS AND LDS-DMA PIECES DO NOT RETIRE IN ISSUE ORDER
+// RELATIVE TO EACH OTHER.  Each kind does among itself, but when the LDS pipe is busy the pieces lag, younger ordinary loads retire first,
+// and a counted vmcnt that has ordinary loads among the pieces it counts lets a step start on weights that have not landed.  Both kernels
+// here now keep ordinary loads out of every counted wait (below); the full allocation stays as a margin (DVID_BNECK_LDS=<bytes>: diagnostics).
 constexpr int kBytes = 160 * 1024;
 
 struct BneckParams {
@@ -166,18 +167,8 @@ __global__ __launch_bounds__(512) void bneck64_tail_kernel(BneckParams p) {
     const int gr = r0 + wave, gx = x0 + frow;
     const bool valid = gr < p.nrows && gx < p.W;
     const long pix = (long)(gr < p.nrows ? gr : p.nrows - 1) * p.W + (gx < p.W ? gx : p.W - 1);
-    // residual of the wave's row, requested now, used after conv2: [tile j][g] = channels 32 j + 16 g + 8 hi + [0, 8)
     constexpr int NRES = SC ? 4 : 16;
     half8 resv[NRES];
-    if (SC) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) resv[ks] = *reinterpret_cast<const half8*>(p.res + pix * 64 + 16 * ks + 8 * hi);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) resv[k] = *reinterpret_cast<const half8*>(p.res + pix * 256 + 16 * k + 8 * hi);
-    }
-    asm volatile("" ::: "memory");
-
     // ---- fragment addressing
     int a_off[3][4];                           // [dx][ks]: halo column dx + frow inside a halo row
 #pragma unroll
@@ -217,13 +208,26 @@ __global__ __launch_bounds__(512) void bneck64_tail_kernel(BneckParams p) {
             for (int j = 0; j < 2; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j][ks], fp[ks], acc2[j], 0, 0, 0);
     };
 
-    bn_wait_vmcnt<10 + NRES>();                // group A landed (issued after it: group B's 10 pieces and the residual loads)
+    // Only DMA pieces are in flight up to here, and they retire in issue order among themselves: the counted wait is exact.  (An
+    // ordinary load does NOT retire in order with them -- see bneck128_tail_kernel -- so the residual is requested only behind the
+    // last counted wait.)
+    bn_wait_vmcnt<10>();                       // group A landed (issued after it: group B's 10 pieces)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap) conv2_tap(tap);
-    bn_wait_vmcnt<NRES>();                     // group B landed
+    bn_wait_vmcnt<0>();                        // group B landed
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // residual of the wave's row, requested now, used after conv2 (six taps and an epilogue away): [tile j][g] = channels 32 j + 16 g + 8 hi + [0, 8)
+    if (SC) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) resv[ks] = *reinterpret_cast<const half8*>(p.res + pix * 64 + 16 * ks + 8 * hi);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) resv[k] = *reinterpret_cast<const half8*>(p.res + pix * 256 + 16 * k + 8 * hi);
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int tap = 3; tap < 9; ++tap) conv2_tap(tap);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -393,7 +397,8 @@ int bn_launch(const BneckParams& p, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck64_tail_kernel<SC, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((bneck64_tail_kernel<SC, TN>), dim3(p.ntiles), dim3(512), kBytes, s, p);
+    static const int lds_env = getenv("DVID_BNECK_LDS") ? atoi(getenv("DVID_BNECK_LDS")) : 0;          // diagnostics: less than the whole LDS (>= kBias + 4096)
+    hipLaunchKernelGGL((bneck64_tail_kernel<SC, TN>), dim3(p.ntiles), dim3(512), lds_env >= kBias + 4096 && lds_env <= kBytes ? lds_env : kBytes, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
 }
@@ -467,11 +472,11 @@ __global__ __launch_bounds__(512) void bneck128_tail_kernel(Bneck128Params p) {
     // unconditional, so they can be counted; stores are predicated (a wave may skip them) and are not: the counts are lower bounds
     // of what was issued after a step's pieces, i.e. the waits err on the early side of the ring only.
     auto dma_cnt = [](int t) { return (t < 0 || t >= NST) ? 0 : (t < NC2 ? 2 : D3); };
-    // residual: tiles 0-3 are ordinary loads into registers (CONV2: at conv2 steps 2-5, long before their use; else in the prologue),
+    // residual: tiles 0-3 are ordinary loads into registers (in the prologue, ahead of every DMA piece),
     // tiles 4-15 ride a per-wave DMA ring of 5 x 2 KB in the halo region, which is free once conv2 is done: tile jj + 4 is requested
     // at the start of conv3 step jj.  (Ordinary loads for all of them make the compiler wait vmcnt(0) at every first use while DMA
     // pieces are in flight -- its scoreboard treats a pending LDS-DMA as out of order.)
-    auto r_cnt = [&](int u) { return ((CONV2 && u >= 2 && u < 6) || (u >= NC2 && u < NC2 + 12)) ? 2 : 0; };
+    auto r_cnt = [&](int u) { return (u >= NC2 && u < NC2 + 12) ? 2 : 0; };
     auto wait_n = [&](int s) { return dma_cnt(s + 1) + dma_cnt(s + 2) + r_cnt(s - 3) + r_cnt(s - 2) + r_cnt(s - 1); };
 
     // ---- biases by DMA: b3 (two pieces), b2 | b1n (one piece: lanes 0-31 / 32-63)
@@ -491,6 +496,15 @@ __global__ __launch_bounds__(512) void bneck128_tail_kernel(Bneck128Params p) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) bn_glds16(reinterpret_cast<const char*>(rrow + 32 * jn + 16 * g), rring + (jn % 5) * 2048 + g * 1024);
     };
+    // The first four residual tiles: ordinary loads, issued BEFORE any DMA piece and never counted.  An ordinary load and an LDS-DMA
+    // piece do not retire in issue order relative to each other (each kind does among itself): with such loads between the pieces of
+    // the ring a counted vmcnt let a step start on weights that had not landed -- once the LDS pipe was busy with another workgroup's
+    // traffic (tools/diag_chain_contention.py, SIDE=spin:...:3).  The waits below count DMA pieces only.
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) resr[jj][g] = *reinterpret_cast<const half8*>(rrow + 32 * jj + 16 * g);
+    asm volatile("" ::: "memory");
     if (CONV2) {
         // t1 halo: piece q = wave + 8 i covers halo pixels [4 q, 4 q + 4); lane -> (pixel, 16-byte slot holding chunk slot ^ (hx & 15))
 #pragma unroll
@@ -506,10 +520,6 @@ __global__ __launch_bounds__(512) void bneck128_tail_kernel(Bneck128Params p) {
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) t2f[k] = *reinterpret_cast<const half8*>(p.t1 + pix * 128 + 16 * k + 8 * hi);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) resr[jj][g] = *reinterpret_cast<const half8*>(rrow + 32 * jj + 16 * g);
     }
     asm volatile("" ::: "memory");
 
@@ -579,10 +589,6 @@ __global__ __launch_bounds__(512) void bneck128_tail_kernel(Bneck128Params p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fp[ks], acc2[j], 0, 0, 0);
                 }
-            }
-            if (s >= 2 && s < 6) {
-#pragma unroll
-                for (int g = 0; g < 2; ++g) resr[s - 2][g] = *reinterpret_cast<const half8*>(rrow + 32 * (s - 2) + 16 * g);
             }
             asm volatile("" ::: "memory");
         }
@@ -708,7 +714,8 @@ int bn128_launch(const Bneck128Params& p, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck128_tail_kernel<CONV2, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, k8Bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((bneck128_tail_kernel<CONV2, TAIL>), dim3(p.ntiles), dim3(512), k8Bytes, s, p);
+    static const int lds_env = getenv("DVID_BNECK_LDS") ? atoi(getenv("DVID_BNECK_LDS")) : 0;          // diagnostics: less than the whole LDS (>= k8Bias + 3072)
+    hipLaunchKernelGGL((bneck128_tail_kernel<CONV2, TAIL>), dim3(p.ntiles), dim3(512), lds_env >= k8Bias + 3072 && lds_env <= k8Bytes ? lds_env : k8Bytes, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
 }

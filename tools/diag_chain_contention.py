@@ -1,6 +1,8 @@
 """The res2 -> res3 hand-over as stand-alone launches (last res2 block with the 128-channel next conv1 -> res3's strided conv2 and shortcut
 -> res3's first fused tail -> a res3 identity block), repeated while a second stream runs farthest-point sweeps: every stage's output
 against the first repetition, bit for bit -- names the first stage that is not reproducible."""
+import ctypes
+import os
 import sys
 
 import torch
@@ -26,6 +28,14 @@ def main():
     mem = torch.randn(1800, 256, generator=g).cuda()
     d0 = dv.cdist(mem)
     side = torch.cuda.Stream()
+    spin, spin_lds, spin_threads = None, 0, 256
+    if os.environ.get("SIDE", "").startswith("spin"):
+        parts = os.environ["SIDE"].split(":")
+        spin_lds, spin_threads = int(parts[1]), int(parts[2]) if len(parts) > 2 else 256
+        spin_cycles = int(parts[3]) if len(parts) > 3 else 4000000
+        spin_mode = int(parts[4]) if len(parts) > 4 else 0          # bit 0: a barrier per turn, bit 1: LDS writes / reads, bit 2: a cross-lane shuffle
+        spin = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab", "libspin.so"))
+        sink = torch.zeros(4, dtype=torch.int32, device="cuda")
 
     def chain():
         out2, t1n = dv.bottleneck64_tail(t1, w2d, b2, w3d, b3, x256, None, None, w1d128, b1128)          # res2 last block + res3.0 conv1
@@ -42,7 +52,11 @@ def main():
     for r in range(reps):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            dv.fps_greedy(d0, 900)
+            if spin is None:
+                dv.fps_greedy(d0, 900)
+            else:          # SIDE=spin:<lds bytes>:<threads>  a long-lived workgroup with that much LDS instead of the sweep
+                spin.spin_launch(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), spin_lds, ctypes.c_long(spin_cycles), spin_threads,
+                                 ctypes.c_void_p(sink.data_ptr()), spin_mode)
         outs = [[o.clone() for o in chain()] for _ in range(3)]
         torch.cuda.synchronize()
         for k, got in enumerate(outs):
@@ -59,6 +73,12 @@ def main():
                         cols = dd.any(dim=2).any(dim=0).nonzero().flatten().tolist()
                         chans = dd.any(dim=1).any(dim=0).nonzero().flatten().tolist()
                         print("    batch rows %s  columns %s  channels %d (%s ...)" % (rows, cols, len(chans), chans[:6]), flush=True)
+                        af, bf_ = a.reshape(-1, a.shape[2], a.shape[3]), b.reshape(-1, b.shape[2], b.shape[3])
+                        for rw in rows[:3]:          # is the wrong row another row's right answer, zero, or the input?
+                            seg = af[rw, cols[0]:cols[-1] + 1]
+                            like = {dl: round((seg == bf_[rw + dl, cols[0]:cols[-1] + 1]).float().mean().item(), 3) for dl in range(-7, 8) if 0 <= rw + dl < bf_.shape[0]}
+                            print("    row %d: zero fraction %.3f (right answer %.3f); equal to the right answer of row + d: %s" % (
+                                rw, (seg == 0).float().mean().item(), (bf_[rw, cols[0]:cols[-1] + 1] == 0).float().mean().item(), {k: v for k, v in like.items() if v > 0.3}), flush=True)
                         per_px = dd.sum(dim=2)
                         print("    differing channels per pixel, by row: %s" % {rw: per_px[rw][per_px[rw] > 0].tolist() for rw in rows[:4]}, flush=True)
                         first = False

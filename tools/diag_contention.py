@@ -1,6 +1,7 @@
 """Determinism under contention: a launch sequence of 24 frames (backbone + one extraction head pass) repeated on the main stream while a
 second stream runs the global-memory build's kernels (1800 x 1800 distances + farthest-point sweeps) back to back -- the situation of
 the second launch sequence of a video's first call.  Outputs of every repetition against the first, bit for bit."""
+import ctypes
 import os
 import sys
 
@@ -27,6 +28,13 @@ def main():
     model = dv.Model(sd, res_blocks=blocks)
     model.reserve(n, 608, 1024, M)
     side = torch.cuda.Stream()
+    if os.environ.get("SIDE", "").startswith("spin"):
+        import ctypes
+        parts = os.environ["SIDE"].split(":")
+        spin_lds, spin_threads, spin_cycles, spin_mode = int(parts[1]), int(parts[2]), int(parts[3]), int(parts[4])
+        spin_n = int(parts[5]) if len(parts) > 5 else 1
+        spin = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab", "libspin.so"))
+        sink = torch.zeros(4, dtype=torch.int32, device="cuda")
     d0 = dv.cdist(mem)
     big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     big2 = torch.empty_like(big)
@@ -53,7 +61,11 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 kind = os.environ.get("SIDE", "both")
-                for _ in range(3):
+                if kind.startswith("spin"):          # SIDE=spin:<lds bytes>:<threads>:<cycles>:<mode> (tools/lab/spin_kernel.hip), several workgroups' worth
+                    for _ in range(spin_n):
+                        spin.spin_launch(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), spin_lds, ctypes.c_long(spin_cycles), spin_threads,
+                                         ctypes.c_void_p(sink.data_ptr()), spin_mode)
+                for _ in range(0 if kind.startswith("spin") else 3):
                     if kind in ("both", "cdist"):
                         d = dv.cdist(mem)
                     if kind in ("both", "fps"):
