@@ -11,7 +11,7 @@
 // (D[n][m] = W A^T: the weights are the MFMA's first operand), so a lane ends up with channels of ONE output row; after a
 // v_permlane32_swap per register pair it holds 2 x 8 consecutive channels -> residual and output move as 16-byte pieces
 // straight from / to the accumulator layout, no fp32 LDS pass, no second barrier.  The residual rides the same DMA ring (each wave
-// fetches the 2 x 1 KiB it will read back lane-linearly), so the only waits are one counted `vmcnt` + one barrier per 32 rows.
+// fetches the 2 x 1 KiB it will read back lane-linearly), so the only waits are one counted `vmcnt` (DMA pieces only) + one barrier per 32 rows.
 // One persistent workgroup per CU (256); XCD x owns rows [x M / 8, (x + 1) M / 8) so the slabs that read the same A rows share an L2.
 //
 // Same MFMA, same K order (ascending, 16 per instruction) and the same epilogue arithmetic as igemm2 (fp32: + bias, + residual; round
@@ -184,10 +184,11 @@ __global__ __launch_bounds__(512) void wstat_kernel(IgemmParams p, int nslab) {
         for (int d = 0; d < D - 1; ++d) issue(d);
 
         for (int t = 0; t < T; ++t) {
-            // own pieces of tile t have landed.  Issued after them: the loads of tiles t + 1 .. t + D - 2 and the stores of the last
-            // (up to) D - 1 steps; vmcnt retires in issue order.
-            if (t >= D - 1) ws_wait_vmcnt<(D - 2) * LG + (D - 1) * SG>();
-            else ws_wait_vmcnt<(D - 2) * LG>();
+            // own pieces of tile t have landed.  Issued after them: the pieces of tiles t + 1 .. t + D - 2 -- and the stores of the last
+            // D - 1 steps, which are NOT counted: DMA pieces retire in issue order among themselves, stores (and ordinary loads) do not
+            // retire in order with them (csrc/bneck.hip, note at kBytes), so a count that includes stores could be reached while tile t
+            // is still in flight.  Counting the pieces only waits for at most the same operations (measured: no slower).
+            ws_wait_vmcnt<(D - 2) * LG>();
             __builtin_amdgcn_s_barrier();        // tile t visible to every wave; nobody reads tile t - 1 any more
             asm volatile("" ::: "memory");
             issue(t + D - 1);                    // into the stage of tile t - 1
@@ -396,13 +397,12 @@ __global__ __launch_bounds__(512) void wstat2_kernel(IgemmParams p, int nslab) {
         for (int d = 0; d < D - 1; ++d) issue(d);
 
         for (int t = 0; t < T; ++t) {
-            if (t >= D) ws_wait_vmcnt<(D - 2) * LG + (D - 1) * 2>();
-            else ws_wait_vmcnt<(D - 2) * LG>();
+            ws_wait_vmcnt<(D - 2) * LG>();          // pieces only (see wstat_kernel): the stores of the last steps are not counted
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's part of the output image is written
             __builtin_amdgcn_s_barrier();        // tile t (A and residual) visible; tile t - 1's output image complete; stage t - 1 free
             asm volatile("" ::: "memory");
             issue(t + D - 1);
-            if (t) store_tile(t - 1);            // (the counted waits only assume these stores from step D on)
+            if (t) store_tile(t - 1);
 
             const char* const stg = smem + (t % D) * STAGE;
             float16v acc;
