@@ -632,6 +632,27 @@ def test_fused_blocks_reproducible_beside_another_stream(dv):
     assert not bad, f"launches beside the other stream differ from the first run: {bad[:8]}"
 
 
+def test_fused_blocks_counted_waits_beside_lds_traffic():
+    """The fault behind the wrong patch rows of the first fused-block build, kept reproducible: with less than the whole LDS
+    (DVID_BNECK_LDS) a fused workgroup shares its CU with a synthetic neighbour that keeps the LDS pipe busy (tools/lab/spin_kernel.hip,
+    mode 3: LDS writes / reads + barriers) -- the condition under which counted vmcnt waits that had ordinary loads among their DMA
+    pieces let a step start early (85 of 450 chains differed).  Runs tools/diag_chain_contention.py in a child process (the LDS size
+    is read once per process); every repetition of the res2 -> res3 chain must reproduce the first bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tools", "lab", "libspin.so")
+    if not os.path.exists(so):
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(root, "tools", "lab", "spin_kernel.hip"), "-o", so],
+                       check=True)
+    env = dict(os.environ, DVID_BNECK_LDS="158720", SIDE="spin:1024:256:4000000:3")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "diag_chain_contention.py"), "60"], cwd=root, env=env, capture_output=True,
+                         text=True, timeout=600)
+    print(out.stdout[-600:])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "60 x 3 chains, 0 differing stage outputs" in out.stdout, out.stdout[-2000:]
+
+
 @pytest.mark.parametrize("size", [(128, 192), (256, 512), (608, 1024)])
 def test_backbone_bottleneck_fusion_bit_identical(dv, size):
     """The ResNet-FPN backbone with res2's and res3's blocks as one launch each behind conv1 (csrc/bneck.hip) against the same backbone with
