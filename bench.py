@@ -54,7 +54,7 @@ from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 # measured HBM bytes per implicit-GEMM launch (rocprofv3 --pmc passes of tools/profile_round.sh), one file PER CONFIGURATION: a line
 # only ever carries the traffic collected on its own workload, never another configuration's
 TRAFFIC_FILES = {("r101", 1): "r03l_pmc_igemm_traffic_r101_x1.json", ("r101", 4): "r03l_pmc_igemm_traffic_r101_x4.json",
-                 ("swinb", 1): "r03_pmc_igemm_traffic_swinb_x1.json"}
+                 ("swinb", 1): "r03l_pmc_igemm_traffic_swinb_x1.json"}
 PEAK_FP16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 # algorithmic work per output frame: backbone + heads + global attention, faithful pass counts
