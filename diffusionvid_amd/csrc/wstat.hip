@@ -493,7 +493,7 @@ int ws_launch_k(const IgemmParams& p, hipStream_t s) {
 template <int K, int D, int TN>
 int ws_launch_v(const IgemmParams& p, hipStream_t s) {
     const bool res = p.res_mode == 1, relu = p.relu == 1;
-    if constexpr (TN == 1) {          // (64 channels per wave + a residual ring does not fit the LDS; those layers take the row-coalesced kernel anyway)
+    if constexpr (TN == 1 && K <= 256) {          // (64 channels per wave or K = 512 + a residual ring does not fit the LDS; those layers take the row-coalesced kernel / igemm2)
         if (res) return relu ? ws_launch_k<K, D, TN, true, 1>(p, s) : ws_launch_k<K, D, TN, true, 0>(p, s);
     }
     if (res) return DVID_ERR_UNSUPPORTED;
@@ -507,7 +507,8 @@ int ws_launch_v(const IgemmParams& p, hipStream_t s) {
 // multiple of) the workgroups of an XCD, fp16 out, bias / ReLU / same-shape fp16 residual
 bool dvid_wstat_supported(const IgemmParams& p) {
     if (p.ntaps != 1 || p.pad != 0 || p.stride != 1 || p.Ho != p.H || p.Wo != p.W) return false;
-    if (p.Cin != p.Kpad || (p.Kpad != 128 && p.Kpad != 256)) return false;
+    // K = 512: only without a residual (the row-coalesced variant's residual ring does not fit beside 32-KB A tiles) -- Swin's stage-3 fc1
+    if (p.Cin != p.Kpad || (p.Kpad != 128 && p.Kpad != 256 && !(p.Kpad == 512 && p.res_mode == 0))) return false;
     if (p.Cout % 256) return false;
     const int ns = p.Cout / 256;
     if (!(ns <= 32 ? 32 % ns == 0 : ns % 32 == 0)) return false;
@@ -562,9 +563,10 @@ static int wstat_launch_rows32(const IgemmParams& p, hipStream_t s) {
     // DVID_WSTAT_V2=0 / 1 forces one, DVID_WSTAT_TN=1 the 32-channel form.
     static const int v2 = getenv("DVID_WSTAT_V2") ? atoi(getenv("DVID_WSTAT_V2")) : -1;
     static const int tn_env = getenv("DVID_WSTAT_TN") ? atoi(getenv("DVID_WSTAT_TN")) : 2;
-    if (v2 > 0 || (v2 < 0 && p.res_mode == 1)) return p.Kpad == 128 ? ws2_launch_v<128, 4>(p, s) : ws2_launch_v<256, 3>(p, s);
+    if (p.Kpad != 512 && (v2 > 0 || (v2 < 0 && p.res_mode == 1))) return p.Kpad == 128 ? ws2_launch_v<128, 4>(p, s) : ws2_launch_v<256, 3>(p, s);
     const int ns2 = p.Cout / 512;
     const bool wide = tn_env == 2 && p.res_mode == 0 && p.Cout % 512 == 0 && ns2 >= 32 && ns2 % 32 == 0;      // dynamic_layer: 0.749 vs 0.775 ms; linear1 (4 slabs) is slower that way
+    if (p.Kpad == 512) return ws_launch_v<512, 4, 1>(p, s);          // 128 registers of weights per wave, four 32-KB A tiles
     if (p.Kpad == 128) return wide ? ws_launch_v<128, 6, 2>(p, s) : ws_launch_v<128, 6, 1>(p, s);
     return wide ? ws_launch_v<256, 4, 2>(p, s) : ws_launch_v<256, 4, 1>(p, s);
 }

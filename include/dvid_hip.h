@@ -210,7 +210,7 @@ int dvid_igemm_set_tuning(int mode);
  * 512 pixels -- a function of the layer and the image size, not of the number of frames in the launch), 2 = on wherever the layer type fits (tests), 0 = off (the igemm2 kernel), -1 = follow DVID_CONV3X3_HALO
  * (default 1).  The choice depends on the layer's shape only; the two kernels differ in fp32 summation order. */
 int dvid_igemm_set_conv3x3(int mode);
-/* 1x1 convolutions / linear layers with K in {128, 256, 512} and N a multiple of 256 (bottleneck conv3 + residual, the decoder's
+/* 1x1 convolutions / linear layers with K in {128, 256} (512 without a residual) and N a multiple of 256 (bottleneck conv3 + residual, the decoder's
  * dynamic_layer and linear1) on the weight-stationary kernel (csrc/wstat.hip: a workgroup keeps the weights of 256 output channels in
  * registers and streams its rows through a DMA ring; epilogue straight from the accumulator layout): 1 = on for launches large
  * enough for 256 persistent workgroups, 2 = wherever the layer type fits (tests), 0 = off (igemm2), -1 = follow DVID_WSTAT (default 1).
