@@ -109,6 +109,7 @@ __global__ __launch_bounds__(512) void wstat_kernel(IgemmParams p, int nslab) {
         slab_step = nslab;                       // one slab per workgroup
         blk0 = xb0 + (int)((long)(xb1 - xb0) * sub / nsub);
         blk1 = xb0 + (int)((long)(xb1 - xb0) * (sub + 1) / nsub);
+        if (sub >= nsub) blk1 = blk0;            // slab counts that do not divide 32 (3, 6: Swin's qkv) leave 32 % nslab workgroups of an XCD idle
     }
     const int T = blk1 - blk0;                   // tiles
     if (T <= 0) return;                          // workgroup-uniform
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(512) void wstat2_kernel(IgemmParams p, int nslab) {
         slab_step = nslab;
         blk0 = xb0 + (int)((long)(xb1 - xb0) * sub / nsub);
         blk1 = xb0 + (int)((long)(xb1 - xb0) * (sub + 1) / nsub);
+        if (sub >= nsub) blk1 = blk0;
     }
     const int T = blk1 - blk0;
     if (T <= 0) return;
@@ -511,7 +513,7 @@ bool dvid_wstat_supported(const IgemmParams& p) {
     if (p.Cin != p.Kpad || (p.Kpad != 128 && p.Kpad != 256 && !(p.Kpad == 512 && p.res_mode == 0))) return false;
     if (p.Cout % 256) return false;
     const int ns = p.Cout / 256;
-    if (!(ns <= 32 ? 32 % ns == 0 : ns % 32 == 0)) return false;
+    if (!(ns <= 32 ? (32 % ns == 0 || ns == 3 || ns == 6) : ns % 32 == 0)) return false;          // 3 / 6 slabs (Swin qkv, N = 3C): 30 of an XCD's 32 workgroups work
     if (p.out_f32 || p.splitk > 1 || p.relu > 2 || (p.ldc & 7)) return false;
     if (p.res_mode > 1 || (p.res_mode == 1 && p.res_f32)) return false;
     if (p.relu == 2 && p.res_mode) return false;          // exact GELU: Swin's fc1, no residual

@@ -977,7 +977,8 @@ def test_bottleneck_tail_matches_layers(dv, geom, variant):
                                    (3000, 256, 8192, False, False), (2400, 256, 32768, False, False), (31, 256, 256, True, False),
                                    (9000, 128, 256, True, True), (40000, 256, 256, False, True),
                                    (38912 + 5, 128, 512, False, 2), (9728, 256, 1024, False, 2),           # Swin-B fc1 of stages 1 / 2: exact GELU
-                                   (2432 * 3 + 7, 512, 2048, False, 2), (5000, 512, 2048, False, True)])    # ... of stage 3 (K = 512)
+                                   (2432 * 3 + 7, 512, 2048, False, 2), (5000, 512, 2048, False, True),     # ... of stage 3 (K = 512)
+                                   (2432 * 5 + 3, 512, 1536, False, False), (9728 * 2 + 1, 256, 768, False, False)])   # Swin qkv (N = 3C: 6 / 3 slabs)
 def test_wstat_matches_igemm2(dv, shape):
     """csrc/wstat.hip (weights stationary in registers, rows streamed through a DMA ring, epilogue from the accumulator layout)
     against torch on the same fp16-rounded operands and against igemm2 on the same launch -- bit for bit: same MFMA, same K
