@@ -7,8 +7,10 @@
                       one frame; the item carries the current frame, the local reference frame(s), the global reference
                       frames and the bookkeeping ints the detector reads -- plus, with INPUT.LOOKAHEAD_BATCHES > 1, the
                       `ref_ahead` hand-over of the MI355X schedule (exactly the frames the next calls would deliver).
-Ground truth / annotation parsing is not part of the hot path; `VIDMEGATestDataset` returns None as target (the evaluator
-takes ground truth from its own source, data/evaluation/vid_eval.py).
+  VIDAnnotations      ground truth for the evaluator (vid.py:142-221): the per-frame XML files (or the reference's own
+                      `<image_set>_anno.pkl` cache: a list of {"boxes", "labels", "im_info" = (h, w)}), served as
+                      `get_img_info` / `get_groundtruth` -- what `do_vid_evaluation` asks a dataset for.  Not on the hot
+                      path: items still carry None as target, exactly as the reference's test items are not read there.
 
 Frames: `loader(path) -> uint8 HWC RGB` (default: Pillow decode on the host -- JPEG decode stays a CPU job, as the
 reference's 16 DataLoader workers do it); `transform(image, is_current)` = data/transforms.ResizeToTensor (host, Pillow:
@@ -47,9 +49,76 @@ class VIDFrameList:
         return len(self.image_set_index)
 
 
+VID_CLASSES = ('__background__', 'airplane', 'antelope', 'bear', 'bicycle', 'bird', 'bus', 'car', 'cattle', 'dog', 'domestic_cat',
+               'elephant', 'fox', 'giant_panda', 'hamster', 'horse', 'lion', 'lizard', 'monkey', 'motorcycle', 'rabbit', 'red_panda',
+               'sheep', 'snake', 'squirrel', 'tiger', 'train', 'turtle', 'watercraft', 'whale', 'zebra')
+VID_WNIDS = ('__background__', 'n02691156', 'n02419796', 'n02131653', 'n02834778', 'n01503061', 'n02924116', 'n02958343', 'n02402425',
+             'n02084071', 'n02121808', 'n02503517', 'n02118333', 'n02510455', 'n02342885', 'n02374451', 'n02129165', 'n01674464',
+             'n02484322', 'n03790512', 'n02324045', 'n02509815', 'n02411705', 'n01726692', 'n02355227', 'n02129604', 'n04468005',
+             'n01662784', 'n04530566', 'n02062744', 'n02391049')
+
+
+class VIDAnnotations:
+    """Per-frame ground truth of an ImageNet-VID frame list.  `anno_path`: directory of `<frame>.xml` files (the data set's
+    Annotations/VID/...); `cache_file`: the reference's pickle of the parsed list, read when present and written otherwise
+    (vid.py:169-194).  XML rule (vid.py:142-167): objects whose <name> is one of the 30 wnids, box clamped to
+    [0, width - 1] x [0, height - 1], label = index of the wnid."""
+
+    def __init__(self, frames, anno_path=None, cache_file=None):
+        self.frames = frames
+        self._xml = os.path.join(anno_path, "%s.xml") if anno_path else None
+        self._label_of = {w: i for i, w in enumerate(VID_WNIDS)}
+        if cache_file and os.path.exists(cache_file):
+            import pickle
+            with open(cache_file, "rb") as f:
+                self.annos = pickle.load(f)
+        else:
+            if self._xml is None:
+                raise ValueError("VIDAnnotations needs anno_path or an existing cache_file")
+            self.annos = [self.parse(self._xml % name) for name in frames.image_set_index]
+            if cache_file:
+                import pickle
+                with open(cache_file, "wb") as f:
+                    pickle.dump(self.annos, f)
+        if len(self.annos) != len(frames):
+            raise ValueError("%d annotations for %d frames" % (len(self.annos), len(frames)))
+
+    def parse(self, xml_file):
+        import xml.etree.ElementTree as ET
+        root = ET.parse(xml_file).getroot()
+        size = root.find("size")
+        h, w = int(size.find("height").text), int(size.find("width").text)
+        boxes, labels = [], []
+        for obj in root.findall("object"):
+            name = obj.find("name").text
+            if name not in self._label_of:
+                continue
+            bb = obj.find("bndbox")
+            boxes.append([max(float(bb.find("xmin").text), 0.0), max(float(bb.find("ymin").text), 0.0),
+                          min(float(bb.find("xmax").text), w - 1), min(float(bb.find("ymax").text), h - 1)])
+            labels.append(self._label_of[name.lower().strip()])
+        return {"boxes": torch.tensor(boxes, dtype=torch.float32).reshape(-1, 4), "labels": torch.tensor(labels), "im_info": (h, w)}
+
+    def get_img_info(self, idx):
+        h, w = self.annos[idx]["im_info"]
+        return {"height": h, "width": w}
+
+    def get_groundtruth(self, idx):
+        from ...structures.bounding_box import BoxList
+        a = self.annos[idx]
+        h, w = a["im_info"]
+        bl = BoxList(a["boxes"].reshape(-1, 4), (w, h), mode="xyxy")
+        bl.add_field("labels", a["labels"])
+        return bl
+
+
 class VIDMEGATestDataset:
-    def __init__(self, cfg, img_dir, img_index, transform=None, loader=None, rng=None, size_divisible=None):
+    classes = VID_CLASSES
+
+    def __init__(self, cfg, img_dir, img_index, transform=None, loader=None, rng=None, size_divisible=None, anno_path=None,
+                 anno_cache=None):
         self.frames = VIDFrameList(img_index)
+        self.annotations = VIDAnnotations(self.frames, anno_path, anno_cache) if (anno_path or anno_cache) else None
         if not self.frames.video_format:
             raise ValueError("%s is not a video frame list (4 columns expected)" % img_index)
         mega = cfg.MODEL.VID.MEGA
@@ -82,6 +151,22 @@ class VIDMEGATestDataset:
 
     def __len__(self):
         return len(self.frames)
+
+    # ---- what the evaluator asks a dataset for (vid.py:196-221, :241-242) --------------------------------------
+    def _annos(self):
+        if self.annotations is None:
+            raise RuntimeError("this dataset was built without anno_path / anno_cache: no ground truth to serve")
+        return self.annotations
+
+    def get_img_info(self, idx):
+        return self._annos().get_img_info(idx)
+
+    def get_groundtruth(self, idx):
+        return self._annos().get_groundtruth(idx)
+
+    @staticmethod
+    def map_class_id_to_class_name(class_id):
+        return VID_CLASSES[class_id]
 
     # ---- which files an item touches (vid_mega.py:176-221) -----------------------------------------------------
     def ref_ids(self, idx):

@@ -9,6 +9,12 @@ AP50 delta between the GPU path and the CPU oracle on identical inputs (SURVEY.m
 `predictions.pth` is what mega_core/engine/inference.py:168 saves: a list of BoxList indexed by
 dataset image id.
 """
+import contextlib
+import importlib
+import os
+import pickle
+import sys
+import types
 from collections import defaultdict
 
 import numpy as np
@@ -164,10 +170,172 @@ def result_string(results, class_names=None):
     return text
 
 
-def save_predictions(predictions, path):
-    """predictions: list[BoxList] indexed by image id (engine/inference.py:101-115, :168)."""
-    torch.save([p.to(torch.device("cpu")) for p in predictions], path)
+def corloc_eval_detection_vid(pred_boxlists, gt_boxlists, iou_thresh=0.5):
+    """CorLoc of vid_eval.py:356-443: per frame only the single highest-scoring detection is looked at; for every ground-truth
+    entry of label l the frame counts as an image of class l, and as correctly localised when that detection carries label
+    l and overlaps a class-l box by MORE than the threshold (double +1 convention as in the AP).  A frame with k boxes of one
+    class counts k times (the reference loops over the label list, not over its set).  -> ({label: corloc}, mean over the
+    labels seen, info text)."""
+    assert len(gt_boxlists) == len(pred_boxlists), "Length of gt and pred lists need to be same."
+    n_img, n_hit = defaultdict(int), defaultdict(int)
+    for gt_bl, pr_bl in zip(gt_boxlists, pred_boxlists):
+        pb, pl, ps = _fields(pr_bl)
+        gb, gl, _ = _fields(gt_bl)
+        top = ps.argsort()[::-1][:1]
+        pb, pl = pb[top], pl[top]
+        for l in gl.astype(int):
+            n_img[l] += 1
+            cand = pb[pl == l]
+            if len(cand) and (_iou_vid(cand, gb[gl == l]) > iou_thresh).any():
+                n_hit[l] += 1
+    corloc = {l: (n_hit[l] / n_img[l] if n_img[l] else float("nan")) for l in n_img}
+    info = "".join("gt:{} correct:{}\n".format(n_img[l], n_hit[l]) for l in n_img)
+    info += "total_gt:{}, total_correct:{}\n".format(sum(n_img.values()), sum(n_hit[l] for l in n_img))
+    avg = sum(corloc.values()) / len(corloc) if corloc else float("nan")
+    return corloc, avg, info + "Avg_CorLoc = {:.4f}".format(avg)
+
+
+VID_CLASSES = ('__background__', 'airplane', 'antelope', 'bear', 'bicycle', 'bird', 'bus', 'car', 'cattle', 'dog', 'domestic_cat',
+               'elephant', 'fox', 'giant_panda', 'hamster', 'horse', 'lion', 'lizard', 'monkey', 'motorcycle', 'rabbit', 'red_panda',
+               'sheep', 'snake', 'squirrel', 'tiger', 'train', 'turtle', 'watercraft', 'whale', 'zebra')
+
+
+class GroundTruthList:
+    """a list of ground-truth BoxLists (one per image id) behind the dataset surface do_vid_evaluation reads"""
+
+    def __init__(self, gts, name_of=None, motion=None):
+        self.gts, self._motion = gts, motion
+        if name_of is not None:
+            self.map_class_id_to_class_name = name_of
+
+    def get_img_info(self, i):
+        w, h = self.gts[i].size
+        return {"width": w, "height": h}
+
+    def get_groundtruth(self, i):
+        return self.gts[i]
+
+    def motion_ious(self):
+        if self._motion is None:
+            raise ValueError("motion-specific evaluation needs the per-box motion IoUs")
+        return self._motion
+
+
+def do_vid_evaluation(dataset, predictions, output_folder=None, box_only=False, motion_specific=False, logger=None,
+                      motion_ious=None):
+    """The evaluator wrapper the reference's `inference` ends in (vid_eval.py:14-78; engine/inference.py:176-181 through
+    `evaluate`).  `dataset` supplies what the reference's VIDDataset does: `get_img_info(i) -> {"width", "height"}` of the
+    ORIGINAL frame, `get_groundtruth(i) -> BoxList` with "labels" in original-frame pixels, and (optionally)
+    `map_class_id_to_class_name(i)`.  Every prediction is first mapped from the resized frame the detector saw (600 x 1000) to
+    the original size with `BoxList.resize` (:17-21) -- the AP is computed in annotation pixels --, then AP50 (per motion range
+    with `motion_specific`; `motion_ious` or `dataset.motion_ious()` supplies the per-box motion IoUs the reference reads from
+    its .mat file, :143-148) and CorLoc; the text goes to the logger and to `output_folder/result.txt`.  Returns the AP
+    result (a list with one dict per motion range, as the reference does)."""
+    if box_only:
+        raise NotImplementedError("proposal recall (RPN_ONLY) is outside the DiffusionVID path")
+    preds, gts = [], []
+    for image_id, prediction in enumerate(predictions):
+        info = dataset.get_img_info(image_id)
+        preds.append(prediction.resize((info["width"], info["height"])))
+        gts.append(dataset.get_groundtruth(image_id))
+    names, ranges = ("all",), ((0.0, 1.0),)
+    if motion_specific:
+        names, ranges = MOTION_NAMES, MOTION_RANGES
+        if motion_ious is None:
+            motion_ious = dataset.motion_ious()
+        result = eval_detection_vid(preds, gts, 0.5, motion_ious=motion_ious, motion_ranges=ranges)
+    else:
+        result = [eval_detection_vid(preds, gts, 0.5)]
+    corloc, corloc_avg, _ = corloc_eval_detection_vid(preds, gts, 0.5)
+    name_of = getattr(dataset, "map_class_id_to_class_name", None) or (lambda i: VID_CLASSES[i] if i < len(VID_CLASSES) else str(i))
+    text = "".join("AP50 | motion={:>6s} = {:0.4f}\n".format(n, r["map"]) for n, r in zip(names, result))
+    text += "Category AP:\n"
+    text += "".join("{:<16}: {:.4f}\n".format(name_of(i), ap) for i, ap in enumerate(result[0]["ap"]) if i != 0)
+    text += "Mean CorLoc: {:.4f}\n".format(corloc_avg)
+    text += "Category CorLoc:\n"
+    text += "".join("{:<16}: {:.4f}\n".format(name_of(l), corloc[l]) for l in corloc)
+    if logger is not None:
+        logger.info("\n" + text)
+    if output_folder:
+        with open(os.path.join(output_folder, "result.txt"), "w") as fid:
+            fid.write(text)
+    return result
+
+
+# ---- predictions.pth -------------------------------------------------------------------------------------------------------------
+# The reference's file is `torch.save(list[mega_core.structures.bounding_box.BoxList])` (engine/inference.py:168): a pickle that
+# names that class.  To hand files back and forth between the two code bases without either importing the other:
+#   * save_predictions(..., class_module="mega_core.structures.bounding_box") writes this repo's detections under the
+#     reference's class path (its real class when importable here, otherwise an alias registered for the duration of the save);
+#   * load_predictions resolves `<any package>.structures.bounding_box.BoxList` to this repo's class when that package is absent.
+REFERENCE_BOXLIST_MODULE = "mega_core.structures.bounding_box"
+
+
+@contextlib.contextmanager
+def _boxlist_class_at(module_name):
+    from ...structures.bounding_box import BoxList
+    if module_name in (None, BoxList.__module__):
+        yield BoxList
+        return
+    try:
+        yield getattr(importlib.import_module(module_name), "BoxList")
+        return
+    except ImportError:
+        pass
+    alias = type("BoxList", (BoxList,), {"__module__": module_name})
+    added = []
+    parts = module_name.split(".")
+    for i in range(1, len(parts) + 1):
+        name = ".".join(parts[:i])
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.__path__ = []
+            sys.modules[name] = mod
+            added.append(name)
+    setattr(sys.modules[module_name], "BoxList", alias)
+    try:
+        yield alias
+    finally:
+        for name in added:
+            sys.modules.pop(name, None)
+
+
+def _as_class(bl, cls):
+    if type(bl) is cls:
+        return bl.to(torch.device("cpu"))
+    out = cls(bl.bbox.detach().cpu(), tuple(bl.size), mode=bl.mode)
+    for k in bl.fields():
+        v = bl.get_field(k)
+        out.add_field(k, v.detach().cpu() if isinstance(v, torch.Tensor) else v)
+    return out
+
+
+def save_predictions(predictions, path, class_module=None):
+    """predictions: list[BoxList] indexed by image id (engine/inference.py:101-115, :168).  class_module None keeps every
+    object's own class; a module path (REFERENCE_BOXLIST_MODULE) writes them all as that module's BoxList."""
+    if class_module is None:
+        torch.save([p.to(torch.device("cpu")) for p in predictions], path)
+        return
+    with _boxlist_class_at(class_module) as cls:
+        torch.save([_as_class(p, cls) for p in predictions], path)
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except (ImportError, AttributeError):
+            if name == "BoxList" and module.endswith("structures.bounding_box"):
+                from ...structures.bounding_box import BoxList
+                return BoxList
+            raise
+
+
+_tolerant_pickle = types.SimpleNamespace(**{k: getattr(pickle, k) for k in dir(pickle) if not k.startswith("__")})
+_tolerant_pickle.__name__ = "pickle"
+_tolerant_pickle.Unpickler = _TolerantUnpickler
+_tolerant_pickle.load = lambda f, **kw: _TolerantUnpickler(f, **kw).load()
 
 
 def load_predictions(path):
-    return torch.load(path, weights_only=False)
+    return torch.load(path, weights_only=False, pickle_module=_tolerant_pickle)

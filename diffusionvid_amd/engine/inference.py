@@ -229,10 +229,15 @@ def predictions_list(merged):
     return [merged[i] for i in ids]
 
 
-def inference(model, dataset, indices, device, output_folder=None, gt_boxlists=None, max_det=None):
-    """Reference `inference` (mega_core/engine/inference.py:118-181) for the in-scope path: run this rank's
-    contiguous share, gather on rank 0, write `predictions.pth`, and -- when ground truth is supplied -- the
-    VID AP50 of data/evaluation/vid_eval.py.  Returns (predictions list | None off rank 0, eval dict | None)."""
+def inference(model, dataset, indices, device, output_folder=None, gt_boxlists=None, max_det=None, motion_specific=False,
+              motion_ious=None, logger=None, class_module=None):
+    """Reference `inference` (mega_core/engine/inference.py:118-181) for the in-scope path: run this rank's share, gather on
+    rank 0, write `predictions.pth` (`class_module`: see vid_eval.save_predictions) and evaluate as the reference's
+    `evaluate` -> `do_vid_evaluation` does (vid_eval.py:14-78): when the dataset serves `get_img_info` / `get_groundtruth`
+    the predictions are mapped from the resized frame to the annotation's original size first and `result.txt` is written;
+    `gt_boxlists` (a list of BoxList, one per image id) stands in for a dataset without annotations -- each prediction is
+    resized to its ground truth's size the same way.  Returns (predictions list | None off rank 0, eval | None):
+    eval = the AP dict, or the list of one dict per motion range with `motion_specific`."""
     import os
 
     from ..data.evaluation import vid_eval
@@ -244,6 +249,14 @@ def inference(model, dataset, indices, device, output_folder=None, gt_boxlists=N
     preds = predictions_list(merged)
     if output_folder:
         os.makedirs(output_folder, exist_ok=True)
-        vid_eval.save_predictions(preds, os.path.join(output_folder, "predictions.pth"))
-    ev = vid_eval.eval_detection_vid(preds, gt_boxlists) if gt_boxlists is not None else None
-    return preds, ev
+        vid_eval.save_predictions(preds, os.path.join(output_folder, "predictions.pth"), class_module)
+    source = None
+    if gt_boxlists is not None:
+        source = vid_eval.GroundTruthList(gt_boxlists, getattr(dataset, "map_class_id_to_class_name", None))
+    elif hasattr(dataset, "get_groundtruth") and getattr(dataset, "annotations", True) is not None:
+        source = dataset
+    if source is None:
+        return preds, None
+    ev = vid_eval.do_vid_evaluation(source, preds, output_folder, motion_specific=motion_specific, logger=logger,
+                                    motion_ious=motion_ious)
+    return preds, (ev if motion_specific else ev[0])

@@ -59,6 +59,27 @@ def _register_nested(root, name, tensor, buffer=False):
         mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
+_FOREIGN_BOXLIST = {}
+
+
+def _result_class(image_list):
+    """BoxList class that belongs to the caller's ImageList: `<pkg>.structures.image_list.ImageList` ->
+    `<pkg>.structures.bounding_box.BoxList` (the reference keeps both under mega_core/structures); this repo's class for
+    tensors, this repo's ImageList, or when no such module exists."""
+    mod = type(image_list).__module__ or ""
+    if not mod.endswith(".image_list") or mod.startswith("diffusionvid_amd."):
+        return BoxList
+    if mod not in _FOREIGN_BOXLIST:
+        cls = BoxList
+        try:
+            import importlib
+            cls = getattr(importlib.import_module(mod[: -len("image_list")] + "bounding_box"), "BoxList", BoxList)
+        except ImportError:
+            pass
+        _FOREIGN_BOXLIST[mod] = cls
+    return _FOREIGN_BOXLIST[mod]
+
+
 class DiffusionDet(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -166,6 +187,10 @@ class DiffusionDet(nn.Module):
         # True: a batch's detections come back with ONE device->host copy and the BoxLists hold CPU tensors
         # (what engine/inference.py does next anyway, there with ~3 copies per frame); False: GPU tensors
         self.results_on_host = False
+        # class of the returned detections.  None: this repo's BoxList -- unless the frames arrive in another package's
+        # ImageList (the reference's collator, collate_batch.py:24-35), in which case the detections are that package's
+        # own `structures.bounding_box.BoxList`, so its evaluator / torch.save see their own type (`_result_class`).
+        self.boxlist_cls = None
         self.host_wait_s = 0.0      # seconds this process spent blocked in the per-batch device->host result copy
         self.video_index = 0
         self.demo = False
@@ -236,6 +261,7 @@ class DiffusionDet(nn.Module):
         if self.training:
             raise NotImplementedError("training is out of scope of the MI355X inference path")
         images = dict(images)
+        self._result_cls = self.boxlist_cls or _result_class(images["cur"])
         images["cur"] = to_image_list(images["cur"])
         images["ref_l"] = [to_image_list(image) for image in images["ref_l"]]
         images["ref_g"] = [to_image_list(image) for image in images["ref_g"]]
@@ -613,7 +639,7 @@ class DiffusionDet(nn.Module):
         self.head.check_boxes_valid()
         results = []
         for b, k in enumerate(counts):
-            bl = BoxList(ob[b, :k], size_wh, mode="xyxy")
+            bl = (getattr(self, "_result_cls", None) or BoxList)(ob[b, :k], size_wh, mode="xyxy")
             bl.add_field("scores", osc[b, :k])
             labels = ol[b, :k].to(torch.int64)
             bl.add_field("labels", labels)

@@ -25,9 +25,17 @@ def _round_up(v, m):
     return v if m <= 0 else -(-v // m) * m
 
 
+def is_image_list(x):
+    """An ImageList by its surface, not its class: the reference's collator wraps frames in
+    `mega_core.structures.image_list.ImageList` (collate_batch.py:24-35) and those objects arrive here unchanged."""
+    return (not isinstance(x, torch.Tensor)) and hasattr(x, "tensors") and hasattr(x, "image_sizes")
+
+
 def to_image_list(tensors, size_divisible=0):
     if isinstance(tensors, ImageList):
         return tensors
+    if is_image_list(tensors):              # a foreign ImageList: same tensor, same sizes, this repo's wrapper
+        return ImageList(tensors.tensors, list(tensors.image_sizes))
     if isinstance(tensors, torch.Tensor):
         if size_divisible > 0:
             tensors = [tensors]             # single image that still needs alignment padding

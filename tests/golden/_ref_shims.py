@@ -109,6 +109,28 @@ class CfgNode(dict):
     def defrost(self):
         pass
 
+    def merge_from_file(self, path):
+        """yacs merge_from_file: the YAML's values over the existing keys (tuples stay tuples where the default is one)"""
+        import yaml
+
+        def merge(dst, src):
+            for k, v in src.items():
+                if isinstance(v, dict):
+                    merge(dst[k], v)
+                else:
+                    if k not in dst:
+                        raise KeyError(k)
+                    if isinstance(v, str):          # yacs _decode_cfg_value: strings that are Python literals become those
+                        import ast
+                        try:
+                            v = ast.literal_eval(v)
+                        except (ValueError, SyntaxError):
+                            pass
+                    dst[k] = tuple(v) if isinstance(dst[k], tuple) and isinstance(v, list) else v
+
+        with open(path) as f:
+            merge(self, yaml.safe_load(f))
+
     def merge_from_list(self, lst):
         for k, v in zip(lst[0::2], lst[1::2]):
             node = self

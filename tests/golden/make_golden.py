@@ -500,6 +500,138 @@ def g16_full_dim_head():
          weights_seed=np.array(0), n=np.array(n), M=np.array(M), H=np.array(H), W=np.array(W))
 
 
+def g17_boundary_types():
+    """The reference's own boundary objects, for the plugin surface:
+      * BoxList.resize / transpose / crop / area / convert / copy_with_fields (bounding_box.py:55-247) on odd sizes, both modes;
+      * BatchCollator(size_divisible, "diffusion") (collate_batch.py:12-41) on one dataset item with ragged frames: the dict the
+        reference's inference loop hands to `model(images)` (engine/inference.py:34-49);
+      * the real VIDDataset's XML parser + get_img_info / get_groundtruth (vid.py:142-221) on a tiny on-disk set;
+      * do_vid_evaluation (vid_eval.py:14-78) end to end on that dataset with predictions in the RESIZED frame: result list and
+        the text of result.txt;
+      * a predictions.pth written by `torch.save` of the reference's BoxList objects (engine/inference.py:168), kept as a file."""
+    import logging
+    import tempfile
+    from mega_core.config import cfg as RC
+    from mega_core.data.collate_batch import BatchCollator
+    from mega_core.data.datasets.vid import VIDDataset
+    from mega_core.data.datasets.evaluation.vid.vid_eval import do_vid_evaluation
+    g = torch.Generator().manual_seed(170)
+    arrs = {}
+    # -- BoxList methods
+    b = torch.rand(9, 4, generator=g) * 300
+    xyxy = torch.cat([b[:, :2], b[:, :2] + b[:, 2:] * 0.5 + 1], 1)
+    for mode in ("xyxy", "xywh"):
+        bl = BoxList(xyxy.clone(), (613, 347), mode="xyxy").convert(mode)
+        bl.add_field("labels", torch.arange(9))
+        bl.add_field("scores", torch.rand(9, generator=g))
+        arrs[mode + ".in"] = bl.bbox
+        arrs[mode + ".resize_same"] = bl.resize((1226, 694)).bbox                # one ratio: numbers scaled as stored
+        arrs[mode + ".resize_odd"] = bl.resize((1000, 563)).bbox                 # two ratios: per-axis on corners
+        arrs[mode + ".resize_odd_mode"] = np.array(bl.resize((1000, 563)).mode)
+        arrs[mode + ".flip_lr"] = bl.transpose(0).bbox
+        arrs[mode + ".flip_tb"] = bl.transpose(1).bbox
+        arrs[mode + ".crop"] = bl.crop((40, 25, 411, 300)).bbox
+        arrs[mode + ".crop_size"] = np.array(bl.crop((40, 25, 411, 300)).size)
+        arrs[mode + ".area"] = bl.area()
+        arrs[mode + ".back"] = bl.convert("xyxy").bbox
+        arrs[mode + ".fields_after_resize"] = np.array(sorted(bl.resize((1000, 563)).fields()))
+        arrs[mode + ".copy_fields"] = np.array(bl.copy_with_fields(["scores", "missing"], skip_missing=True).fields())
+    # -- the collator's dict for one item
+    frames = [torch.rand(3, 37, 50, generator=g), torch.rand(3, 37, 50, generator=g), torch.rand(3, 40, 61, generator=g)]
+    item = ({"cur": frames[0], "ref_l": [frames[0], frames[1]], "ref_g": [frames[2]], "frame_category": 0, "frame_id": 0, "start_id": 0,
+             "end_id": 20, "seg_len": 21, "last_queue_id": 7, "pattern": "val/vid00/%06d", "img_dir": "x/%s.JPEG", "transforms": None},
+            None, [0, 1, 2, 3, 4, 5, 6, 7])
+    images, targets, ids = BatchCollator(32, "diffusion", False)([item])
+    assert type(images["cur"]).__module__ == "mega_core.structures.image_list"
+    arrs["coll.frames0"], arrs["coll.frames1"], arrs["coll.frames2"] = frames
+    arrs["coll.cur"], arrs["coll.cur_size"] = images["cur"].tensors, np.array(images["cur"].image_sizes[0])
+    arrs["coll.ref_l1"], arrs["coll.ref_l1_size"] = images["ref_l"][1].tensors, np.array(images["ref_l"][1].image_sizes[0])
+    arrs["coll.ref_g0"], arrs["coll.ref_g0_size"] = images["ref_g"][0].tensors, np.array(images["ref_g"][0].image_sizes[0])
+    arrs["coll.keys"] = np.array(sorted(images.keys()))
+    arrs["coll.ids"] = np.array(ids[0])
+    # -- the real VIDDataset on XML files
+    root = tempfile.mkdtemp()
+    wnids = VIDDataset.classes_map
+    os.makedirs(os.path.join(root, "ImageSets"))
+    lines, xmls, names = [], [], []
+    n = 0
+    for v, (L, (W, H)) in enumerate(zip([5, 4], [(1280, 720), (500, 375)])):
+        os.makedirs(os.path.join(root, "Annotations", "VID", "val", "vid%02d" % v))
+        for f in range(L):
+            n += 1
+            objs = ""
+            for k in range(int(torch.randint(0, 4, (1,), generator=g))):
+                x1, y1 = int(torch.randint(-5, W - 60, (1,), generator=g)), int(torch.randint(-5, H - 60, (1,), generator=g))
+                x2, y2 = x1 + int(torch.randint(20, 400, (1,), generator=g)), y1 + int(torch.randint(20, 300, (1,), generator=g))
+                wn = wnids[int(torch.randint(1, 31, (1,), generator=g))] if k != 2 else "n00000000"        # an unknown class is skipped
+                objs += ("<object><trackid>%d</trackid><name>%s</name><bndbox><xmax>%d</xmax><xmin>%d</xmin><ymax>%d</ymax><ymin>%d</ymin>"
+                         "</bndbox><occluded>0</occluded><generated>0</generated></object>" % (k, wn, x2, x1, y2, y1))
+            xml = ("<annotation><folder>val/vid%02d</folder><filename>%06d</filename><source><database>ILSVRC_2015</database></source>"
+                   "<size><width>%d</width><height>%d</height></size>%s</annotation>" % (v, f, W, H, objs))
+            name = "val/vid%02d/%06d" % (v, f)
+            open(os.path.join(root, "Annotations", "VID", name + ".xml"), "w").write(xml)
+            xmls.append(xml)
+            names.append(name)
+            lines.append("val/vid%02d %d %d %d" % (v, n, f, L))
+    index = os.path.join(root, "ImageSets", "VID_val_videos.txt")
+    open(index, "w").write("\n".join(lines) + "\n")
+    ds = VIDDataset("VID_val_videos", root, os.path.join(root, "Data", "VID"), os.path.join(root, "Annotations", "VID"), index, None,
+                    is_train=False)
+    arrs["vid.index_lines"], arrs["vid.xml"], arrs["vid.names"] = np.array(lines), np.array(xmls), np.array(names)
+    preds = []
+    for i in range(len(ds)):
+        gt = ds.get_groundtruth(i)
+        info = ds.get_img_info(i)
+        arrs["vid.gt_box_%d" % i], arrs["vid.gt_lab_%d" % i] = gt.bbox, gt.get_field("labels").to(torch.int64)
+        arrs["vid.wh_%d" % i] = np.array([info["width"], info["height"]])
+        # detections in the frame the detector saw: the short side resized to 600 (capped at 1000), like transforms.Resize
+        W, H = info["width"], info["height"]
+        sc = min(600.0 / min(W, H), 1000.0 / max(W, H))
+        rw, rh = int(W * sc + 0.5), int(H * sc + 0.5)
+        rows, labs = [], []
+        for j in range(len(gt)):
+            if torch.rand(1, generator=g) < 0.8:
+                rows.append(gt.bbox[j] * sc + torch.randn(4, generator=g) * 9)
+                labs.append(int(gt.get_field("labels")[j]) if torch.rand(1, generator=g) < 0.8 else 3)
+        for j in range(int(torch.randint(0, 3, (1,), generator=g))):
+            c = torch.rand(2, generator=g) * torch.tensor([rw - 80.0, rh - 80.0])
+            rows.append(torch.cat([c, c + torch.rand(2, generator=g) * 70 + 8]))
+            labs.append(int(torch.randint(1, 31, (1,), generator=g)))
+        pr = BoxList(torch.stack(rows) if rows else torch.zeros(0, 4), (rw, rh))
+        pr.add_field("scores", torch.rand(len(labs), generator=g))
+        pr.add_field("labels", torch.tensor(labs, dtype=torch.int64))
+        preds.append(pr)
+        arrs["vid.pr_box_%d" % i], arrs["vid.pr_lab_%d" % i], arrs["vid.pr_sc_%d" % i] = pr.bbox, pr.get_field("labels"), pr.get_field("scores")
+        arrs["vid.pr_wh_%d" % i] = np.array([rw, rh])
+    out = tempfile.mkdtemp()
+    res = do_vid_evaluation(ds, preds, out, False, False, logging.getLogger("g17"))
+    arrs["vid.nframes"] = np.array(len(ds))
+    arrs["vid.ap"], arrs["vid.map"] = res[0]["ap"], np.array(res[0]["map"])
+    arrs["vid.result_txt"] = np.array(open(os.path.join(out, "result.txt")).read())
+    torch.save(preds[:3], os.path.join(HERE, "g17_predictions_ref.pth"))
+    # -- the reference's own config node for the two shipped model files: defaults.py merged with BASE_RCNN_1gpu.yaml and the
+    #    model yaml exactly as tools/test_net.py:76-82 does, flattened to {dotted key: value}
+    import json
+    from mega_core.config import cfg as RC2
+
+    def flat(node, prefix=""):
+        out = {}
+        for k, v in node.items():
+            if hasattr(v, "items"):
+                out.update(flat(v, prefix + k + "."))
+            else:
+                out[prefix + k] = list(v) if isinstance(v, tuple) else v
+        return out
+
+    for tag, y in (("r101", "vid_R_101_DiffusionVID.yaml"), ("swinb", "vid_Swin_B_DiffusionVID.yaml")):
+        c = RC2.clone()
+        c.merge_from_file(os.path.join(S.REFERENCE_ROOT, "configs", "BASE_RCNN_1gpu.yaml"))
+        DD.add_diffusiondet_config(c)                                   # tools/test_net.py:78-79
+        c.merge_from_file(os.path.join(S.REFERENCE_ROOT, "configs", y))
+        arrs["cfg." + tag] = np.array(json.dumps(flat(c), sort_keys=True))
+    save("g17_boundary_types", **arrs)
+
+
 if __name__ == "__main__":
     # The reference targets torch 1.8 (INSTALL.md:3-13) where nn.MultiheadAttention.forward IS
     # F.multi_head_attention_forward; keep torch 2.x's fused inference fast path out of the goldens.
@@ -521,3 +653,4 @@ if __name__ == "__main__":
     g15_vid_eval_motion()
     g14_vid_dataset_protocol()
     g16_full_dim_head()
+    g17_boundary_types()

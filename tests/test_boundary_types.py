@@ -1,0 +1,429 @@
+"""The plugin surface on the REFERENCE's own types (missing #1 / #2, weak #1).
+
+Golden g17 holds outputs of the reference's own `BoxList`, `BatchCollator("diffusion")`, `VIDDataset` (XML parser,
+get_img_info / get_groundtruth), `do_vid_evaluation` and a `predictions.pth` pickled from its BoxList class
+(tests/golden/make_golden.py::g17_boundary_types).  The tests below feed objects of a FOREIGN package -- a stand-in
+package `refpkg.structures.{image_list,bounding_box}` built here with the reference's module layout; mega_core itself
+cannot travel -- through `DiffusionDet.forward`, and check this repo's BoxList / annotation reader / evaluator wrapper
+against the golden values.
+"""
+import os
+import pickletools
+import sys
+import types
+import zipfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+
+
+# ---- a foreign package with the reference's layout: <pkg>.structures.image_list.ImageList / .bounding_box.BoxList ------------
+def _foreign_package(name="refpkg"):
+    if name + ".structures.image_list" in sys.modules:
+        return sys.modules[name + ".structures.image_list"].ImageList, sys.modules[name + ".structures.bounding_box"].BoxList
+    for m in (name, name + ".structures", name + ".structures.image_list", name + ".structures.bounding_box"):
+        mod = types.ModuleType(m)
+        mod.__path__ = []
+        sys.modules[m] = mod
+
+    class ImageList(object):                      # the whole surface of mega_core/structures/image_list.py:7-27
+        def __init__(self, tensors, image_sizes):
+            self.tensors, self.image_sizes = tensors, image_sizes
+
+        def to(self, *a, **k):
+            return ImageList(self.tensors.to(*a, **k), self.image_sizes)
+
+    class BoxList(object):                        # constructor + fields: what the detector needs to fill one in
+        def __init__(self, bbox, image_size, mode="xyxy"):
+            self.bbox, self.size, self.mode, self.extra_fields = bbox, image_size, mode, {}
+
+        def add_field(self, k, v):
+            self.extra_fields[k] = v
+
+        def get_field(self, k):
+            return self.extra_fields[k]
+
+        def fields(self):
+            return list(self.extra_fields)
+
+        def __len__(self):
+            return self.bbox.shape[0]
+
+        def to(self, device):
+            out = BoxList(self.bbox.to(device), self.size, self.mode)
+            for k, v in self.extra_fields.items():
+                out.add_field(k, v.to(device))
+            return out
+
+    ImageList.__module__ = name + ".structures.image_list"
+    BoxList.__module__ = name + ".structures.bounding_box"
+    sys.modules[name + ".structures.image_list"].ImageList = ImageList
+    sys.modules[name + ".structures.bounding_box"].BoxList = BoxList
+    return ImageList, BoxList
+
+
+def test_boxlist_geometry_matches_reference_class():
+    """resize (one ratio / two ratios), transpose, crop, area, convert, copy_with_fields vs bounding_box.py:55-247"""
+    from diffusionvid_amd.structures.bounding_box import FLIP_LEFT_RIGHT, FLIP_TOP_BOTTOM, BoxList
+    z = golden("g17_boundary_types")
+    for mode in ("xyxy", "xywh"):
+        bl = BoxList(torch.from_numpy(z[mode + ".in"]).clone(), (613, 347), mode=mode)
+        bl.add_field("labels", torch.arange(9))
+        bl.add_field("scores", torch.rand(9))
+        same = bl.resize((1226, 694))
+        odd = bl.resize((1000, 563))
+        assert same.size == (1226, 694) and odd.size == (1000, 563) and same.mode == mode
+        assert odd.mode == str(z[mode + ".resize_odd_mode"]) == mode
+        np.testing.assert_array_equal(same.bbox.numpy(), z[mode + ".resize_same"])
+        np.testing.assert_array_equal(odd.bbox.numpy(), z[mode + ".resize_odd"])
+        np.testing.assert_array_equal(bl.transpose(FLIP_LEFT_RIGHT).bbox.numpy(), z[mode + ".flip_lr"])
+        np.testing.assert_array_equal(bl.transpose(FLIP_TOP_BOTTOM).bbox.numpy(), z[mode + ".flip_tb"])
+        c = bl.crop((40, 25, 411, 300))
+        np.testing.assert_array_equal(c.bbox.numpy(), z[mode + ".crop"])
+        assert tuple(c.size) == tuple(z[mode + ".crop_size"])
+        np.testing.assert_array_equal(bl.area().numpy(), z[mode + ".area"])
+        np.testing.assert_array_equal(bl.convert("xyxy").bbox.numpy(), z[mode + ".back"])
+        assert sorted(odd.fields()) == list(z[mode + ".fields_after_resize"])
+        assert torch.equal(odd.get_field("labels"), bl.get_field("labels"))
+        assert bl.copy_with_fields(["scores", "missing"], skip_missing=True).fields() == list(z[mode + ".copy_fields"])
+        with pytest.raises(KeyError):
+            bl.copy_with_fields("missing")
+        with pytest.raises(NotImplementedError):
+            bl.transpose(2)
+
+
+def _collated_item(z, image_list_cls, device="cpu"):
+    """the dict BatchCollator(32, "diffusion") made from one dataset item (values from the golden), frames wrapped in
+    `image_list_cls`, moved with `.to(device)` as engine/inference.py:34-40 does"""
+    wrap = lambda t, s: image_list_cls(torch.from_numpy(z[t]).clone(), [torch.Size(int(v) for v in z[s])]).to(device)     # noqa: E731
+    return {"cur": wrap("coll.cur", "coll.cur_size"),
+            "ref_l": [wrap("coll.cur", "coll.cur_size"), wrap("coll.ref_l1", "coll.ref_l1_size")],
+            "ref_g": [wrap("coll.ref_g0", "coll.ref_g0_size")],
+            "frame_category": 0, "frame_id": 0, "start_id": 0, "end_id": 20, "seg_len": 21, "last_queue_id": 7,
+            "pattern": "val/vid00/%06d", "img_dir": "x/%s.JPEG", "transforms": None}
+
+
+def test_collator_padding_matches_reference_and_foreign_image_lists_are_accepted():
+    from diffusionvid_amd.structures.image_list import ImageList, is_image_list, to_image_list
+    z = golden("g17_boundary_types")
+    # this repo's to_image_list on the raw ragged frames = the reference collator's tensors and sizes
+    for frame, padded, size in (("coll.frames0", "coll.cur", "coll.cur_size"), ("coll.frames1", "coll.ref_l1", "coll.ref_l1_size"),
+                                ("coll.frames2", "coll.ref_g0", "coll.ref_g0_size")):
+        il = to_image_list((torch.from_numpy(z[frame]),), 32)
+        np.testing.assert_array_equal(il.tensors.numpy(), z[padded])
+        assert tuple(il.image_sizes[0]) == tuple(z[size])
+    assert sorted(_collated_item(z, ImageList).keys()) == list(z["coll.keys"])
+    FImageList, _ = _foreign_package()
+    f = FImageList(torch.zeros(1, 3, 64, 64), [torch.Size((37, 50))])
+    assert is_image_list(f) and not is_image_list(torch.zeros(3)) and not isinstance(f, ImageList)
+    mine = to_image_list(f)
+    assert isinstance(mine, ImageList) and mine.tensors is f.tensors and tuple(mine.image_sizes[0]) == (37, 50)
+    with pytest.raises(TypeError):
+        to_image_list(3.0)
+
+
+def _small_detector():
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), None, os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+    cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+    cfg.freeze()
+    return build_detection_model(cfg).eval()
+
+
+def test_forward_takes_the_reference_collators_dict_up_to_the_first_engine_call():
+    """A dict whose frames are another package's ImageList objects goes through DiffusionDet.forward / _forward_test exactly
+    like this repo's own: it reaches the first launch sequence (`_extract`) with the frames re-wrapped (same tensors, same
+    un-padded sizes) and the result class resolved to that package's BoxList."""
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    from diffusionvid_amd.structures.image_list import ImageList
+    z = golden("g17_boundary_types")
+    FImageList, FBoxList = _foreign_package()
+    m = _small_detector()
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_extract(frame_id, ref_l, ref_g, ahead, whwh, on_global=None):
+        seen.update(frame_id=frame_id, ref_l=ref_l, ref_g=ref_g, whwh=whwh)
+        raise Stop()
+
+    m._extract = fake_extract
+    item = _collated_item(z, FImageList)
+    with pytest.raises(Stop):
+        m(item)
+    assert seen["frame_id"] == 0 and seen["whwh"] == (50.0, 37.0)
+    assert len(seen["ref_l"]) == 2 and len(seen["ref_g"]) == 1
+    for got, src in zip(seen["ref_l"] + seen["ref_g"], item["ref_l"] + item["ref_g"]):
+        assert isinstance(got, ImageList) and got.tensors is src.tensors and list(got.image_sizes) == list(src.image_sizes)
+    assert m._result_cls is FBoxList
+    # this repo's own types and bare tensors keep this repo's result class
+    with pytest.raises(Stop):
+        m(_collated_item(z, ImageList))
+    assert m._result_cls is BoxList
+    m.boxlist_cls = FBoxList            # explicit choice wins
+    with pytest.raises(Stop):
+        m(_collated_item(z, ImageList))
+    assert m._result_cls is FBoxList
+
+
+def _write_vid_set(z, root):
+    os.makedirs(os.path.join(root, "ImageSets"))
+    for name, xml in zip(z["vid.names"], z["vid.xml"]):
+        path = os.path.join(root, "Annotations", "VID", str(name) + ".xml")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(str(xml))
+    index = os.path.join(root, "ImageSets", "VID_val_videos.txt")
+    with open(index, "w") as f:
+        f.write("\n".join(str(x) for x in z["vid.index_lines"]) + "\n")
+    return index
+
+
+def _golden_predictions(z, cls):
+    preds = []
+    for i in range(int(z["vid.nframes"])):
+        pr = cls(torch.from_numpy(z["vid.pr_box_%d" % i]), tuple(int(v) for v in z["vid.pr_wh_%d" % i]))
+        pr.add_field("scores", torch.from_numpy(z["vid.pr_sc_%d" % i]))
+        pr.add_field("labels", torch.from_numpy(z["vid.pr_lab_%d" % i]))
+        preds.append(pr)
+    return preds
+
+
+def test_annotations_and_do_vid_evaluation_match_reference(tmp_path):
+    """XML -> ground truth as the reference's VIDDataset parses it; do_vid_evaluation maps predictions from the resized frame
+    to the annotation's size, and its AP / result.txt equal the reference's on the same inputs."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.datasets.vid import VIDAnnotations, VIDFrameList, VIDMEGATestDataset
+    from diffusionvid_amd.data.evaluation import vid_eval
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    z = golden("g17_boundary_types")
+    index = _write_vid_set(z, str(tmp_path))
+    anno_dir = os.path.join(str(tmp_path), "Annotations", "VID")
+    cache = os.path.join(str(tmp_path), "VID_val_videos_anno.pkl")
+    an = VIDAnnotations(VIDFrameList(index), anno_dir, cache)
+    n = int(z["vid.nframes"])
+    for i in range(n):
+        gt = an.get_groundtruth(i)
+        np.testing.assert_array_equal(gt.bbox.numpy(), z["vid.gt_box_%d" % i])
+        np.testing.assert_array_equal(gt.get_field("labels").numpy(), z["vid.gt_lab_%d" % i])
+        info = an.get_img_info(i)
+        assert (info["width"], info["height"]) == tuple(z["vid.wh_%d" % i]) == tuple(gt.size)
+    assert os.path.exists(cache)
+    again = VIDAnnotations(VIDFrameList(index), None, cache)          # the cache alone is enough the second time
+    assert torch.equal(again.get_groundtruth(n - 1).bbox, an.get_groundtruth(n - 1).bbox)
+    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), None, os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+    ds = VIDMEGATestDataset(cfg, os.path.join(str(tmp_path), "Data", "VID"), index, anno_path=anno_dir)
+    assert ds.map_class_id_to_class_name(1) == "airplane"
+    with pytest.raises(RuntimeError):
+        VIDMEGATestDataset(cfg, "x", index).get_groundtruth(0)
+    preds = _golden_predictions(z, BoxList)
+    out = tmp_path / "out"
+    out.mkdir()
+    res = vid_eval.do_vid_evaluation(ds, preds, str(out))
+    np.testing.assert_allclose(res[0]["ap"], z["vid.ap"], rtol=0, atol=1e-12, equal_nan=True)
+    assert abs(res[0]["map"] - float(z["vid.map"])) < 1e-12
+    assert (out / "result.txt").read_text() == str(z["vid.result_txt"])
+    # without the size mapping the AP differs: the golden case does exercise it
+    raw = vid_eval.eval_detection_vid(preds, [ds.get_groundtruth(i) for i in range(n)])
+    assert abs(raw["map"] - float(z["vid.map"])) > 1e-3
+
+
+def test_engine_inference_evaluates_in_annotation_pixels(tmp_path):
+    """engine.inference.inference = the reference's inference(): predictions.pth + do_vid_evaluation on the dataset's own
+    ground truth (a model stand-in returns the golden predictions in the resized frame)."""
+    from diffusionvid_amd.data.datasets.vid import VIDAnnotations, VIDFrameList
+    from diffusionvid_amd.data.evaluation import vid_eval
+    from diffusionvid_amd.engine import inference as eng
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    z = golden("g17_boundary_types")
+    index = _write_vid_set(z, str(tmp_path))
+    an = VIDAnnotations(VIDFrameList(index), os.path.join(str(tmp_path), "Annotations", "VID"))
+    preds = _golden_predictions(z, BoxList)
+
+    class DS:
+        annotations = an
+        get_img_info, get_groundtruth = an.get_img_info, an.get_groundtruth
+
+        def __getitem__(self, i):
+            return {"frame_id": i, "end_id": 8, "frame_category": 1, "ref_l": []}, None, [i]
+
+    class Model:
+        infer_batch, lookahead = 1, 1
+
+        def eval(self):
+            return self
+
+        def __call__(self, images):
+            return [preds[images["frame_id"]]]
+
+    out = str(tmp_path / "o")
+    got, ev = eng.inference(Model(), DS(), range(len(preds)), torch.device("cpu"), out,
+                            class_module=vid_eval.REFERENCE_BOXLIST_MODULE)
+    assert abs(ev["map"] - float(z["vid.map"])) < 1e-12
+    assert open(os.path.join(out, "result.txt")).read() == str(z["vid.result_txt"])
+    assert tuple(got[0].size) == tuple(z["vid.pr_wh_0"])          # the returned / saved predictions stay in the resized frame
+    # the same through a ground-truth list
+    gts = [an.get_groundtruth(i) for i in range(len(preds))]
+    _, ev2 = eng.inference(Model(), type("D", (), {"__getitem__": DS.__getitem__})(), range(len(preds)), torch.device("cpu"), None, gt_boxlists=gts)
+    assert abs(ev2["map"] - float(z["vid.map"])) < 1e-12
+    # the file names the reference's class and reads back here without that package
+    zf = zipfile.ZipFile(os.path.join(out, "predictions.pth"))
+    data = zf.read([n for n in zf.namelist() if n.endswith("data.pkl")][0])
+    globs = [arg for op, arg, _ in pickletools.genops(data) if op.name in ("GLOBAL", "STACK_GLOBAL") and arg]
+    assert "mega_core.structures.bounding_box BoxList" in globs and not any("diffusionvid_amd" in g for g in globs)
+    assert "mega_core" not in sys.modules
+    back = vid_eval.load_predictions(os.path.join(out, "predictions.pth"))
+    assert all(isinstance(b, BoxList) for b in back)
+    assert torch.equal(back[4].bbox, preds[4].bbox) and torch.equal(back[4].get_field("labels"), preds[4].get_field("labels"))
+
+
+def test_reference_written_predictions_file_loads_without_the_reference():
+    """tests/golden/g17_predictions_ref.pth = torch.save(list of the reference's BoxList) (engine/inference.py:168)"""
+    from diffusionvid_amd.data.evaluation import vid_eval
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    z = golden("g17_boundary_types")
+    assert "mega_core" not in sys.modules
+    preds = vid_eval.load_predictions(os.path.join(ROOT, "tests", "golden", "g17_predictions_ref.pth"))
+    assert len(preds) == 3 and all(type(p) is BoxList for p in preds)
+    for i, p in enumerate(preds):
+        np.testing.assert_array_equal(p.bbox.numpy(), z["vid.pr_box_%d" % i])
+        np.testing.assert_array_equal(p.get_field("scores").numpy(), z["vid.pr_sc_%d" % i])
+        assert tuple(p.size) == tuple(z["vid.pr_wh_%d" % i]) and p.mode == "xyxy"
+        assert p.resize((100, 60)).size == (100, 60)              # a live object of this repo's class
+
+
+@pytest.mark.gpu
+def test_one_call_from_foreign_typed_dict_on_gpu():
+    """One 8-frame call whose frames arrive as another package's ImageList objects (the reference collator's dict after
+    `.to(device)`): same detections, bit for bit, as the call on this repo's types -- returned as that package's BoxList."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    from diffusionvid_amd.utils import synthetic
+    FImageList, FBoxList = _foreign_package()
+    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), None, os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+    cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+    cfg.freeze()
+    model = build_detection_model(cfg)
+    model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+    model = model.to("cuda:0").eval()
+    model.noise_fn = synthetic.noise_fn
+    ds = SyntheticVIDDataset([8], cfg, height=120, width=180, device="cpu", smooth=True)
+    images, _, ids = ds[0]
+    native = dict(images)
+    native["cur"] = images["cur"].to("cuda:0")
+    native["ref_l"] = [im.to("cuda:0") for im in images["ref_l"]]
+    native["ref_g"] = [im.to("cuda:0") for im in images["ref_g"]]
+    foreign = dict(images)
+    foreign["cur"] = FImageList(images["cur"].tensors, images["cur"].image_sizes).to("cuda:0")
+    foreign["ref_l"] = [FImageList(im.tensors, im.image_sizes).to("cuda:0") for im in images["ref_l"]]
+    foreign["ref_g"] = [FImageList(im.tensors, im.image_sizes).to("cuda:0") for im in images["ref_g"]]
+    with torch.no_grad():
+        a = model(native)
+        b = model(foreign)
+    assert len(a) == len(b) == 8
+    assert all(type(x) is BoxList for x in a) and all(type(x) is FBoxList for x in b)
+    for x, y in zip(a, b):
+        assert x.size == y.size and len(x) > 0
+        assert torch.equal(x.bbox, y.bbox)
+        assert torch.equal(x.get_field("scores"), y.get_field("scores")) and torch.equal(x.get_field("labels"), y.get_field("labels"))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/mega_core/structures"), reason="the reference tree exists in the build container only")
+def test_real_reference_classes_round_trip_in_the_build_container(tmp_path):
+    """With the reference importable (build container): its real ImageList selects its real BoxList as result class, and a
+    predictions.pth written by this repo under the reference's class path unpickles into the reference's class."""
+    import subprocess
+    code = r'''
+import sys, torch
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, %r)
+from mega_core.structures.image_list import ImageList as RImageList
+from mega_core.structures.bounding_box import BoxList as RBoxList
+from diffusionvid_amd.modeling.detector.diffusion_det import _result_class
+from diffusionvid_amd.structures.image_list import to_image_list
+from diffusionvid_amd.structures.bounding_box import BoxList
+from diffusionvid_amd.data.evaluation import vid_eval
+il = RImageList(torch.zeros(1, 3, 32, 32), [torch.Size((30, 31))])
+assert _result_class(il) is RBoxList and _result_class(to_image_list(il)) is BoxList
+b = BoxList(torch.tensor([[1., 2., 30., 40.]]), (100, 60)); b.add_field("scores", torch.tensor([0.5])); b.add_field("labels", torch.tensor([7]))
+vid_eval.save_predictions([b], %r, vid_eval.REFERENCE_BOXLIST_MODULE)
+back = torch.load(%r, weights_only=False)
+assert type(back[0]) is RBoxList and torch.equal(back[0].bbox, b.bbox) and back[0].size == (100, 60)
+r = back[0].resize((200, 120)); assert torch.equal(r.bbox, b.resize((200, 120)).bbox)
+print("ok")
+''' % (ROOT, str(tmp_path / "p.pth"), str(tmp_path / "p.pth"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+class _ForeignNode(dict):
+    """a yacs-like node that is NOT this repo's CfgNode: nested dict with attribute access, AttributeError on unknown keys"""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def _node_from_flat(flat):
+    root = _ForeignNode()
+    for key, v in flat.items():
+        node = root
+        parts = key.split(".")
+        for p in parts[:-1]:
+            node = node.setdefault(p, _ForeignNode())
+        node[parts[-1]] = v
+    return root
+
+
+@pytest.mark.parametrize("tag", ["r101", "swinb"])
+def test_detector_builds_from_the_reference_config_node(tag):
+    """`build_detection_model(cfg)` with the REFERENCE's config: defaults.py + BASE_RCNN_1gpu.yaml + add_diffusiondet_config +
+    the model yaml, merged by the reference (tools/test_net.py:76-82) and stored flattened in golden g17 -- handed over as a
+    foreign attribute-dict node, not this repo's CfgNode.  Every key the detector reads must exist under the reference's name
+    (the MI355X extensions -- LOOKAHEAD_BATCHES, BLOCKS_OVERRIDE, SKIP_UNOBSERVABLE -- must default when absent), and the
+    values this repo's own `get_cfg` derives from the same files must agree."""
+    import json
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    flat = json.loads(str(golden("g17_boundary_types")["cfg." + tag]))
+    assert "INPUT.LOOKAHEAD_BATCHES" not in flat and "MODEL.RESNETS.BLOCKS_OVERRIDE" not in flat
+    flat["MODEL.DEVICE"] = "cpu"
+    m = build_detection_model(_node_from_flat(flat)).eval()
+    yaml_name = {"r101": "vid_R_101_DiffusionVID.yaml", "swinb": "vid_Swin_B_DiffusionVID.yaml"}[tag]
+    mine = get_cfg(os.path.join(ROOT, "configs", yaml_name), None, os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+    ref = build_detection_model(mine).eval()
+    assert m.lookahead == 1 and m.infer_batch == ref.infer_batch == flat["INPUT.INFER_BATCH"] and m.num_proposals == 300 and m.sampling_timesteps == ref.sampling_timesteps
+    assert (m.swin is None) == (tag == "r101") and m.swin == ref.swin and getattr(m, "res_blocks", None) == getattr(ref, "res_blocks", None)
+    a, b = m.state_dict(), ref.state_dict()
+    assert list(a.keys()) == list(b.keys()) and all(a[k].shape == b[k].shape for k in a)
+    # every value this repo's config system holds for a key the reference also has is the reference's value
+
+    def walk(node, prefix=""):
+        for k, v in node.items():
+            if hasattr(v, "items"):
+                yield from walk(v, prefix + k + ".")
+            else:
+                yield prefix + k, v
+
+    norm = lambda v: list(v) if isinstance(v, (tuple, list)) else v          # noqa: E731
+    # this repo's trimmed YAMLs leave out the sections of training, RPN and the generic ROI heads (out of scope: SURVEY.md 8);
+    # everything else must agree
+    skip = ("MODEL.RPN.", "MODEL.ROI_HEADS.", "SOLVER.", "DATASETS.TRAIN", "INPUT.MIN_SIZE_TRAIN", "INPUT.MAX_SIZE_TRAIN", "MODEL.DEVICE",
+            "DATALOADER.NUM_WORKERS", "MODEL.VID.MEGA.MEMORY_MANAGEMENT_SIZE_TRAIN", "MODEL.VID.MEGA.REF_NUM_GLOBAL")
+    checked, bad = 0, []
+    for key, v in walk(mine):
+        if key in flat and not key.startswith(skip):
+            checked += 1
+            if norm(v) != norm(flat[key]):
+                bad.append((key, v, flat[key]))
+    assert not bad, bad
+    assert checked >= 90, checked
+    assert norm(mine.MODEL.ROI_HEADS.IN_FEATURES) == flat["MODEL.ROI_HEADS.IN_FEATURES"]

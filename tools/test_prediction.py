@@ -19,22 +19,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffusionvid_amd.data.evaluation import vid_eval  # noqa: E402
-from diffusionvid_amd.structures.bounding_box import BoxList  # noqa: E402
-
-CLASSES = ['__background__', 'airplane', 'antelope', 'bear', 'bicycle', 'bird', 'bus', 'car', 'cattle', 'dog', 'domestic_cat',
-           'elephant', 'fox', 'giant_panda', 'hamster', 'horse', 'lion', 'lizard', 'monkey', 'motorcycle', 'rabbit', 'red_panda',
-           'sheep', 'snake', 'squirrel', 'tiger', 'train', 'turtle', 'watercraft', 'whale', 'zebra']
-
-
-def rescale(pred, size_wh):
-    if tuple(pred.size) == tuple(size_wh):
-        return pred
-    sx, sy = size_wh[0] / pred.size[0], size_wh[1] / pred.size[1]
-    out = BoxList(pred.bbox * torch.tensor([sx, sy, sx, sy]), size_wh, mode="xyxy")
-    for k in ("scores", "labels"):
-        out.add_field(k, pred.get_field(k))
-    return out
-
 
 def main():
     ap = argparse.ArgumentParser()
@@ -50,17 +34,16 @@ def main():
     gts = gt["gt"]
     if len(gts) != len(preds):
         raise SystemExit("predictions.pth holds %d frames, the ground truth %d" % (len(preds), len(gts)))
-    preds = [rescale(p, g.size) for p, g in zip(preds, gts)]
     motion = None
     if args.motion_specific:
         motion = vid_eval.load_motion_ious(args.motion_iou_mat) if args.motion_iou_mat else gt.get("motion_ious")
         if motion is None:
             raise SystemExit("--motion-specific needs --motion-iou-mat or 'motion_ious' in the ground-truth file")
-    res = vid_eval.eval_detection_vid(preds, gts, motion_ious=motion)
-    text = vid_eval.result_string(res, CLASSES)
-    print(text)
-    with open(os.path.join(folder, "result.txt"), "w") as f:
-        f.write(text)
+    # do_vid_evaluation maps every prediction to its ground truth's size (BoxList.resize), evaluates AP50 (+ CorLoc) and
+    # writes folder/result.txt
+    vid_eval.do_vid_evaluation(vid_eval.GroundTruthList(gts, motion=motion), preds, folder, motion_specific=args.motion_specific)
+    with open(os.path.join(folder, "result.txt")) as f:
+        print(f.read())
 
 
 if __name__ == "__main__":
