@@ -48,6 +48,7 @@ SIGNATURES = {
                                             c_void_p, c_void_p, c_void_p]),
     "dvid_select_topk_features": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                           c_void_p]),
+    "dvid_counter_normal": (c_int, [c_void_p, C.c_int64, c_int, C.c_uint64, c_void_p]),
     "dvid_noise_to_boxes": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p]),
     "dvid_ddim_renew_step": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_float] * 9 + [c_void_p]),
     "dvid_postproc_topk_nms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int,

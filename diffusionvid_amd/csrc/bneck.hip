@@ -392,10 +392,9 @@ __global__ __launch_bounds__(512) void bneck64_tail_kernel(BneckParams p) {
 template <bool SC, int TN>
 int bn_launch(const BneckParams& p, hipStream_t s) {
     static_assert(kBytes <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
+    if (first_on_device(attr_set)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck64_tail_kernel<SC, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
-        attr_set = true;
     }
     static const int lds_env = getenv("DVID_BNECK_LDS") ? atoi(getenv("DVID_BNECK_LDS")) : 0;          // diagnostics: less than the whole LDS (>= kBias + 4096)
     hipLaunchKernelGGL((bneck64_tail_kernel<SC, TN>), dim3(p.ntiles), dim3(512), lds_env >= kBias + 4096 && lds_env <= kBytes ? lds_env : kBytes, s, p);
@@ -413,8 +412,14 @@ int bn_launch(const BneckParams& p, hipStream_t s) {
 //   [128][32] that multiply exactly those channels (8 + 8 MFMAs per wave), so the block output is consumed as it is produced
 //   and only the next conv1's accumulators (64 registers) live across steps.
 // The residual of a step's 32 channels is requested four steps ahead (by DMA into a per-wave ring in the halo region, which is free
-// after conv2; the first four tiles into registers); loads retire in issue order, so the step's own wait for its weights is also the
-// wait for that residual.  LDS: t1 halo 10 x 34 pixels x 256 B (88 KB) + ring 64 KB
+// after conv2; the first four tiles into registers, requested BEFORE any DMA piece).  DMA pieces retire in issue order AMONG THEMSELVES,
+// so the step's own counted wait for its weight pieces is also the wait for that residual's pieces.  CONTRACT of every counted wait in
+// this file (wait_n / dma_cnt): it counts LDS-DMA pieces only.  An ordinary load does NOT retire in order with OLDER pieces (a piece
+// decrements vmcnt only after its LDS write: when the LDS pipe is busy a younger ordinary load retires first and vmcnt(N) is reached
+// with an older piece still in flight -- the fault described in DESIGN.md section 5).  So no ordinary global load may sit among the
+// youngest N operations of a vmcnt(N) that covers a piece; loads issued BEFORE the pieces are fine (data returns in issue order), and
+// stores are never counted (a wait that counts too few operations only waits longer).
+// tools/check_dma_waits.py compiles this file to assembly and checks that rule on every counted wait (tests/test_host_logic.py).  LDS: t1 halo 10 x 34 pixels x 256 B (88 KB) + ring 64 KB
 // + biases 3 KB.  CONV2 = false: the block's conv2 ran as its own launch (res3's first block: 3x3 / stride 2) and `t1` is its output.
 // K order of conv2: tap, then channel (igemm2's; the chunked patch kernel of conv3x3.hip sums channel-chunk-major), so this
 // kernel is bit-identical to the layer-by-layer launches on igemm2 and differs from the patch kernel in fp32 summation order only;
@@ -709,10 +714,9 @@ __global__ __launch_bounds__(512) void bneck128_tail_kernel(Bneck128Params p) {
 template <bool CONV2, bool TAIL>
 int bn128_launch(const Bneck128Params& p, hipStream_t s) {
     static_assert(k8Bytes <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
+    if (first_on_device(attr_set)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck128_tail_kernel<CONV2, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, k8Bytes));
-        attr_set = true;
     }
     static const int lds_env = getenv("DVID_BNECK_LDS") ? atoi(getenv("DVID_BNECK_LDS")) : 0;          // diagnostics: less than the whole LDS (>= k8Bias + 3072)
     hipLaunchKernelGGL((bneck128_tail_kernel<CONV2, TAIL>), dim3(p.ntiles), dim3(512), lds_env >= k8Bias + 3072 && lds_env <= k8Bytes ? lds_env : k8Bytes, s, p);

@@ -22,6 +22,48 @@ __global__ void noise_to_boxes_kernel(const float* __restrict__ x, float* __rest
     *reinterpret_cast<float4v*>(boxes + i * 4) = o;
 }
 
+// Counter-based N(0, 1) draws (the reference draws with torch.randn on the device, diffusion_det.py:449,:542,:587,:595; a draw here
+// is a pure function of (key, element index), so calls need no generator state, ranks need no stream position, and the CPU oracle
+// regenerates the same values -- oracle/noise.py).  Philox4x32-10 (Salmon et al., SC'11): counter = (element / 4, 0, 0, 0), key =
+// the 64-bit draw key of the image; its four 32-bit outputs make two Box-Muller pairs in fp64 (u = (x + 0.5) 2^-32: never 0 or 1),
+// rounded once to fp32: element 4 q + {0, 1} = r cos / r sin of (x0, x1), element 4 q + {2, 3} of (x2, x3).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void counter_normal_kernel(float* __restrict__ out, long per_image, int n_images, uint64_t key0) {
+    const long quads = (per_image + 3) / 4;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int img = blockIdx.y;
+    if (q >= quads) return;
+    const uint64_t key = key0 + (uint64_t)img;
+    uint32_t x[4];
+    philox4x32_10((uint32_t)q, (uint32_t)((uint64_t)q >> 32), 0u, 0u, (uint32_t)key, (uint32_t)(key >> 32), x);
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double u1 = ((double)x[2 * h] + 0.5) * (1.0 / 4294967296.0), u2 = ((double)x[2 * h + 1] + 0.5) * (1.0 / 4294967296.0);
+        const double r = sqrt(-2.0 * log(u1)), th = 6.283185307179586476925286766559 * u2;
+        z[2 * h] = (float)(r * cos(th));
+        z[2 * h + 1] = (float)(r * sin(th));
+    }
+    float* dst = out + (long)img * per_image + q * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (q * 4 + e < per_image) dst[e] = z[e];
+}
+
 __global__ void apply_deltas_kernel(const float* __restrict__ deltas, int delta_ld, const float* __restrict__ boxes,
                                     float* __restrict__ out, int n, float wx, float wy, float ww, float wh, float clamp,
                                     int* __restrict__ bad_flag) {
@@ -155,6 +197,14 @@ __global__ __launch_bounds__(256) void ddim_renew_kernel(const float* __restrict
 int dvid_noise_to_boxes_launch(const float* x, float* boxes, int n, float scale, float w, float h, hipStream_t s) {
     if (n == 0) return DVID_OK;
     hipLaunchKernelGGL(noise_to_boxes_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, x, boxes, n, scale, w, h);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_counter_normal_launch(float* out, long per_image, int n_images, uint64_t key0, hipStream_t s) {
+    if (per_image <= 0 || n_images <= 0) return DVID_OK;
+    const long quads = (per_image + 3) / 4;
+    hipLaunchKernelGGL(counter_normal_kernel, dim3((unsigned)ceil_div(quads, 256L), (unsigned)n_images), dim3(256), 0, s, out, per_image, n_images, key0);
     LAUNCH_CHECK();
     return DVID_OK;
 }

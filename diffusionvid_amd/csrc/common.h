@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -31,6 +32,16 @@ typedef float float16v __attribute__((ext_vector_type(16)));
     } while (0)
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of a function ON a device: a process that runs models on
+// several devices (the detector scopes the device per call) has to set it once per device, not once per process.
+// `mask` holds one bit per device ordinal; -> true for the first caller on the current device.
+static inline bool first_on_device(std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    return (mask.load(std::memory_order_relaxed) & bit) == 0 && (mask.fetch_or(bit) & bit) == 0;
+}
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -397,10 +397,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(IgemmParams p, int 
 }
 
 int launch_c64(IgemmParams p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned long long> attr_done{0};          // one bit per device: the attribute belongs to (function, device)
+    if (first_on_device(attr_done)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C64_BYTES));
-        attr_done = true;
     }
     const int tiles_x = ceil_div(p.W, TW);
     p.tiles_m = tiles_x * ceil_div((p.M / (p.H * p.W)) * p.H, TH);
@@ -545,10 +544,9 @@ int launch_s2d(IgemmParams p, hipStream_t s) {
 template <int BN, int WN>
 int launch(IgemmParams p, hipStream_t s) {
     using C = Halo<BN, WN>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned long long> attr_done{0};          // one bit per device: the attribute belongs to (function, device)
+    if (first_on_device(attr_done)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, C::kBytes));
-        attr_done = true;
     }
     const int tiles_x = ceil_div(p.W, TW), tiles_y = ceil_div((p.M / (p.H * p.W)) * p.H, TH);
     p.tiles_m = tiles_x * tiles_y;

@@ -204,10 +204,9 @@ int dvid_fps_launch(const float* dist, int n, int m, int bs_emul, int* idx, hipS
         return DVID_OK;
     }
     const size_t smem = (size_t)n * 4;
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<unsigned long long> attr{0};          // one bit per device: the attribute belongs to (function, device)
+    if (first_on_device(attr)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr = true;
     }
     hipLaunchKernelGGL(fps_kernel, dim3(1), dim3(1024), smem, s, dist, n, m, bs, bits, idx);
     LAUNCH_CHECK();

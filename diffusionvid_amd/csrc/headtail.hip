@@ -380,10 +380,9 @@ template <int MT>
 int launch(const HeadTailParams& p, hipStream_t s) {
     constexpr int BM = 32 * MT;
     constexpr int smem = 2 * BM * APITCH + BM * CPITCH * 4;
-    static bool attr_set = false;
-    if (!attr_set && smem > 64 * 1024) {
+    static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
+    if (first_on_device(attr_set) && smem > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_tail_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
     }
     hipLaunchKernelGGL(head_tail_kernel<MT>, dim3((unsigned)((p.R + BM - 1) / BM)), dim3(512), smem, s, p);
     LAUNCH_CHECK();

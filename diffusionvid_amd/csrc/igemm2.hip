@@ -476,11 +476,10 @@ template <int BM, int BN, int BKT, int NSTAGE, int WN, int AK, int EPI>
 int launch2k(const IgemmParams& p, hipStream_t s) {
     constexpr int smem = Smem2<BM, BN, BKT, NSTAGE>::kBytes;
     if (smem > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
+        if (first_on_device(attr_set)) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, AK, EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_set = true;
         }
     }
     const int nsplit = p.splitk > 1 ? p.splitk : 1;

@@ -133,6 +133,7 @@ int dvid_head_tail_launch(const HeadTailParams& p, hipStream_t s);
 // boxes.hip
 int dvid_apply_deltas_launch(const float* deltas, int delta_ld, const float* boxes, float* out, int n, float wx, float wy, float ww,
                              float wh, float clamp, int* bad_flag, hipStream_t s);
+int dvid_counter_normal_launch(float* out, long per_image, int n_images, uint64_t key0, hipStream_t s);
 int dvid_noise_to_boxes_launch(const float* x, float* boxes, int n, float scale, float w, float h, hipStream_t s);
 int dvid_topk_mask_launch(const float* logits, int n_img, int m, int c, int k1, int k2, const float* feats, int d, float* out1,
                           float* out2, hipStream_t s);

@@ -253,7 +253,11 @@ struct dvid_model {
     DevBuf img8, bufX, bufY, bufT1, bufT2, bufSC, c3, c4, c5, lat[3];
     DevBuf sw_x, sw_x2, sw_ln16, sw_qkv16, sw_attn16, sw_h16;   // Swin token buffers
     DevBuf roi, params, dyn, qkv, attn16, f32a, f32b, f32c, f32d, h16a, h16b, hid16, ss, deltas, kvproj, mem16, splitk, vt;
-    std::map<std::pair<int, int64_t>, DevBuf> ss_rows;     // (head slot, t) -> device scale/shift row [bt_out]
+    // (head slot, t) -> device scale/shift row [bt_out], sub-allocated from slabs of kSsSlabRows rows (a sampler that walks all
+    // 1000 time steps on 4 head slots ends at 16 allocations of 512 KB, not 4000 of 2 KB; rows live until the model is destroyed)
+    std::map<std::pair<int, int64_t>, float*> ss_rows;
+    std::vector<DevBuf> ss_slabs;
+    size_t ss_slab_used = 0;          // rows taken from the last slab
 
     int mem_lk = 0;       // rows of the global memory whose K/V projections sit in kvproj (0: none)
 
@@ -808,7 +812,7 @@ int dvid_model_destroy(dvid_model* m) {
                       &m->lat[1], &m->lat[2], &m->roi, &m->params, &m->dyn, &m->qkv, &m->attn16, &m->f32a, &m->f32b, &m->f32c,
                       &m->f32d, &m->h16a, &m->h16b, &m->hid16, &m->ss, &m->deltas, &m->kvproj, &m->mem16, &m->splitk, &m->vt};
     for (DevBuf* b : bufs) b->release();
-    for (auto& kv : m->ss_rows) kv.second.release();
+    for (DevBuf& b : m->ss_slabs) b.release();
     delete m;
     return DVID_OK;
 }
@@ -1297,12 +1301,18 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
                 for (int i = 0; i < td; ++i) acc += (double)hw.bt_w[(size_t)o * td + i] * sl[i];
                 row[o] = (float)acc;
             }
-            DevBuf buf;
-            TRY(buf.ensure(row.size() * sizeof(float)));
-            HIP_TRY(hipMemcpy(buf.p, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice));   // once per distinct (head, t)
-            it = m->ss_rows.emplace(key, buf).first;
+            constexpr size_t kSsSlabRows = 256, kSsRowFloats = 512;          // bt_out = 2 d <= 512 floats
+            if ((size_t)hw.bt_out > kSsRowFloats) return DVID_ERR_UNSUPPORTED;
+            if (m->ss_slabs.empty() || m->ss_slab_used == kSsSlabRows) {
+                m->ss_slabs.emplace_back();
+                TRY(m->ss_slabs.back().ensure(kSsSlabRows * kSsRowFloats * sizeof(float)));
+                m->ss_slab_used = 0;
+            }
+            float* dst = m->ss_slabs.back().as<float>() + (m->ss_slab_used++) * kSsRowFloats;
+            HIP_TRY(hipMemcpy(dst, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice));   // once per distinct (head, t)
+            it = m->ss_rows.emplace(key, dst).first;
         }
-        *dev = it->second.as<float>();
+        *dev = it->second;
         return DVID_OK;
     };
     const float* ss_dev = nullptr;
@@ -1413,6 +1423,13 @@ int dvid_select_topk_features(const float* logits, int n_frames, int mm, int num
     g_err[0] = 0;
     TRY(dvid_topk_mask_launch(logits, n_frames, mm, num_classes, k1, k2, feats, hidden, out_k1, out_k2,
                               reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_counter_normal(float* out, int64_t per_image, int n_images, uint64_t key0, void* stream) {
+    g_err[0] = 0;
+    if (!out || per_image < 0 || n_images < 0 || n_images > 65535) FAIL(DVID_ERR_ARG, "dvid_counter_normal: bad arguments");
+    TRY(dvid_counter_normal_launch(out, (long)per_image, n_images, key0, reinterpret_cast<hipStream_t>(stream)));
     return DVID_OK;
 }
 

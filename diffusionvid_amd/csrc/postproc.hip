@@ -304,11 +304,10 @@ int dvid_topk_candidates_launch(const float* logits, const float* boxes, int n_i
         const int mpad = next_pow2(m);
         const size_t smem2 = (size_t)mpad * 8 + (size_t)m * c * 4 + 2048 * 4;
         if (!full_sort && m * c > m && smem2 <= 150 * 1024) {
-            static bool attr2 = false;
-            if (!attr2) {
+            static std::atomic<unsigned long long> attr2{0};          // one bit per device: the attribute belongs to (function, device)
+            if (first_on_device(attr2)) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             150 * 1024));
-                attr2 = true;
             }
             hipLaunchKernelGGL(topk_select_kernel, dim3(n_img, nsets), dim3(1024), smem2, s, logits, boxes, n_img, m, c, mpad, cand_boxes,
                                cand_scores, cand_labels);
@@ -319,11 +318,10 @@ int dvid_topk_candidates_launch(const float* logits, const float* boxes, int n_i
     const int npad = next_pow2(m * c);
     const size_t smem = (size_t)npad * 8;
     if (smem > 160 * 1024) return DVID_ERR_UNSUPPORTED;
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<unsigned long long> attr{0};          // one bit per device: the attribute belongs to (function, device)
+    if (first_on_device(attr)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_candidates_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     hipLaunchKernelGGL(topk_candidates_kernel, dim3(n_img, nsets), dim3(1024), smem, s, logits, boxes, n_img, m, c, npad, cand_boxes,
                        cand_scores, cand_labels);
@@ -340,11 +338,10 @@ int dvid_nms_frames_launch(const float* cand_boxes, const float* cand_scores, co
     const int words = (n + 63) / 64;
     const size_t smem = (size_t)npad * 8 + (size_t)n * (16 + 4 + 4) + 64 + (size_t)((n + 1) & ~1) * 4 + (size_t)n * words * 8;
     if (smem > 160 * 1024) return DVID_ERR_UNSUPPORTED;
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<unsigned long long> attr{0};          // one bit per device: the attribute belongs to (function, device)
+    if (first_on_device(attr)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
-        attr = true;
     }
     hipLaunchKernelGGL(nms_frame_kernel, dim3(n_img), dim3(1024), smem, s, cand_boxes, cand_scores, cand_labels, n, npad, img_w, img_h,
                        iou, use_nms, out_cap, out_boxes, out_scores, out_labels, out_counts);

@@ -461,10 +461,9 @@ template <int K, int D, bool HAS_RES, bool RELU>
 int ws2_launch_k(const IgemmParams& p, hipStream_t s) {
     constexpr int smem = Ws2Smem<K, D>::kBytes;
     static_assert(smem <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
+    if (first_on_device(attr_set)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat2_kernel<K, D, HAS_RES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
     }
     hipLaunchKernelGGL((wstat2_kernel<K, D, HAS_RES, RELU>), dim3(256), dim3(512), smem, s, p, p.Cout / 256);
     LAUNCH_CHECK();
@@ -482,10 +481,9 @@ template <int K, int D, int TN, bool HAS_RES, int RELU>
 int ws_launch_k(const IgemmParams& p, hipStream_t s) {
     constexpr int smem = WsSmem<K, D, TN, HAS_RES>::kBytes;
     static_assert(smem <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
+    if (first_on_device(attr_set)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat_kernel<K, D, TN, HAS_RES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
     }
     hipLaunchKernelGGL((wstat_kernel<K, D, TN, HAS_RES, RELU>), dim3(256), dim3(512), smem, s, p, p.Cout / (256 * TN));
     LAUNCH_CHECK();

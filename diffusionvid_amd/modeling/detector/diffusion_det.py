@@ -234,12 +234,16 @@ class DiffusionDet(nn.Module):
         return out
 
     def _noise(self, kind, frame_id, step, image, shape):
+        if getattr(self.noise_fn, "on_device", False):          # counter-based draws generated by a kernel (synthetic.DeviceNoise)
+            return self.noise_fn.draw(kind, frame_id, step, image, 1, shape, self.device)[0]
         if self.noise_fn is not None:
             return self.noise_fn(kind, frame_id, step, image, shape).to(self.device, torch.float32)
         return torch.randn(shape, device=self.device)
 
     def _noise_images(self, kind, frame_id, step, batch, shape):
         """[batch, *shape]: one draw per image of the batch, uploaded as ONE tensor (an injected noise_fn draws on the host)"""
+        if getattr(self.noise_fn, "on_device", False):          # consecutive images have consecutive keys: one launch
+            return self.noise_fn.draw(kind, frame_id, step, 0, batch, shape, self.device)
         if self.noise_fn is not None:
             host = torch.stack([self.noise_fn(kind, frame_id, step, i, shape) for i in range(batch)])
             return host.to(self.device, torch.float32)

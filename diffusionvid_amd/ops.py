@@ -168,6 +168,18 @@ def noise_to_boxes(x, snr_scale, img_w, img_h):
     return out
 
 
+def counter_normal(key0, n_images, shape, device=None):
+    """[n_images, *shape] N(0, 1) draws generated on the device: image i is the stream keyed `key0 + i` (dvid_counter_normal)."""
+    if not torch.cuda.is_available():
+        raise _lib.DvidError("no HIP device visible: counter_normal draws on the GPU (no CPU fallback; the CPU restatement is oracle/noise.py)")
+    out = torch.empty((n_images,) + tuple(shape), dtype=torch.float32, device=device or torch.device("cuda", torch.cuda.current_device()))
+    per = 1
+    for v in shape:
+        per *= int(v)
+    call("dvid_counter_normal", ptr(out), per, int(n_images), int(key0) & 0xFFFFFFFFFFFFFFFF, stream_ptr())
+    return out
+
+
 def ddim_renew_step(logits, boxes, x_t, noise, fresh, whwh, snr_scale, sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_next, coef_c,
                     sigma, keep_thr=0.5):
     """Box renewal + DDIM update (diffusion_det.py:559-596); all [n, M, 4] fp32, logits [n, M, C]."""
@@ -365,12 +377,15 @@ class Model:
     def global_xattn(self, query, memory):
         """cond = MHA(query, memory, memory).  The K/V projections of `memory` are kept until `invalidate_memory()` (the
         detector calls it wherever it assigns the memory) or until another tensor object is passed, i.e. they are computed
-        once per memory update of a video; staleness is never inferred from tensor version counters."""
+        once per memory update of a video.  The cache key is (tensor object, its version counter): an in-place torch write to
+        the memory (copy_, index_put_, ...) bumps the counter and projects again; a write through a raw pointer, which no
+        counter sees, needs `invalidate_memory()`."""
         query = _cuda(query, torch.float32)
-        if self._kv_src is None or self._kv_src is not memory:
+        if self._kv_src is None or self._kv_src is not memory or self._kv_ver != memory._version:
             mem = _cuda(memory, torch.float32)
             call("dvid_global_memory_project", self.handle, ptr(mem), mem.shape[0], stream_ptr())
             self._kv_src = memory            # holds the tensor: its storage cannot be recycled under the cache
+            self._kv_ver = memory._version
         out = torch.empty_like(query)
         call("dvid_global_xattn", self.handle, ptr(query), query.shape[0], None, memory.shape[0], ptr(out), stream_ptr())
         return out

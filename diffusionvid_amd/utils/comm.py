@@ -34,3 +34,73 @@ def init_dist(backend=None, force=False):
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend=backend, init_method="env://")
+
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus += list(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def rank_cpu_share(local_rank, local_world, gpu_numa_nodes=None, node_cpus=None, allowed=None):
+    """CPUs for rank `local_rank` of `local_world` ranks on this host: the ranks whose GPU hangs off NUMA node k share node k's
+    CPUs in contiguous slices (the host threads of a rank -- its Python loop, pinned-memory copies, decode workers -- then run
+    next to their GPU's PCIe root); without topology information the allowed CPUs are cut into `local_world` contiguous
+    slices.  Pure function of its arguments (tests inject the topology): gpu_numa_nodes[i] = NUMA node of GPU i (-1 unknown),
+    node_cpus = {node: [cpu, ...]}, allowed = CPUs this process may run on."""
+    allowed = sorted(allowed if allowed is not None else range(os.cpu_count() or 1))
+    if local_world <= 1:
+        return allowed
+    known = gpu_numa_nodes is not None and node_cpus and len(gpu_numa_nodes) >= local_world and \
+        all(n in node_cpus for n in gpu_numa_nodes[:local_world])
+    if known:
+        node = gpu_numa_nodes[local_rank]
+        peers = [r for r in range(local_world) if gpu_numa_nodes[r] == node]
+        cpus = [c for c in node_cpus[node] if c in set(allowed)]
+        per = len(cpus) // len(peers)
+        if per >= 1:
+            k = peers.index(local_rank)
+            return cpus[k * per:(k + 1) * per]
+    per = max(1, len(allowed) // local_world)
+    lo = min(local_rank * per, len(allowed) - 1)
+    return allowed[lo:lo + per]
+
+
+def gpu_numa_topology(n_gpus):
+    """([NUMA node of GPU i], {node: cpus}) from sysfs, or (None, None) when the platform does not say"""
+    try:
+        nodes = []
+        for i in range(n_gpus):
+            p = torch.cuda.get_device_properties(i)
+            bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+                nodes.append(int(f.read().strip()))
+        node_cpus = {}
+        for n in set(nodes):
+            if n < 0:
+                return None, None
+            with open("/sys/devices/system/node/node%d/cpulist" % n) as f:
+                node_cpus[n] = _parse_cpulist(f.read())
+        return nodes, node_cpus
+    except (OSError, AttributeError, ValueError, RuntimeError):
+        return None, None
+
+
+def bind_rank_to_cpus(local_rank, local_world):
+    """Pin this process (and the threads it starts later) to its share of the host's CPUs; returns the CPU list (for the
+    bench line) or None when affinity cannot be set here.  No-op for a single rank."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        nodes, node_cpus = gpu_numa_topology(local_world) if torch.cuda.is_available() else (None, None)
+        cpus = rank_cpu_share(local_rank, local_world, nodes, node_cpus, allowed)
+        os.sched_setaffinity(0, cpus)
+        torch.set_num_threads(max(1, min(len(cpus), 32)))
+        return cpus
+    except OSError:
+        return None

@@ -17,6 +17,7 @@
  *   dvid_global_xattn          nn.MultiheadAttention global stage, box_head.py:366-380
  *   dvid_select_topk_features  box_head.py:304-317
  *   dvid_noise_to_boxes        diffusion_det.py:657-660
+ *   dvid_counter_normal        torch.randn(shape, device=self.device) at diffusion_det.py:449, :542, :587, :595
  *   dvid_ddim_renew_step       box renewal + DDIM update, diffusion_det.py:559-596
  *   dvid_postproc_topk_nms     DiffusionDet.inference + detectron2 batched_nms + BoxList.clip_to_image
  *                              diffusion_det.py:754-839, :607-627; structures/bounding_box.py:214-224
@@ -132,6 +133,9 @@ int dvid_roialign_v2_multilevel(const void* p3, const void* p4, const void* p5, 
                                 float* mean_out /* [R,C] or NULL */, void* stream);
 int dvid_select_topk_features(const float* logits, int n_frames, int m, int num_classes, int k1, int k2, const float* feats,
                               int hidden, float* out_k1, float* out_k2, void* stream);
+/* N(0, 1) draws as a pure function of (key, element index): out[i][e], i < n_images, e < per_image, = element e of the stream
+ * keyed key0 + i.  Philox4x32-10 + fp64 Box-Muller rounded to fp32; oracle/noise.py restates it on the CPU (same values). */
+int dvid_counter_normal(float* out, int64_t per_image, int n_images, uint64_t key0, void* stream);
 int dvid_noise_to_boxes(const float* x, float* boxes, int n, float snr_scale, float img_w, float img_h, void* stream);
 /* Box renewal + DDIM update (eta = 1) of diffusion_det.py:559-596 (+ :649-653, :666-672): per frame, boxes whose
  * sigmoid(max logit) > keep_thr are kept (index order), updated as x0*sqrt_ac_next + coef_c*eps + sigma*noise[j],

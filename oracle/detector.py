@@ -123,6 +123,7 @@ class OracleDiffusionDet:
                 k2_all.append(k2)
             total_feats = {p: torch.cat([fs[p] for fs in feats_split], dim=0) for p in c.in_features}
             feats_l = {p: total_feats[p][:len_l] for p in c.in_features}
+            self.taps["feats"] = total_feats          # p3 / p4 / p5 [n, 256, h, w] of every frame of the call (parity tests)
             classes_t = torch.cat(cls_all, dim=0).view(-1, c.num_proposals, c.num_classes)
             boxes_t = torch.cat(box_all, dim=0).view(-1, c.num_proposals, 4)
             proposals_t = torch.cat(prop_all, dim=1).view(-1, c.num_proposals, c.hidden_dim)

@@ -10,8 +10,9 @@ weights/activations in fp16, so the comparison is staged:
   3. final stage with the oracle's memory injected: logits / boxes within tolerance, detections matched
      one-to-one by (label, IoU, score).
 Stated tolerances: object features |err| <= 0.08 (LayerNorm-ed, O(1)); logits |err| <= 0.08; boxes
-<= max(0.75 px, 2% of box size); scores |err| <= 5e-3 -- for at least 99% of the boxes (a box that sits
-on a pyramid-level or sample-validity threshold may flip discretely between fp16 and fp32 features).
+<= max(0.5 px, 1% of box size); scores |err| <= 5e-3 -- for at least 99% of the boxes (a box that sits
+on a pyramid-level or sample-validity threshold may flip discretely between fp16 and fp32 features); the fraction outside is
+printed with every stage line.  (Rounds 1-3 ran the box bound at max(0.75 px, 2 %); round 4 tightened it to the contract's.)
 
 Conditioning.  With white-noise frames and raw random-init heads the 3-stage refinement is chaotic:
 rounding the CPU oracle's OWN feature maps to fp16 moves its stage-3 features by O(1) (measured,
@@ -28,17 +29,50 @@ from oracle import detector as odet  # noqa: E402
 from oracle import memory as omem  # noqa: E402
 
 
-def _build(sample_step, blocks):
+def _weights(model, weights="init"):
+    """"init": random-init heads with box-delta layers x0.1 (class scores 0.010 +- 0.003); "trained_like": additionally class layers
+    with a trained detector's score spread (synthetic.trained_like_scores); "untamed": the raw random-init state dict"""
+    from diffusionvid_amd.utils import synthetic
+    sd = model.state_dict()
+    if weights != "untamed":
+        sd = synthetic.tame_box_deltas(sd, 0.1)
+    if weights == "trained_like":
+        sd = synthetic.trained_like_scores(sd)
+    model.load_state_dict(sd)
+    return model
+
+
+def _build(sample_step, blocks, weights="init"):
     from diffusionvid_amd.config import get_cfg
     from diffusionvid_amd.modeling.detector import build_detection_model
     cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["MODEL.DiffusionDet.SAMPLE_STEP", sample_step],
                   "configs/BASE_RCNN_1gpu.yaml")
     cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = blocks
     cfg.freeze()
-    model = build_detection_model(cfg)
-    from diffusionvid_amd.utils import synthetic
-    model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
+    model = _weights(build_detection_model(cfg), weights)
     return cfg, model.to("cuda").eval()
+
+
+def _feature_check(tag, model, oracle, bound_max=0.06, bound_rms=0.012):
+    """Direct check of the backbone output at whatever depth / size the test runs: p3 / p4 / p5 of every frame of the call,
+    GPU (fp16 NHWC, `debug_taps["extract"][i][3]`) against the oracle (fp32 NCHW, `taps["feats"]`).  Per level: largest
+    absolute error and RMS error, both relative to the level's RMS value -- a scale or offset drift through the 101 layers
+    shows up here, where the three LayerNorm-ed heads behind would hide it."""
+    lines = []
+    for lvl, name in enumerate(("p3", "p4", "p5")):
+        g = torch.cat([e[3][lvl].float().cpu() for e in model.debug_taps["extract"]]).permute(0, 3, 1, 2)
+        o = oracle.taps["feats"][name]
+        assert g.shape == o.shape, (g.shape, o.shape)
+        rms = o.pow(2).mean().sqrt().item()
+        e_max = (g - o).abs().max().item() / rms
+        e_rms = (g - o).pow(2).mean().sqrt().item() / rms
+        gain = (g * o).sum().item() / o.pow(2).sum().item()          # least-squares scale of the GPU features on the oracle's
+        lines.append(f"{name}: max |err| / rms = {e_max:.3e}, rms err / rms = {e_rms:.3e}, scale = {gain:.5f}, mean offset / rms = {(g - o).mean().item() / rms:+.2e}")
+        assert e_max <= bound_max and e_rms <= bound_rms and abs(gain - 1) <= 2e-3, f"{tag} {lines[-1]}"
+    line = f"{tag} backbone features vs oracle ({tuple(o.shape[:1])[0]} frames, rms {rms:.2f}): " + "; ".join(lines)
+    print(line)
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write(line + "\n")
 
 
 def _oracle_items(ds, idx):
@@ -59,8 +93,10 @@ def _iou(a, b):
     return inter / ua if ua > 0 else 1.0
 
 
-def _stage_check(tag, gpf, opf, gcl, ocl, gbx, obx, frac_ok=0.99, b_logit=0.08, b_feat=0.08, b_px=0.75, b_rel=0.02):
-    """per-box errors against the stated bounds; >= frac_ok of the boxes must be inside all of them"""
+def _stage_check(tag, gpf, opf, gcl, ocl, gbx, obx, frac_ok=0.99, b_logit=0.08, b_feat=0.08, b_px=0.5, b_rel=0.01):
+    """per-box errors against the stated bounds (boxes: SURVEY.md 8(d)'s max(0.5 px, 1 % of the box size)); the fraction of
+    boxes outside any bound -- slots whose RoI flipped a pyramid level or a sample-validity test between fp16 and fp32 features
+    -- is REPORTED with every line and must stay below 1 - frac_ok"""
     e_cl = (gcl - ocl).abs().amax(-1).reshape(-1)
     size = (obx[..., 2:] - obx[..., :2]).clamp(min=1).max(-1).values
     e_bx = ((gbx - obx).abs().max(-1).values / torch.maximum(size * b_rel, torch.tensor(b_px))).reshape(-1)
@@ -72,11 +108,12 @@ def _stage_check(tag, gpf, opf, gcl, ocl, gbx, obx, frac_ok=0.99, b_logit=0.08, 
         ok &= e_pf <= b_feat
         msg += f"; |dfeat| median={e_pf.median():.2e} p99={e_pf.quantile(0.99):.2e} max={e_pf.max():.2e}"
     frac = ok.float().mean().item()
-    print(msg + f"; boxes within bounds {frac:.4f}")
+    msg += f"; boxes outside a bound {1 - frac:.4%} ({int((~ok).sum())} of {ok.numel()}; bounds |dlogit| {b_logit}, box max({b_px} px, {b_rel:.0%}))"
+    print(msg)
     import os
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/parity_report.txt", "a") as f:
-        f.write(msg + f"; boxes within bounds {frac:.4f}\n")
+        f.write(msg + "\n")
     assert frac >= frac_ok, msg
     return frac
 
@@ -278,7 +315,7 @@ def _threshold_aware_detections(tag, o_logits, o_boxes, g_logits, g_boxes, w, h,
     return n_decided, n_open
 
 
-def _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, **bounds):
+def _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, min_decided=0.1, **bounds):
     """Final stage (global attention + conditioned head) of every DDIM step with the ORACLE's memory, and for steps > 0
     the oracle's renewed boxes, injected: logits / boxes per step within the stated bounds."""
     from diffusionvid_amd.utils import synthetic
@@ -294,7 +331,7 @@ def _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, **bounds)
                 model.head.proposals_feat_cur = [[cached[0], cached[1], cached[2].reshape(1, L * M, d)]]
                 img = torch.zeros(L, M, 4, device="cuda")
             elif step == 0:
-                img = synthetic.noise_fn("img", 0, 0, 0, (L, M, 4)).cuda()
+                img = oracle.noise_fn("img", 0, 0, 0, (L, M, 4)).cuda()          # the draw the oracle made (host or counter-based)
             else:
                 # one flipped keep decision shifts every later slot of its frame, so each step starts from the oracle's
                 # renewed boxes (the renewal itself is compared in test_gpu_kernels.py::test_ddim_renew_step)
@@ -308,14 +345,19 @@ def _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, **bounds)
     # detections of this final stage under SURVEY.md 8(d)'s criterion: decisions beyond the stated tolerances must be identical
     decided, open_ = _threshold_aware_detections(tag, torch.stack(ens["ol"]), torch.stack(ens["ob"]), torch.stack(ens["gl"]),
                                                  torch.stack(ens["gb"]), float(W0), float(H0))
-    assert decided >= 0.1 * (decided + open_), f"{tag}: the set comparison is nearly vacuous: {open_} of {decided + open_} candidates sit within a band of a threshold"
+    assert decided >= min_decided * (decided + open_), f"{tag}: only {decided} of {decided + open_} candidates are decided beyond the bands (need {min_decided:.0%})"
+    return decided, open_
 
 
-@pytest.mark.parametrize("sample_step", [1, 4])
-def test_video_e2e(sample_step):
+@pytest.mark.parametrize("sample_step,noise", [(1, "host"), (4, "host"), (4, "device")])
+def test_video_e2e(sample_step, noise):
+    """noise = "device" (round 4): the GPU path generates every draw with dvid_counter_normal (synthetic.DeviceNoise) while the
+    oracle regenerates the same values on the CPU (oracle/noise.py) -- the device-side counterpart of the reference's
+    torch.randn calls, diffusion_det.py:449, :542, :587, :595."""
     from diffusionvid_amd import ops
     from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
     from diffusionvid_amd.utils import synthetic
+    from oracle import noise as onoise
     blocks = (1, 1, 2, 1)
     cfg, model = _build(sample_step, blocks)
     L, H0, W0 = 8, 250, 380                    # padded to 256 x 384 by the size-divisibility rule
@@ -323,8 +365,8 @@ def test_video_e2e(sample_step):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ocfg = odet.DetCfg(sample_step=sample_step, blocks=blocks)
     ocfg.head.sampling_timesteps = sample_step
-    oracle = odet.OracleDiffusionDet(sd, ocfg, synthetic.noise_fn)
-    model.noise_fn = synthetic.noise_fn
+    oracle = odet.OracleDiffusionDet(sd, ocfg, synthetic.noise_fn if noise == "host" else onoise.noise_fn)
+    model.noise_fn = synthetic.noise_fn if noise == "host" else synthetic.DeviceNoise()
     model.debug_taps = {}
 
     # ---- call 0 on both (frame 0: 8 local + 24 global frames) -----------------------------------------
@@ -339,6 +381,7 @@ def test_video_e2e(sample_step):
     gcl = torch.cat([e[0] for e in model.debug_taps["extract"]]).cpu()
     gbx = torch.cat([e[1] for e in model.debug_taps["extract"]]).cpu()
     gpf = torch.cat([e[2] for e in model.debug_taps["extract"]]).cpu().view(-1, 300, 256)
+    _feature_check(f"[x{sample_step}]", model, oracle)
     _stage_check(f"[x{sample_step}] extraction", gpf, opf, gcl, ocl, gbx, obx)
 
     # 2. memory: GPU FPS on the oracle's candidate features -> identical rows (integer work)
@@ -380,6 +423,50 @@ def test_video_e2e(sample_step):
         s = g.get_field("scores")
         assert torch.all(s[:-1] >= s[1:])                       # NMS order: descending score
         assert g.bbox[:, 0::2].max() <= W0 - 1 and g.bbox[:, 1::2].max() <= H0 - 1 and g.bbox.min() >= 0
+
+
+@pytest.mark.parametrize("sample_step", [1, 4])
+def test_video_e2e_untamed_box_deltas(sample_step):
+    """One end-to-end case WITHOUT `tame_box_deltas` (VERDICT r3 weak #2b): the raw random-init regression layers, which multiply
+    box sizes by up to e^(+-2) per head -- three heads in the extraction pass, a fourth in the final stage -- on smooth frames
+    with trained-like class scores.  The per-stage bounds are the contract's (logits scaled by the class-layer gain); what this
+    regime costs is the FRACTION of boxes outside them, which is measured and printed per stage (a box that grows 7x per
+    head amplifies an fp16 rounding of its RoI features accordingly).  Gates: extraction >= 97 % of the boxes inside every bound,
+    final stage (oracle memory and boxes injected) >= 97 %, detections matched >= 0.9 per frame, AP50(GPU | oracle) >= 0.99."""
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.utils import synthetic
+    blocks = (1, 1, 2, 1)
+    cfg, model = _build(sample_step, blocks, "untamed")
+    model.load_state_dict(synthetic.trained_like_scores(model.state_dict()))
+    L, H0, W0 = 8, 250, 380
+    ds = SyntheticVIDDataset([L], cfg, height=H0, width=W0, device="cuda", smooth=True)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ocfg = odet.DetCfg(sample_step=sample_step, blocks=blocks)
+    ocfg.head.sampling_timesteps = sample_step
+    oracle = odet.OracleDiffusionDet(sd, ocfg, synthetic.noise_fn)
+    model.noise_fn = synthetic.noise_fn
+    model.debug_taps = {}
+    images, oitem, ids = _oracle_items(ds, 0)
+    with torch.no_grad():
+        ref_out = oracle.forward(oitem)
+        got_out = model(images)
+    tag = f"[x{sample_step} untamed box deltas]"
+    ocl, obx, opf = oracle.taps["extract"]
+    gcl = torch.cat([e[0] for e in model.debug_taps["extract"]]).cpu()
+    gbx = torch.cat([e[1] for e in model.debug_taps["extract"]]).cpu()
+    gpf = torch.cat([e[2] for e in model.debug_taps["extract"]]).cpu().view(-1, 300, 256)
+    _feature_check(tag, model, oracle)
+    _stage_check(f"{tag} extraction", gpf, opf, gcl, ocl, gbx, obx, frac_ok=0.97, b_logit=0.32)
+    rates = [_match_rate(r, g) for r, g in zip(ref_out, got_out)]
+    ap = _ap50_vs_oracle(ref_out, got_out, (W0, H0))
+    line = (f"{tag} detections kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]}; match "
+            f"{['%.2f' % r for r in rates]}; AP50(GPU | oracle) = {ap:.4f}")
+    print(line)
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write(line + "\n")
+    model.debug_taps = {}
+    _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, min_decided=0.5, frac_ok=0.97, b_logit=0.32)
+    assert min(rates) >= 0.9 and ap >= 0.99
 
 
 def test_non_batch_calls_return_empty_and_errors():
@@ -529,29 +616,33 @@ def test_lookahead_invariance_full_size(arch, sample_step, groups, frames):
         print(f"{arch} x{sample_step}: look-ahead {la} vs 1 at full size: max |dbox| = {worst:.2e} px over {frames} frames")
 
 
+@pytest.mark.parametrize("weights", ["init", "trained_like"])
 @pytest.mark.parametrize("arch,sample_step", [("r101", 1), ("r101", 4), ("swinb", 1)])
-def test_video_e2e_full_configuration(arch, sample_step):
+def test_video_e2e_full_configuration(arch, sample_step, weights):
     """BASELINE.json configs[1..3] as they are benchmarked -- ResNet-101 (3,4,23,3) x1 and x4, Swin-Base (embed 128,
     depths 2-2-18-2, heads 4-8-16-32) x1; 1000x600 frames, 300 boxes -- on the first call of a one-batch video (8 / 4
     local + 24 global frames through backbone and extraction heads, memory pruning, final stage with every DDIM step):
     extraction logits / boxes / object features, per-step final-stage logits / boxes, detections and AP50 against the
-    CPU oracle, same tolerances as the reduced-size tests."""
+    CPU oracle, same tolerances as the reduced-size tests; and the backbone's p3 / p4 / p5 DIRECTLY against the oracle's at
+    full depth and size (`_feature_check`).
+    weights = "trained_like" (round 4): class layers with a trained detector's score spread (scores 0.003 .. 0.9, a few boxes
+    per frame above the 0.5 renewal threshold) -- the regime in which the threshold-aware set comparison DECIDES: at least 90 %
+    of the candidates must be decided beyond the bands, every one of them agreeing with the GPU's detections, and the AP50 of
+    the GPU detections against the oracle's must be >= 0.999 (BASELINE's "AP50 within +-0.1 point")."""
     from diffusionvid_amd.config import get_cfg
     from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
     from diffusionvid_amd.modeling.detector import build_detection_model
     from diffusionvid_amd.utils import synthetic
     if arch == "r101":
-        cfg, model = _build(sample_step, None)
+        cfg, model = _build(sample_step, None, weights)
         L = 8
     else:
         cfg = get_cfg("configs/vid_Swin_B_DiffusionVID.yaml", ["MODEL.DiffusionDet.SAMPLE_STEP", sample_step], "configs/BASE_RCNN_1gpu.yaml")
         cfg.freeze()
-        model = build_detection_model(cfg)
-        model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))
-        model = model.to("cuda").eval()
+        model = _weights(build_detection_model(cfg), weights).to("cuda").eval()
         L = 4
     H0, W0 = 600, 1000
-    tag = f"[{arch} x{sample_step} full size]"
+    tag = f"[{arch} x{sample_step} full size, {weights} weights]"
     ds = SyntheticVIDDataset([L], cfg, height=H0, width=W0, device="cuda", smooth=True)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ocfg = odet.DetCfg(sample_step=sample_step, infer_batch=L, all_frame_interval=L)
@@ -574,15 +665,18 @@ def test_video_e2e_full_configuration(arch, sample_step):
     gbx = torch.cat([e[1] for e in model.debug_taps["extract"]]).cpu()
     gpf = torch.cat([e[2] for e in model.debug_taps["extract"]]).cpu().view(-1, 300, 256)
     assert gcl.shape[0] == L + 24
-    _stage_check(f"{tag} extraction", gpf, opf, gcl, ocl, gbx, obx)
+    _feature_check(tag, model, oracle)
+    _stage_check(f"{tag} extraction", gpf, opf, gcl, ocl, gbx, obx, b_logit=0.08 if weights == "init" else 0.32)
     rates = [_match_rate(r, g) for r, g in zip(ref_out, got_out)]
     ap = _ap50_vs_oracle(ref_out, got_out, (W0, H0))
-    print(f"{tag} detections kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]}; "
-          f"match {['%.2f' % r for r in rates]}; AP50(GPU | oracle) = {ap:.4f}")
+    top = [float(torch.as_tensor(r["scores"]).max()) if len(r["scores"]) else 0.0 for r in ref_out]
+    print(f"{tag} detections kept {[len(g) for g in got_out]} vs oracle {[len(r['scores']) for r in ref_out]} (oracle top scores "
+          f"{['%.2f' % t for t in top]}); match {['%.2f' % r for r in rates]}; AP50(GPU | oracle) = {ap:.4f}")
     with open("gpurun_out/parity_report.txt", "a") as f:
         f.write(f"{tag} AP50(GPU | oracle detections as ground truth) = {ap:.4f}; match rates {['%.2f' % r for r in rates]}\n")
-    _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag)
-    assert min(rates) >= 0.9 and ap >= 0.95
+    _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, min_decided=0.1 if weights == "init" else 0.9,
+                           b_logit=0.08 if weights == "init" else 0.32)
+    assert min(rates) >= 0.9 and ap >= (0.95 if weights == "init" else 0.999)
 
 
 @pytest.mark.parametrize("num_proposals", [100, 500])

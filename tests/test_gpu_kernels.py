@@ -1013,3 +1013,27 @@ def test_wstat_matches_igemm2(dv, shape):
     print("wstat vs igemm2: identical %.6f, max |diff| %.3e" % (same, (got.float() - base.float()).abs().max().item()))
     assert torch.equal(got, base)
 
+
+
+def test_counter_normal_matches_oracle():
+    """dvid_counter_normal (device-side draws of the DDIM loop) vs oracle/noise.py: the integer part (Philox4x32-10) is exact by
+    construction; the fp64 Box-Muller of the device math library and of numpy may differ in the last fp64 bits, which survives the
+    rounding to fp32 with probability ~4e-9 per value -- over 1.2 million values at most 4 may differ, by one fp32 ulp."""
+    from diffusionvid_amd import ops
+    from oracle import noise
+    key0 = noise.draw_key("renew", 296, 2, 0)
+    got = ops.counter_normal(key0, 5, (60001, 4)).cpu().numpy()
+    assert got.shape == (5, 60001, 4)
+    n_diff = 0
+    for i in range(5):
+        ref = noise.counter_normal(key0 + i, 60001 * 4).reshape(60001, 4)
+        d = got[i] != ref
+        n_diff += int(d.sum())
+        if d.any():
+            ulp = np.spacing(np.abs(ref[d]).astype(np.float32))
+            assert (np.abs(got[i][d] - ref[d]) <= ulp).all()
+    assert n_diff <= 4, n_diff
+    # ragged sizes (the tail quad is cut), one image, and a 64-bit key
+    for per in (1, 2, 3, 5, 1023):
+        g = ops.counter_normal((1 << 40) + 17, 1, (per,)).cpu().numpy()[0]
+        np.testing.assert_array_equal(g, noise.counter_normal((1 << 40) + 17, per))

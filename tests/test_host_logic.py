@@ -531,3 +531,28 @@ def test_gelu_erfc_form_matches_exact_gelu():
     assert (err[big] / np.abs(want[big])).max() < 2e-5
     # after the fp16 store of the fc1 output: essentially always the exactly rounded value
     assert (got.astype(np.float16) != want.astype(np.float16)).mean() < 1e-3
+
+
+def test_counted_dma_waits_cover_no_ordinary_load():
+    """the fused-block and weight-stationary kernels count LDS-DMA pieces in hand-written vmcnt waits; an ordinary
+    load among the youngest N operations of such a wait lets it return with a covered piece in flight.
+    tools/check_dma_waits.py checks that on the compiled assembly of csrc/bneck.hip and csrc/wstat.hip; its rule is first
+    checked on hand-made streams (the round-3 fault pattern must be flagged)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_dma_waits", os.path.join(ROOT, "tools", "check_dma_waits.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    piece, load = "\tglobal_load_lds_dwordx4 v[2:3], off", "\tglobal_load_dwordx4 v[4:7], v[2:3], off"
+    stream = lambda *t: list(enumerate(t, 1))                                     # noqa: E731
+    # round-3 fault: piece, then a younger ordinary load, wait allows one operation in flight -> the load may be the one that retired
+    assert chk.check_kernel("k", stream(piece, load, "\ts_waitcnt vmcnt(1)"))
+    assert not chk.check_kernel("k", stream(load, piece, piece, "\ts_waitcnt vmcnt(1)"))      # loads older than the pieces
+    assert not chk.check_kernel("k", stream(piece, load, "\ts_waitcnt vmcnt(0)"))             # a full drain is always safe
+    assert not chk.check_kernel("k", stream(piece, "\tglobal_store_dwordx4 v[2:3], v[4:7], off", piece, "\ts_waitcnt vmcnt(1)"))
+    # loop-carried: the load issued at the end of the body is young at the next trip's wait
+    loop = stream(".LBB0_1:", piece, "\ts_waitcnt vmcnt(2)", load, "\ts_cbranch_scc1 .LBB0_1")
+    assert chk.check_kernel("k", loop)
+    for f in ("bneck.hip", "wstat.hip"):
+        stats, bad = chk.check_source(os.path.join(ROOT, "diffusionvid_amd", "csrc", f))
+        assert len(stats) >= 9 and sum(c for _, c in stats.values()) >= 100
+        assert not bad, bad[:3]

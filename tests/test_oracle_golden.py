@@ -204,3 +204,27 @@ def test_g12_nms_known_answers():
                     ua = ((bb[a, 2] - bb[a, 0] + one) * (bb[a, 3] - bb[a, 1] + one) + (bb[c, 2] - bb[c, 0] + one) * (bb[c, 3] - bb[c, 1] + one) - w * h)
                     assert w * h / ua <= th + 1e-6
     assert n_diff <= 2           # the +1 / >= conventions matter on at most two of the six cases
+
+
+def test_counter_noise_philox_known_answers_and_moments():
+    """oracle/noise.py (CPU restatement of dvid_counter_normal): Philox4x32-10 against the known-answer vectors published with
+    Random123 (kat_vectors: counter / key all zero, all ones, digits of pi), then the normal draws: moments of a million values,
+    independence of the key, prefix property (a shorter request is a prefix of a longer one), fp32 output."""
+    import numpy as np
+    from oracle import noise
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = noise.philox4x32_10(np.array([ctr], dtype=np.uint32), key)[0]
+        assert tuple(int(v) for v in got) == want
+    z = noise.counter_normal(12345, 1000003)
+    assert z.dtype == np.float32 and z.shape == (1000003,) and np.isfinite(z).all()
+    assert abs(z.mean()) < 4e-3 and abs(z.std() - 1) < 3e-3 and abs((z ** 3).mean()) < 1.5e-2 and abs((z ** 4).mean() - 3) < 3e-2
+    assert np.array_equal(noise.counter_normal(12345, 1001), z[:1001])
+    other = noise.counter_normal(12346, 4096)
+    assert abs(np.corrcoef(other, z[:4096])[0, 1]) < 0.06
+    a = noise.noise_fn("ddim", 8, 1, 3, (300, 4))
+    assert a.shape == (300, 4) and np.array_equal(a.numpy().reshape(-1), noise.counter_normal(noise.draw_key("ddim", 8, 1, 3), 1200))
+    from diffusionvid_amd.utils import synthetic
+    assert synthetic.DeviceNoise().key("ddim", 8, 1, 3) == noise.draw_key("ddim", 8, 1, 3)
