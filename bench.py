@@ -53,8 +53,22 @@ from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
 # measured HBM bytes per implicit-GEMM launch (rocprofv3 --pmc passes of tools/profile_round.sh), one file PER CONFIGURATION: a line
 # only ever carries the traffic collected on its own workload, never another configuration's
-TRAFFIC_FILES = {("r101", 1): "r03l_pmc_igemm_traffic_r101_x1.json", ("r101", 4): "r03l_pmc_igemm_traffic_r101_x4.json",
-                 ("swinb", 1): "r03l_pmc_igemm_traffic_swinb_x1.json"}
+TRAFFIC_FILES = {("r101", 1): "r04_pmc_igemm_traffic_r101_x1.json", ("r101", 4): "r04_pmc_igemm_traffic_r101_x4.json",
+                 ("swinb", 1): "r04_pmc_igemm_traffic_swinb_x1.json", ("r101", 1, "lookahead1"): "r04_pmc_igemm_traffic_r101_x1_lookahead1.json"}
+
+
+def _md5(path):
+    import hashlib
+    try:
+        with open(path, "rb") as f:
+            return hashlib.md5(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
+# the build this run measures: committed PMC traffic files carry the md5 of the library they were collected on, and a line whose
+# traffic comes from another build says so
+LIB_MD5 = _md5(os.path.join(ROOT, "diffusionvid_amd", "libdvid_hip.so"))
 PEAK_FP16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 # algorithmic work per output frame: backbone + heads + global attention, faithful pass counts
@@ -182,7 +196,7 @@ def real_data_feed_rate(device, n_files=48, passes=4):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def vidval(args, build, timed, barrier, device, rank, world, H, W):
+def vidval(args, build, timed, barrier, device, rank, world, H, W, embedded=False):
     """BASELINE.json configs[4]: the VID-val-shaped set (555 videos, 176126 frames, lengths 24..3262) sharded over the ranks
     by frame-count-balanced whole videos, every rank running the reference's per-item loop over its videos,
     one gather of the predictions to rank 0 inside the timed region.  Strong scaling: the set is fixed, N ranks split it."""
@@ -214,10 +228,11 @@ def vidval(args, build, timed, barrier, device, rank, world, H, W):
     if grouped:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+    record = None
     if rank == 0:
         total = int(sum(lens))
         assert int(ff.item()) == total and len(merged) == total
-        print(json.dumps({
+        record = ({
             "metric": "frames/sec (1000x600) DiffusionVID-%s x%d, VID-val-shaped set" % ("R101" if args.arch == "r101" else "SwinB", args.sample_step),
             "value": round(total / float(tt.item()), 2), "unit": "frames/sec", "n_gpus": world, "steps": 1, "warmup": 0,
             "ms_per_step": round(float(tt.item()) * 1e3, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -227,7 +242,16 @@ def vidval(args, build, timed, barrier, device, rank, world, H, W):
                                    % (len(lens), total, min(lens), max(lens)),
                        "lookahead_batches": args.lookahead, "ranks": world, "process_group": ("nccl, %d rank(s)" % dist.get_world_size()) if grouped else "none",
                        "frames_of_heaviest_rank_over_mean": round(max(sum(lens[v] for v in p) for p in balanced_video_partition(lens, world))
-                                                                  / (total / world), 5)}}), flush=True)
+                                                                  / (total / world), 5)}})
+    if model._engine is not None:
+        model._engine.close()
+        model._engine = None
+    del model, ds, warm
+    torch.cuda.empty_cache()
+    if embedded:
+        return record
+    if rank == 0:
+        print(json.dumps(record), flush=True)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
@@ -293,6 +317,8 @@ def main():
     ap.add_argument("--skip-unobservable", action="store_true",
                     help="MODEL.DiffusionDet.SKIP_UNOBSERVABLE for the main measurement (x4 only; SURVEY.md Appendix B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-noise", action="store_true", help="draw the DDIM noise with the host generator and upload it (rounds 1-3) instead of on the device")
+    ap.add_argument("--no-vidval", action="store_true", help="skip the VID-val-shaped measurement reported inside the line (other_configs.vidval)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned frames, H2D in the timed region) measurement")
     ap.add_argument("--no-feed-rate", action="store_true", help="skip the real-data feed-rate measurement (image files -> decode workers -> uint8 H2D -> device resize)")
     ap.add_argument("--no-side-configs", action="store_true",
@@ -328,6 +354,19 @@ def main():
         raise SystemExit("rank %d has no GPU: %d visible device(s) for --gpus %d" % (rank, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpus = comm.bind_rank_to_cpus(local_rank, local_world)          # this rank's share of the host CPUs, next to its GPU's NUMA node
+    # N ranks, ONE tile-tuner result: rank 0 times each GEMM shape in its set-up pass and appends the winners to a file every
+    # other rank reads at its first launch (they keep timing shapes rank 0 did not see).  Must be in the environment before this
+    # process's first library launch.  A user-provided DVID_IGEMM_TUNE_CACHE is left alone.
+    shared_tune = None
+    if world > 1 and "DVID_IGEMM_TUNE_CACHE" not in os.environ:
+        import tempfile
+        shared_tune = os.path.join(tempfile.gettempdir(), "dvid_tune_%s_%s.txt" % (os.environ.get("MASTER_PORT", "0"), os.getuid()))
+        os.environ["DVID_IGEMM_TUNE_CACHE"] = shared_tune
+        os.environ.setdefault("DVID_IGEMM_TUNE", "1")
+        if rank == 0 and os.path.exists(shared_tune):
+            os.unlink(shared_tune)
     grouped = world > 1 or args.force_dist          # a process group exists: collectives run (through RCCL, also for one rank)
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -361,7 +400,9 @@ def main():
                       os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
         cfg.freeze()
         model = build_detection_model(cfg).to(device).eval()
-        model.noise_fn = synthetic.noise_fn
+        # every random draw of the DDIM loop is generated ON THE DEVICE (dvid_counter_normal; the reference draws with
+        # torch.randn on its device, diffusion_det.py:449,:542,:587,:595) -- --host-noise restores the host generator + upload
+        model.noise_fn = synthetic.noise_fn if args.host_noise else synthetic.DeviceNoise()
         model.results_on_host = True      # one D2H copy per batch group (results end up on the host either way)
         return cfg, model
 
@@ -420,10 +461,14 @@ def main():
     cfg, model = build(args.arch, args.sample_step, args.lookahead, args.skip_unobservable)
     ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
     ds.preload()
+    if shared_tune and rank != 0:
+        barrier()                      # rank 0's set-up pass first: its tuner winners are what this rank starts from
     with torch.no_grad():
         # set-up, outside the step accounting: weight repack / upload and the per-shape tile tuner (it times every
         # configuration on the first launch of each GEMM shape; DVID_IGEMM_TUNE_CACHE makes that persistent)
         run_video(model, ds, device)
+    if shared_tune and rank == 0:
+        barrier()
     dt, total_frames = timed(model, ds, args.steps, args.warmup, gather=True)
     host_view = dict(timed.last)
 
@@ -450,62 +495,72 @@ def main():
         del hf, hds
 
     # ---- roofline of the dominant kernel: instrumented repeat of one step -------------------------
-    roofline = None
     lib = _lib.load()
-    # per-launch HIP events on the library's stream; sub-batch chains are switched off for this pass so that launches
-    # do not overlap and each event pair times one kernel alone (the same condition rocprofv3 summaries in profiles/
-    # are taken under: DVID_CHAINS=1)
-    engine_model = model._get_engine()
-    engine_model.set_chains(1)
-    with torch.no_grad():
-        run_video(model, ds, device)      # un-instrumented: lets the per-shape tile tuner see the chains=1 launch shapes first
-    torch.cuda.synchronize()
-    lib.dvid_profile_reset()
-    lib.dvid_profile_enable(1)
-    with torch.no_grad():
-        run_video(model, ds, device)
-    torch.cuda.synchronize()
-    engine_model.set_chains(int(os.environ.get("DVID_CHAINS", "2")))
-    ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-    _lib.check(lib.dvid_profile_read(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), "dvid_profile_read")
-    ab = ctypes.c_double()
-    _lib.check(lib.dvid_profile_read_bytes(ctypes.byref(ab)), "dvid_profile_read_bytes")
-    lib.dvid_profile_enable(0)
-    if os.environ.get("DVID_PROFILE_DUMP") and rank == 0:
-        lib.dvid_profile_dump(os.environ["DVID_PROFILE_DUMP"].encode())
-    lib.dvid_profile_reset()
-    traffic = mfma_busy = None
-    TRAFFIC_FILE = TRAFFIC_FILES.get((args.arch, args.sample_step), "")
-    tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-    if TRAFFIC_FILE and os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS configuration (cannot be collected in-process)
-        pmc = json.load(open(tpath))
-        traffic = round(pmc["hbm_bytes_per_launch"])
-        mfma_busy = pmc.get("mfma_busy_fraction")
-    if ms.value > 0:
+
+    def measure_roofline(model, ds, arch, sample_step, fps, frames_per_step, lookahead):
+        """per-launch HIP events on the library's stream; sub-batch chains are switched off for this pass so that launches do
+        not overlap and each event pair times one kernel alone (the same condition the rocprofv3 summaries in profiles/ are
+        taken under: DVID_CHAINS=1)"""
+        engine_model = model._get_engine()
+        engine_model.set_chains(1)
+        graphs, model.use_call_graph = model.use_call_graph, False          # per-launch events need kernel-by-kernel launches
+        with torch.no_grad():
+            run_video(model, ds, device)      # un-instrumented: lets the per-shape tile tuner see the chains=1 launch shapes first
+        torch.cuda.synchronize()
+        lib.dvid_profile_reset()
+        lib.dvid_profile_enable(1)
+        with torch.no_grad():
+            run_video(model, ds, device)
+        torch.cuda.synchronize()
+        engine_model.set_chains(int(os.environ.get("DVID_CHAINS", "2")))
+        model.use_call_graph = graphs
+        ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(lib.dvid_profile_read(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), "dvid_profile_read")
+        ab = ctypes.c_double()
+        _lib.check(lib.dvid_profile_read_bytes(ctypes.byref(ab)), "dvid_profile_read_bytes")
+        lib.dvid_profile_enable(0)
+        if os.environ.get("DVID_PROFILE_DUMP") and rank == 0 and arch == args.arch and sample_step == args.sample_step and lookahead == args.lookahead:
+            lib.dvid_profile_dump(os.environ["DVID_PROFILE_DUMP"].encode())
+        lib.dvid_profile_reset()
+        traffic = mfma_busy = stamp = None
+        key = (arch, sample_step) if lookahead > 1 else (arch, sample_step, "lookahead1")
+        traffic_file = TRAFFIC_FILES.get(key, "")
+        tpath = os.path.join(ROOT, "profiles", traffic_file)
+        if traffic_file and os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS configuration (cannot be collected in-process)
+            pmc = json.load(open(tpath))
+            traffic = round(pmc["hbm_bytes_per_launch"])
+            mfma_busy = pmc.get("mfma_busy_fraction")
+            stamp = pmc.get("library_md5")
+        if ms.value <= 0:
+            return None
         sec = ms.value * 1e-3
         tflops = fl.value / sec / 1e12
         gbs = ab.value / sec / 1e9
-        fps = total_frames / dt
+        gflop_frame = ALG_GFLOP_PER_FRAME.get((arch, sample_step), 0)
         # SURVEY.md 8(d): the path is MFMA-bound (249.3 GFLOP against 60-90 MB of ideal-fusion HBM traffic per frame, ~3-4
         # kFLOP/B); `achieved` = algorithmic FLOP of the launches / their summed durations.  The layer-by-layer byte model
         # (every layer's input + weights + output + residual once) and the measured traffic are printed next to it: their
         # ratio to the ideal-fusion figure is the activation round-trip traffic that fusion has yet to remove.
-        roofline = {"bound": "mfma", "kernel": "implicit-GEMM conv/linear kernels, fp16 MFMA (igemm2_kernel; conv3x3_* for the 3x3 / stride-1 layers; wstat_kernel for the short-K / wide-N 1x1 layers; bneck64_tail_kernel = a res2 block behind its conv1 as one launch)",
-                    "achieved": round(tflops, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP16_TFLOPS, 4),
-                    "traffic": traffic,
-                    "traffic_source": ("profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh on this "
-                                       "configuration's workload, bytes per launch; not collected in this run)" % TRAFFIC_FILE) if traffic is not None
-                                      else "no PMC profile of this configuration is committed (tools/profile_round.sh <tag> --arch ... --sample-step ...)",
-                    "mfma_busy_pmc": None if mfma_busy is None else round(mfma_busy, 4),
-                    "end_to_end_tflops": round(fps / max(world, 1) * ALG_GFLOP_PER_FRAME.get((args.arch, args.sample_step), 0) / 1e3, 1),
-                    "end_to_end_frac": round(fps / max(world, 1) * ALG_GFLOP_PER_FRAME.get((args.arch, args.sample_step), 0) / 1e3 / PEAK_FP16_TFLOPS, 4),
-                    "layerwise_alg_gbs": round(gbs, 1), "layerwise_alg_hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
-                    "layerwise_alg_mbytes_per_launch": round(ab.value / max(1, nl.value) / 1e6, 2),
-                    "ideal_fusion_mbytes_per_frame": "60-90 (SURVEY.md 8d)",
-                    "layerwise_alg_mbytes_per_frame": round(ab.value / 1e6 / (L + 24), 1),
-                    "alg_gflop_per_launch": round(fl.value / max(1, nl.value) / 1e9, 3),
-                    "launches_per_step": int(nl.value), "avg_launch_us": round(ms.value * 1e3 / max(1, nl.value), 2),
-                    "kernel_ms_per_step": round(ms.value, 2)}
+        r = {"bound": "mfma", "kernel": "implicit-GEMM conv/linear kernels, fp16 MFMA (igemm2_kernel; conv3x3_* for the 3x3 / stride-1 layers; wstat_kernel for the short-K / wide-N 1x1 layers; bneck64 / bneck128_tail_kernel = a res2 / res3 block behind its conv1 as one launch)",
+             "achieved": round(tflops, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP16_TFLOPS, 4),
+             "traffic": traffic,
+             "traffic_source": ("profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh on this "
+                                "configuration's workload, bytes per launch; not collected in this run%s)"
+                                % (traffic_file, "" if stamp in (None, LIB_MD5) else "; COLLECTED ON ANOTHER BUILD of the library (md5 %s, this run %s)" % (stamp, LIB_MD5))) if traffic is not None
+                               else "no PMC profile of this configuration is committed (tools/profile_round.sh <tag> --arch ... --sample-step ...)",
+             "mfma_busy_pmc": None if mfma_busy is None else round(mfma_busy, 4),
+             "end_to_end_tflops": round(fps / max(world, 1) * gflop_frame / 1e3, 1),
+             "end_to_end_frac": round(fps / max(world, 1) * gflop_frame / 1e3 / PEAK_FP16_TFLOPS, 4),
+             "layerwise_alg_gbs": round(gbs, 1), "layerwise_alg_hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+             "layerwise_alg_mbytes_per_launch": round(ab.value / max(1, nl.value) / 1e6, 2),
+             "ideal_fusion_mbytes_per_frame": "60-90 (SURVEY.md 8d)",
+             "layerwise_alg_mbytes_per_frame": round(ab.value / 1e6 / (frames_per_step + 24), 1),
+             "alg_gflop_per_launch": round(fl.value / max(1, nl.value) / 1e9, 3),
+             "launches_per_step": int(nl.value), "avg_launch_us": round(ms.value * 1e3 / max(1, nl.value), 2),
+             "kernel_ms_per_step": round(ms.value, 2)}
+        return r
+
+    roofline = measure_roofline(model, ds, args.arch, args.sample_step, total_frames / dt, L, args.lookahead)
 
     # ---- the reference's own call protocol (no look-ahead hand-over from the dataset) and the other single-GPU
     # configurations of BASELINE.json, each with its own model; reported inside the same line ---------------------
@@ -516,7 +571,7 @@ def main():
     del model
     others = {}
 
-    def side(name, arch, sample_step, lookahead, steps, skip_unobservable=False, extra=(), note=None):
+    def side(name, arch, sample_step, lookahead, steps, skip_unobservable=False, extra=(), note=None, with_roofline=False):
         try:
             c2, m2 = build(arch, sample_step, lookahead, skip_unobservable, extra)
             d2 = SyntheticVIDDataset([L], c2, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
@@ -527,6 +582,10 @@ def main():
             others[name] = {"value": round(f2 / t2, 2), "unit": "frames/sec", "ms_per_step": round(t2 / steps * 1e3, 2),
                             "lookahead_batches": lookahead, "infer_batch": c2.INPUT.INFER_BATCH, "sample_step": sample_step, "steps": steps,
                             "host_blocked_on_gpu_frac": timed.last["host_blocked_on_gpu_frac_min_over_ranks"]}
+            if lookahead == 1:
+                others[name]["call_graph_replays"] = m2.graph_replays          # calls served by one hipGraph launch each (0: kernel by kernel)
+            if with_roofline:
+                others[name]["roofline"] = measure_roofline(m2, d2, arch, sample_step, f2 / t2, L, lookahead)
             if note:
                 others[name]["ms_per_frame"] = round(t2 / max(f2, 1) * world * 1e3, 3)
                 others[name]["what"] = note
@@ -535,12 +594,12 @@ def main():
             others[name] = {"error": repr(e)[:300]}
 
     if not args.no_side_configs:
-        side("reference_protocol_lookahead_1", args.arch, args.sample_step, 1, 5)
+        side("reference_protocol_lookahead_1", args.arch, args.sample_step, 1, 5, with_roofline=True)
         if headline and world == 1:
-            side("r101_x4", "r101", 4, 38, 5)
+            side("r101_x4", "r101", 4, 38, 5, with_roofline=True)
             # 12 observable head passes per frame instead of the faithful 19 (same detections)
             side("r101_x4_observable_passes_only", "r101", 4, 38, 5, skip_unobservable=True)
-            side("swinb_x1", "swinb", 1, 76, 5)
+            side("swinb_x1", "swinb", 1, 76, 5, with_roofline=True)
             # the latency-oriented variant of demo/demo.py:60-68 -- one frame per call, one new global frame per
             # call merged into the memory and pruned back (vid_mega.py:213-215)
             side("r101_x1_streaming", "r101", 1, 1, 3,
@@ -550,6 +609,20 @@ def main():
                  note="INFER_BATCH 1, ALL_FRAME_INTERVAL 1, MAX_OFFSET 0, GLOBAL.STOP_UPDATE_AFTER_INIT_TEST False: every call runs the backbone + "
                       "extraction heads on its own frame and one new global frame, merges 75 / 25 rows into the 900 / 150-row memories, prunes them "
                       "by farthest-point sampling and finishes the frame; ms_per_frame is the per-call latency")
+
+    # BASELINE.json configs[4] inside the same line: the VID-val-shaped set sharded over the ranks by whole videos (strong scaling).
+    # N > 1: the whole 555-video set; one rank: its first 60 videos (so that the default run stays within minutes).
+    if headline and not args.no_side_configs and not args.no_vidval:
+        try:
+            import copy
+            a2 = copy.copy(args)
+            a2.videos = args.videos if args.videos > 0 else (0 if world > 1 else 60)
+            rec = vidval(a2, build, timed, barrier, device, rank, world, H, W, embedded=True)
+            if rank == 0:
+                others["vidval"] = {"value": rec["value"], "unit": rec["unit"], "seconds": round(rec["ms_per_step"] / 1e3, 2), "scaling": "strong",
+                                    "config": rec["config"]}
+        except Exception as e:
+            others["vidval"] = {"error": repr(e)[:300]}
 
     feed = None
     if rank == 0 and headline and not grouped and not args.no_feed_rate:          # (forks decode workers: single-process runs only)
@@ -578,6 +651,12 @@ def main():
                                          if grouped else "single rank, no collective"),
                        "ranks": world},
             "roofline": roofline,
+            "build": {"library_md5": LIB_MD5,
+                      # every DVID_* variable the library or the host side reads decides which kernel / schedule ran: the ones set in
+                      # this process's environment are listed; anything not listed ran on its default
+                      "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DVID_")},
+                      "noise": "host generator + upload" if args.host_noise else "device (dvid_counter_normal)",
+                      "shared_tuner_cache": shared_tune, "rank0_cpus": None if cpus is None else "%d CPUs: %d..%d" % (len(cpus), cpus[0], cpus[-1])},
             "host_view": host_view,
             "host_fed": host_fed,
             "real_data_feed": feed,

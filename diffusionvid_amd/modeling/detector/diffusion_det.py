@@ -22,7 +22,7 @@ from torch import nn
 
 from ... import ops
 from ...structures.bounding_box import BoxList
-from ...structures.image_list import to_image_list
+from ...structures.image_list import ImageList, to_image_list
 from ...utils import synthetic
 from ..roi_heads.box_head.box_head import DynamicHead
 
@@ -191,6 +191,11 @@ class DiffusionDet(nn.Module):
         # ImageList (the reference's collator, collate_batch.py:24-35), in which case the detections are that package's
         # own `structures.bounding_box.BoxList`, so its evaluator / torch.save see their own type (`_result_class`).
         self.boxlist_cls = None
+        # hipGraph replay of the steady-state call of the reference's own protocol (one INFER_BATCH batch per call, no look-ahead):
+        # see _graphed_call.  DVID_CALL_GRAPH=0 / `use_call_graph = False` launches every call kernel by kernel (A/B, profiling).
+        self.use_call_graph = os.environ.get("DVID_CALL_GRAPH", "1") != "0"
+        self._graphs, self._graph_seen = {}, {}
+        self.graph_replays = 0
         self.host_wait_s = 0.0      # seconds this process spent blocked in the per-batch device->host result copy
         self.video_index = 0
         self.demo = False
@@ -231,6 +236,7 @@ class DiffusionDet(nn.Module):
         if self._engine is not None:           # weights changed: repack on next use
             self._engine.close()
             self._engine = None
+        self._graphs, self._graph_seen = {}, {}          # captured launches point at the old engine's weights
         return out
 
     def _noise(self, kind, frame_id, step, image, shape):
@@ -345,6 +351,12 @@ class DiffusionDet(nn.Module):
         # DDIM draws of every batch finished in this call, keyed and shaped exactly as that batch's own call would draw them
         ddim_draws = {fb: self._ddim_draws(nb, fb, pairs) for fb, nb in nb_of.items()} if self.sampling_timesteps > 1 else {}
 
+        # 0. the steady-state call of the reference's protocol as ONE hipGraph launch (see _graphed_call)
+        if self._call_graph_applies(infos, ref_l, ref_g, ahead, batch, frame_id):
+            out = self._graphed_call(frame_id, ref_l, whwh, w, h, pairs, batch, ddim_draws.get(frame_id))
+            if out is not None:
+                return out
+
         # 1. features + extraction pass over [local frames | global frames] (+ the look-ahead batches)
         local_split = self._ahead.pop(frame_id, None)
         if ref_g:
@@ -455,7 +467,107 @@ class DiffusionDet(nn.Module):
         self._mem_side_pending = True
         return True
 
-    def _extract(self, frame_id, ref_l, ref_g, ahead, whwh, on_global=None):
+    # ---- the steady-state call as a hipGraph ------------------------------------------------------------------------------
+    def _call_graph_applies(self, infos, ref_l, ref_g, ahead, batch, frame_id):
+        """A call that runs one full batch through the whole per-call pipeline and nothing else: the shipped protocol
+        (KEY_FRAME_LOCATION 0, ALL_FRAME_INTERVAL == INFER_BATCH, memory final after the video's first call), not the video's
+        first call, no global frames, no look-ahead hand-over, every frame a resident fp32 tensor of one size, memory present."""
+        if not self.use_call_graph or self.lookahead != 1 or self.debug_taps is not None or self.demo:
+            return False
+        mega = self.cfg.MODEL.VID.MEGA
+        if not (self.key_frame_location == 0 and self.all_frame_interval == self.infer_batch == mega.MAX_OFFSET + 1
+                and self.global_enable and mega.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST):
+            return False
+        if infos["frame_category"] == 0 or ref_g or ahead or frame_id in self._ahead or self._mem_side_pending:
+            return False
+        if len(ref_l) != self.infer_batch or batch != self.infer_batch or self.head.proposal_feats_global[0] is None:
+            return False
+        f0 = ref_l[0].tensors
+        return all(f.tensors.is_cuda and f.tensors.device == self.device and f.tensors.dtype == torch.float32
+                   and f.tensors.shape == f0.shape and f.tensors.shape[0] == 1 for f in ref_l)
+
+    def _graphed_call(self, frame_id, ref_l, whwh, w, h, pairs, batch, draws):
+        """One batch of the reference's call protocol (mega_core/engine/inference.py:22-94: 8 frames per working call) is ~180
+        kernel launches of 10-90 us -- backbone, 3 + 1 heads, attention, post-processing -- that differ from call to call only in
+        their INPUT VALUES: the frames and the random draws.  The first steady call of a shape runs kernel by kernel (tuner,
+        workspace growth, scale/shift rows); the second is captured into a hipGraph (torch.cuda.CUDAGraph on the launch stream:
+        the library launches on torch's current stream, so its kernels are captured like torch's own) reading static input
+        buffers; every later call copies its frames and draws into those buffers and replays the graph: one launch instead of
+        ~180, same kernels, same arguments, same order -- bit-identical detections (tests/test_gpu_e2e.py::
+        test_call_graph_replay_is_bit_identical).  Keyed by (frame shape, batch, DDIM steps, memory rows, engine); a graph is
+        dropped with its engine (load_state_dict).  Returns None when this call ran (or must run) the ordinary way."""
+        frames = [im.tensors for im in ref_l]
+        mem = self.head.proposal_feats_global
+        key = (tuple(frames[0].shape), len(frames), self.sampling_timesteps, int(mem[0].shape[0]), int(mem[1].shape[0]) if mem[1] is not None else 0,
+               id(self._engine), (float(w), float(h)))
+        M = self.num_proposals
+        g = self._graphs.get(key)
+        if g is None:
+            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            if self._graph_seen[key] < 2:
+                return None                      # the first steady call of this shape: eager (it also warms everything a capture may not do)
+            g = self._capture_call(key, frames, whwh, w, h, pairs, batch, draws)
+            if g is None:
+                return None
+        # this call's inputs into the graph's static buffers (device-to-device, on the launch stream), then ONE launch
+        torch._foreach_copy_(g["frames"], frames)
+        g["box_init"].copy_(self._noise("box_init", frame_id, 0, 0, (batch, M, 4)))
+        if draws is not None:
+            g["draws"]["img"].copy_(draws["img"])
+            for step, pair in g["draws"].items():
+                if step != "img":
+                    pair[0].copy_(draws[step][0])
+                    pair[1].copy_(draws[step][1])
+        if self.after_first_launch is not None:
+            self.after_first_launch()
+        g["graph"].replay()
+        self.graph_replays += 1
+        self.local_img_queue = []
+        return self._to_boxlists(*g["out"], (int(w), int(h)))
+
+    def _capture_call(self, key, frames, whwh, w, h, pairs, batch, draws):
+        M = self.num_proposals
+        static = {"frames": [torch.empty_like(f) for f in frames], "box_init": torch.empty((batch, M, 4), device=self.device),
+                  "draws": None}
+        if draws is not None:
+            static["draws"] = {k: (torch.empty_like(v) if k == "img" else (torch.empty_like(v[0]), torch.empty_like(v[1]))) for k, v in draws.items()}
+        static_l = [ImageList(f, im.image_sizes) for f, im in zip(static["frames"], [to_image_list(f) for f in frames])]
+        hook, self.after_first_launch = self.after_first_launch, None
+
+        def body():
+            local, _, _ = self._extract(0, static_l, [], {}, whwh, box_init=[static["box_init"]])
+            feats_cur, cached = local["feats"], (local["logits"], local["boxes"], local["obj"])
+            return self._final_stage_launch(feats_cur, cached, whwh, w, h, pairs, [(0, batch)], {0: static["draws"]} if static["draws"] is not None else {}, slots=batch)
+
+        try:
+            torch._foreach_copy_(static["frames"], frames)
+            static["box_init"].normal_()
+            if static["draws"] is not None:
+                for v in static["draws"].values():
+                    for t in (v if isinstance(v, tuple) else (v,)):
+                        t.normal_()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                body()                               # on the capture's kind of stream once: nothing left to allocate or tune
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):          # other host threads (a data loader's copies) stay legal
+                out = body()
+        except Exception as e:                       # a platform that cannot capture falls back to kernel-by-kernel launches, loudly
+            import warnings
+            warnings.warn("DiffusionDet: hipGraph capture of the steady-state call failed (%r); calls are launched kernel by kernel" % (e,))
+            self.use_call_graph = False
+            return None
+        finally:
+            self.after_first_launch = hook
+        static["graph"], static["out"] = graph, out
+        self._graphs[key] = static
+        return static
+
+    def _extract(self, frame_id, ref_l, ref_g, ahead, whwh, on_global=None, box_init=None):
         """Backbone + the 3 extraction RCNNHeads + top-k feature selection over [local | global | look-ahead] frames.
         Every stage here is per-frame independent, so the reference's splits of INFER_BATCH -- and with
         INPUT.LOOKAHEAD_BATCHES > 1 the frames of the next batches -- run as launches of up to INFER_BATCH *
@@ -469,7 +581,7 @@ class DiffusionDet(nn.Module):
         # as that batch's own call would: split 0 of call `fb`).  All uploads happen BEFORE any kernel is queued: a
         # host->device copy from pageable memory blocks the host until the stream has drained.
         sizes = [min(self.infer_batch, n_own - a) for a in range(0, n_own, self.infer_batch)]
-        noise = [self._noise("box_init", frame_id, bi, 0, (b, M, 4)) for bi, b in enumerate(sizes)]
+        noise = list(box_init) if box_init is not None else [self._noise("box_init", frame_id, bi, 0, (b, M, 4)) for bi, b in enumerate(sizes)]
         for fb in sorted(ahead):
             group = [to_image_list(im).tensors for im in ahead[fb]]
             frames += group
@@ -558,6 +670,10 @@ class DiffusionDet(nn.Module):
     def _final_stage(self, feats, cached, whwh, w, h, pairs, items, ddim_draws, slots=None):
         """Global attention + conditioned head (+ DDIM loop) + top-k/NMS over `R` frame slots holding the batches `items`
         = [(call frame id, real frames)], INFER_BATCH slots each unless `slots` says otherwise; -> one BoxList per slot."""
+        return self._to_boxlists(*self._final_stage_launch(feats, cached, whwh, w, h, pairs, items, ddim_draws, slots), (int(w), int(h)))
+
+    def _final_stage_launch(self, feats, cached, whwh, w, h, pairs, items, ddim_draws, slots=None):
+        """the device part of _final_stage: queues every kernel, no host synchronisation -> the post-processing outputs"""
         M = self.num_proposals
         R = cached[0].shape[0]
         per = self.infer_batch if slots is None else slots
@@ -580,7 +696,7 @@ class DiffusionDet(nn.Module):
                 if time_next >= 0:
                     draws[step] = tuple(torch.cat([padded(ddim_draws[fb][step][i], nb) for fb, nb in items]) for i in (0, 1))
             ob, osc, ol, oc = self._ddim_ensemble(feats, whwh, R, items[0][0], pairs, w, h, draws)
-        return self._to_boxlists(ob, osc, ol, oc, (int(w), int(h)))
+        return ob, osc, ol, oc
 
     # ---- helpers --------------------------------------------------------------------------------
     def _time_pairs(self):

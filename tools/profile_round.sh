@@ -7,13 +7,15 @@
 TAG=${1:-r01}
 ARCH=${2:-r101}
 SS=${3:-1}
+LA=${4:-0}                      # 0: the bench default (one group per video); 1: the reference call protocol (one batch per call)
 SUF=${ARCH}_x${SS}
+if [ "$LA" != "0" ]; then SUF=${SUF}_lookahead${LA}; fi
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export DVID_CHAINS=1            # sequential launches: per-kernel durations are not inflated by overlap
-CMD="python $REPO/bench.py --arch $ARCH --sample-step $SS --steps 1 --warmup 1 --no-cpu-baseline --no-host-fed --no-side-configs --no-feed-rate"
+CMD="python $REPO/bench.py --arch $ARCH --sample-step $SS --lookahead $LA --steps 1 --warmup 1 --no-cpu-baseline --no-host-fed --no-side-configs --no-feed-rate"
 # tile-tuner timing launches would pollute the statistics: fill the tuning cache in an unprofiled run first
 export DVID_IGEMM_TUNE_CACHE=/tmp/dvid_tune_cache.txt
 rm -f $DVID_IGEMM_TUNE_CACHE
@@ -25,8 +27,9 @@ for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -o pmc -- $CMD --warmup 0 > /tmp/prof_$C.log 2>&1
 done
 python - "$TAG" "$OUT" "$SUF" <<'PY'
-import csv, glob, json, sys
+import csv, glob, hashlib, json, os, sys
 tag, out, suf = sys.argv[1], sys.argv[2], sys.argv[3]
+lib_md5 = hashlib.md5(open(os.path.join(os.path.dirname(out), "diffusionvid_amd", "libdvid_hip.so"), "rb").read()).hexdigest()
 f = glob.glob("/tmp/prof_stats/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -35,7 +38,7 @@ with open(f"{out}/{tag}_kernel_stats_{suf}.txt", "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-fed --no-side-configs  (DVID_CHAINS=1; 5 videos of 304 frames:\n")
     o.write("# set-up, warm-up, timed step, chains=1 pass and instrumented pass)\n")
     o.write("total kernel time %.1f ms\n" % (tot / 1e6))
-    ig = [r for r in rows if "igemm2_kernel" in r["Name"] or "conv3x3_" in r["Name"] or "wstat" in r["Name"] or "bneck64" in r["Name"]]
+    ig = [r for r in rows if "igemm2_kernel" in r["Name"] or "conv3x3_" in r["Name"] or "wstat" in r["Name"] or "bneck" in r["Name"]]
     igt = sum(float(r["TotalDurationNs"]) for r in ig); igc = sum(int(r["Calls"]) for r in ig)
     o.write("implicit-GEMM kernels (igemm2_kernel, conv3x3_halo_kernel, conv3x3_c64_kernel, wstat_kernel, wstat2_kernel, bneck64_tail_kernel; all instantiations): calls %d total %.2f ms avg %.2f us  %.1f%%\n" % (igc, igt / 1e6, igt / igc / 1e3, 100 * igt / tot))
     for r in rows[:40]:
@@ -46,14 +49,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     s = n = 0.0
     for fn in fs:
         for r in csv.DictReader(open(fn)):
-            if ("igemm2_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck64" in r["Kernel_Name"]) and r["Counter_Name"] == c:
+            if ("igemm2_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck" in r["Kernel_Name"]) and r["Counter_Name"] == c:
                 s += float(r["Counter_Value"]); n += 1
     res[c] = (s, n)
 def per_kernel(c):
     s = n = 0.0
     for fn in glob.glob(f"/tmp/prof_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
-            if ("igemm2_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck64" in r["Kernel_Name"]) and r["Counter_Name"] == c:
+            if ("igemm2_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck" in r["Kernel_Name"]) and r["Counter_Name"] == c:
                 s += float(r["Counter_Value"]); n += 1
     return s, n
 mb, _ = per_kernel("SQ_VALU_MFMA_BUSY_CYCLES")
@@ -67,7 +70,7 @@ if res["FETCH_SIZE"][1] and res["WRITE_SIZE"][1]:
     write = res["WRITE_SIZE"][0] / res["WRITE_SIZE"][1] * 1024
     same = json.loads([l for l in open("/tmp/prof_FETCH_SIZE.log") if l.startswith('{"metric"')][-1])["roofline"]
     json.dump({"kernel": "implicit-GEMM kernels (igemm2_kernel + conv3x3_* + wstat*_kernel + bneck*_tail_kernel; all instantiations)", "launches": int(res["FETCH_SIZE"][1]),
-               "configuration": suf,
+               "configuration": suf, "library_md5": lib_md5,
                "alg_bytes_per_launch_same_run": same["layerwise_alg_mbytes_per_launch"] * 1e6,
                "mfma_busy_fraction": mfma_busy,
                "mfma_busy_method": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs over sum(GRBM_GUI_ACTIVE) / 8 XCDs, implicit-GEMM launches only",
