@@ -72,7 +72,6 @@ SIGNATURES = {
     "dvid_igemm_set_tuning": (c_int, [c_int]),
     "dvid_igemm_set_conv3x3": (c_int, [c_int]),
     "dvid_igemm_set_wstat": (c_int, [c_int]),
-    "dvid_igemm_set_wdirect": (c_int, [c_int]),
     "dvid_igemm_set_bottleneck_fusion": (c_int, [c_int]),
     "dvid_profile_enable": (c_int, [c_int]),
     "dvid_profile_reset": (c_int, []),

@@ -751,12 +751,6 @@ int dvid_igemm_set_conv3x3(int mode) {
 
 // short-K / wide-N 1x1 layers on the weight-stationary kernel (wstat.hip): -1 = DVID_WSTAT or on, 0 = off, 1 = on where the shape rule
 // prefers it, 2 = on wherever the layer type fits (tests).  Bit-identical to igemm2, so the rule may look at the row count.
-static int g_wdirect_mode = -1;
-int dvid_igemm_set_wdirect(int mode) {
-    if (mode < -1 || mode > 2) return DVID_ERR_ARG;
-    g_wdirect_mode = mode;
-    return DVID_OK;
-}
 static int g_wstat_mode = -1;
 int dvid_igemm_set_wstat(int mode) {
     if (mode < -1 || mode > 2) return DVID_ERR_ARG;
@@ -773,9 +767,6 @@ int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
         const bool forced = g_forced_cfg >= 0 || (g_forced_cfg < -1 && cfg_forced_env0 >= 0);
         const int ws = g_wstat_mode >= 0 ? g_wstat_mode : ws_env;
         if (ws && !forced && (ws >= 2 ? dvid_wstat_supported(p) : dvid_wstat_preferred(p))) return dvid_wstat_launch(p, s);
-        static const int wd_env = getenv("DVID_WDIRECT") ? atoi(getenv("DVID_WDIRECT")) : 1;
-        const int wd = g_wdirect_mode >= 0 ? g_wdirect_mode : wd_env;
-        if (wd && !forced && (wd >= 2 ? dvid_wdirect_supported(p) : dvid_wdirect_preferred(p))) return dvid_wdirect_launch(p, s);
     }
     return dvid_igemm2_launch(p, s);
 }

@@ -15,7 +15,6 @@ struct IgemmParams {
     int splitk;                             // > 1: K split over `splitk` workgroups per tile, fp32 partials (no bias/relu/residual)
     long split_stride;                      //       written to out + split * split_stride (elements)
     int tiles_m, tiles_n;                   // filled by the launcher
-    const half_t* wfrag;                    // the weights in MFMA fragment order (model.hip: make_frags) or nullptr (csrc/wdirect.hip)
 };
 int dvid_igemm_launch(const IgemmParams& p, hipStream_t s);   // igemm2.hip: picks the kernel family (wstat / conv3x3 / igemm2) by the layer's shape
 int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s);  // igemm2.hip: the igemm2 kernel with its per-shape tuned tile configuration
@@ -29,12 +28,6 @@ int dvid_conv3x3_halo_launch(const IgemmParams& p, hipStream_t s);
 bool dvid_wstat_supported(const IgemmParams& p);
 bool dvid_wstat_preferred(const IgemmParams& p);
 int dvid_wstat_launch(const IgemmParams& p, hipStream_t s);
-
-// wdirect.hip: long-K 1x1 layers with N = 256 -- A rows through an 8-stage DMA ring, weight fragments straight from L2 into the MFMA
-// operand registers (bit-identical to igemm2)
-bool dvid_wdirect_supported(const IgemmParams& p);
-bool dvid_wdirect_preferred(const IgemmParams& p);
-int dvid_wdirect_launch(const IgemmParams& p, hipStream_t s);
 
 // bneck.hip: the tail of a res2 bottleneck block (conv2 3x3 64 -> 64, conv3 64 -> 256 + residual or shortcut convolution, ReLU and the
 // next block's conv1 256 -> 64) as one launch; bit-identical to the layer-by-layer launches.  ws == null: the residual is `res`

@@ -174,7 +174,6 @@ struct DevBuf {
 
 struct ConvW {   // conv or linear weights in MFMA-operand layout
     half_t* w = nullptr;
-    half_t* wf = nullptr;      // the same weights in MFMA fragment order (make_frags) for the layers csrc/wdirect.hip takes, else nullptr
     float* bias = nullptr;
     int cin = 0, cout = 0, kh = 1, kw = 1, stride = 1, pad = 0, kpad = 0;
     int cin_real = 0;  // un-padded input channels (algorithmic FLOP count)
@@ -548,7 +547,6 @@ int conv_run(const ConvW& w, const half_t* in, int n, int h, int wd, void* out, 
     memset(&p, 0, sizeof(p));
     p.in = in;
     p.w = w.w;
-    p.wfrag = w.wf;
     p.bias = w.bias;
     p.res = res;
     p.out = out;
@@ -847,8 +845,6 @@ int dvid_model_finalize(dvid_model* m) {
                 Block& blk = m->blocks[s][b];
                 const int stride = (b == 0 && s > 0) ? 2 : 1;  // STRIDE_IN_1X1: False -> stride on the 3x3
                 TRY(make_conv_bn(m, p + ".conv1", 1, 0, 0, &blk.c1));
-                // the long-K conv1 layers with 256 outputs (res4) also in fragment order: csrc/wdirect.hip reads them straight from L2
-                if (blk.c1.cout == 256 && (blk.c1.kpad == 512 || blk.c1.kpad == 1024 || blk.c1.kpad == 2048)) TRY(make_frags(m, blk.c1, &blk.c1.wf));
                 TRY(make_conv_bn(m, p + ".conv2", stride, 1, 0, &blk.c2));
                 TRY(make_conv_bn(m, p + ".conv3", 1, 0, 0, &blk.c3));
                 blk.has_sc = (b == 0);

@@ -220,11 +220,6 @@ int dvid_igemm_set_conv3x3(int mode);
  * enough for 256 persistent workgroups, 2 = wherever the layer type fits (tests), 0 = off (igemm2), -1 = follow DVID_WSTAT (default 1).
  * Bit-identical to igemm2. */
 int dvid_igemm_set_wstat(int mode);
-/* 1x1 convolutions / linear layers with N = 256 and K in {512, 1024, 2048} without a residual (res4's conv1, 22 layers of ResNet-101)
- * on the weight-direct kernel (csrc/wdirect.hip: the A rows stream through an 8-stage DMA ring, every wave reads the weight fragments
- * of its 32 output channels straight from L2 into the MFMA operand registers): 1 = launches of at least 512 row tiles, 2 = wherever
- * the layer type fits (tests), 0 = off (igemm2), -1 = follow DVID_WDIRECT (default 1).  Bit-identical to igemm2. */
-int dvid_igemm_set_wdirect(int mode);
 
 /* res2 / res3 bottleneck blocks behind their conv1 as one launch each (csrc/bneck.hip: dvid_bottleneck64_tail_f16 /
  * dvid_bottleneck128_tail_f16 inside the ResNet backbone): 1 = where the shape rule of the 3x3 patch kernels holds for the stage's map

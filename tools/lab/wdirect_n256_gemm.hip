@@ -276,3 +276,14 @@ int dvid_wdirect_launch(const IgemmParams& p, hipStream_t s) {
         default: return p.relu ? launch<2048, true>(p, wfrag, s) : launch<2048, false>(p, wfrag, s);
     }
 }
+
+// ---- round-4 record (why this is in tools/lab/ and not in the library) ----------------------------------------------------------
+// Bit-identical to igemm2 (tests: 5 shapes, ragged rows, K 512 / 1024 / 2048; 220 VGPRs, no spills) and SLOWER on the layer it was
+// written for (profiles/r04d_wdirect_bench.txt, tools/bench_igemm.py --only res4.1.conv1): res4 conv1 at 304 frames 0.601 ms against
+// igemm2's 0.497 (645 vs 780 TFLOP/s; the vendor GEMM 0.509), at 104 frames 0.212 vs 0.176, at 8 frames 0.033 vs 0.022.  Halving the
+// DMA pieces and doubling the ring depth did not help because all eight waves move through a step together: after the barrier every wave
+// issues its loads, then nine fragment reads, then waits for them (lgkmcnt) with the matrix pipe empty -- the two waves of a SIMD
+// are in the same phase, so nobody covers the LDS latency.  igemm2's 256 x 256 configuration wins with twice the pieces because its
+// two wave rows run in anti-phase (one reads while the other multiplies).  The idea that survived is the operand split itself --
+// A rows by DMA, weight fragments from L2 into registers -- built into igemm2's anti-phase schedule as tile configuration NSTAGE 6
+// (csrc/igemm2.hip), where the tuner times it against the others per shape.
