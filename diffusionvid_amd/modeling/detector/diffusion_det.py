@@ -181,6 +181,7 @@ class DiffusionDet(nn.Module):
         self.after_first_launch = None      # optional callable, run once the first backbone launch of a call is queued
         self.memory_on_side_stream = os.environ.get("DVID_MEMORY_SIDE_STREAM", "1") != "0"
         self._mem_stream = None
+        self._mem_stream2 = None
         self._mem_side_pending = False
         self._mem_side_inputs = None
         self.debug_taps = None      # dict -> receives intermediates (parity tests)
@@ -444,8 +445,22 @@ class DiffusionDet(nn.Module):
     def _build_memory(self, gsplit):
         g1 = gsplit["k1"].reshape(-1, self.hidden_dim)
         g2 = gsplit["k2"].reshape(-1, self.hidden_dim)
-        m0, _ = ops.update_erase_memory(g1, self.head.proposal_feats_global[0], self.mem_management_size_test)
-        m1, _ = ops.update_erase_memory(g2, self.head.proposal_feats_global[1], 150)
+        # The two memories (900 / 150 rows) are pruned independently, each by a sweep of dependent arg-max steps on ONE workgroup:
+        # the short one runs on a second stream beside the long one (same kernels, same inputs -> same memories).
+        if self.memory_on_side_stream:
+            if self._mem_stream2 is None:
+                self._mem_stream2 = torch.cuda.Stream(device=self.device)
+            cur = torch.cuda.current_stream()
+            self._mem_stream2.wait_stream(cur)
+            with torch.cuda.stream(self._mem_stream2):
+                m1, _ = ops.update_erase_memory(g2, self.head.proposal_feats_global[1], 150)
+            m0, _ = ops.update_erase_memory(g1, self.head.proposal_feats_global[0], self.mem_management_size_test)
+            cur.wait_stream(self._mem_stream2)
+            g2.record_stream(self._mem_stream2)          # read on the second stream: its block is not recycled under that read
+            m1.record_stream(cur)                        # allocated on the second stream, read on this one from here on
+        else:
+            m0, _ = ops.update_erase_memory(g1, self.head.proposal_feats_global[0], self.mem_management_size_test)
+            m1, _ = ops.update_erase_memory(g2, self.head.proposal_feats_global[1], 150)
         self._set_global_memory([m0, m1])
         if self.debug_taps is not None:
             self.debug_taps["memory"] = [m0, m1]
