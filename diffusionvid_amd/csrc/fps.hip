@@ -116,7 +116,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ dis
 // from the winning key itself -- prio = bitrev(k % bs) * pmul + k / bs is invertible -- so a step is one row read, one wave
 // reduction, ONE barrier (winner slots double-buffered) instead of two barriers and an owner search through LDS.  Same keys, same
 // maximum: the same picks as fps_kernel (tests/test_gpu_kernels.py compares both with the thread-level emulation of fps.cu).
-template <int EPT, bool WARM>
+template <int EPT>
 __global__ __launch_bounds__(256) void fps_reg_kernel(const float* __restrict__ dist, int n, int m, int bs, int bs_bits,
                                                        int* __restrict__ idx) {
     __shared__ u64 wbest[2][4];
@@ -133,24 +133,6 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float* __restrict__ 
         kc[e] = (int)k < n ? (int)k : n - 1;
     }
     if (tid == 0) idx[0] = 0;
-    // Pull the distance matrix into THIS XCD's L2 first.  The sweep is m - 1 dependent steps, each a read of one row nobody can
-    // predict; the matrix was written by a kernel spread over all eight XCDs (per-XCD L2s are not coherent: its lines were written
-    // back at that kernel's end), so every such read is a far-memory access (~1-2 us) -- the step time.  n <= 1000 is 4 MB at most,
-    // an XCD's L2: one streaming pass (16-byte loads, 8 in flight per lane, ~40 us) turns them into L2 hits.  `warm` only keeps
-    // the loads alive.
-    if (WARM) {
-        const long total16 = ((long)n * n) >> 2;
-        const float4v* d4 = reinterpret_cast<const float4v*>(dist);
-        float warm = 0.f;
-        for (long i = tid; i < total16; i += 256 * 8) {
-            float4v t[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = d4[i + 256 * e < total16 ? i + 256 * e : i];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) warm += t[e][0];
-        }
-        asm volatile("" ::"v"(warm));
-    }
     int old = 0;
     for (int j = 1; j < m; ++j) {
         const float* row = dist + (long)old * n;
@@ -215,14 +197,9 @@ int dvid_fps_launch(const float* dist, int n, int m, int bs_emul, int* idx, hipS
     static const bool lds_form = getenv("DVID_FPS_LDS") && atoi(getenv("DVID_FPS_LDS")) != 0;          // A/B: the round-1 kernel
     if (!lds_form && n <= 256 * 16) {
         const int ept = (n + 255) / 256;
-        // the L2 warm-up pays when the matrix fits an XCD's L2 and the sweep is long enough to amortise the pass (DVID_FPS_WARM=0: off)
-        static const bool warm_env = !(getenv("DVID_FPS_WARM") && atoi(getenv("DVID_FPS_WARM")) == 0);
-        const bool warm = warm_env && (long)n * n * 4 <= (4l << 20) && m >= 64 && ((long)n * n) % 4 == 0;
-        if (ept <= 4) {
-            if (warm) hipLaunchKernelGGL((fps_reg_kernel<4, true>), dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
-            else hipLaunchKernelGGL((fps_reg_kernel<4, false>), dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
-        } else if (ept <= 8) hipLaunchKernelGGL((fps_reg_kernel<8, false>), dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
-        else hipLaunchKernelGGL((fps_reg_kernel<16, false>), dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
+        if (ept <= 4) hipLaunchKernelGGL(fps_reg_kernel<4>, dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
+        else if (ept <= 8) hipLaunchKernelGGL(fps_reg_kernel<8>, dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
+        else hipLaunchKernelGGL(fps_reg_kernel<16>, dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
         LAUNCH_CHECK();
         return DVID_OK;
     }
