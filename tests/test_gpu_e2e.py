@@ -1242,3 +1242,64 @@ def test_call_graph_replay_is_bit_identical(arch, sample_step, noise):
         assert len(a) == len(b) and len(a) > 0, f
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores")) and \
             torch.equal(a.get_field("labels"), b.get_field("labels")), f"frame {f} differs between graph replay and kernel-by-kernel launches"
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_x4_free_running_divergence_belongs_to_the_precision_policy(full):
+    """x4 with real renewals (trained-like scores): one keep decision that flips at the 0.5 threshold re-draws every later slot of
+    its frame (diffusion_det.py:559-572), so two evaluations that differ by rounding part ways after the first flip -- the
+    full-size x4 run agrees with the fp32 oracle on only 0.33-0.96 of a frame's detections (TRAINED_LIKE above).  Is that the
+    kernels' doing?  The same video through the CPU oracle under the fp16 STORAGE POLICY of the path (oracle/precision.py: fp16
+    weights and stored activations, fp32 accumulation -- no HIP kernel involved) diverges from the fp32 oracle the same way:
+    the GPU path must be no further from the fp32 oracle than that policy oracle is (match rate and AP50 over the fp32
+    oracle's objects, margin 0.1), and the three pairwise figures are printed."""
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.structures.bounding_box import BoxList
+    from diffusionvid_amd.utils import synthetic
+    from oracle import precision
+    blocks = None if full else (1, 1, 2, 1)          # full: R101 (3, 4, 23, 3) at 1000 x 600, the configuration of TRAINED_LIKE's x4 line
+    cfg, model = _build(4, blocks, "trained_like")
+    L, H0, W0 = (8, 600, 1000) if full else (8, 250, 380)
+    ds = SyntheticVIDDataset([L], cfg, height=H0, width=W0, device="cuda", smooth=True)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    model.noise_fn = synthetic.noise_fn
+    images, oitem, ids = _oracle_items(ds, 0)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+
+    def oracle_run(policy):
+        ocfg = odet.DetCfg(sample_step=4, **({} if blocks is None else {"blocks": blocks}))
+        ocfg.head.sampling_timesteps = 4
+        o = odet.OracleDiffusionDet(sd, ocfg, synthetic.noise_fn)
+        with torch.no_grad():
+            if policy:
+                with precision.use("fp16"):
+                    return o.forward(oitem)
+            return o.forward(oitem)
+    with torch.no_grad():
+        got = model(images)
+    ref32, ref16 = oracle_run(False), oracle_run(True)
+    size = (W0, H0)
+
+    def as_boxlists(ref):
+        out = []
+        for r in ref:
+            bl = BoxList(torch.as_tensor(r["boxes"], dtype=torch.float32).reshape(-1, 4), size)
+            bl.add_field("scores", torch.as_tensor(r["scores"], dtype=torch.float32).reshape(-1))
+            bl.add_field("labels", torch.as_tensor(r["labels"], dtype=torch.int64).reshape(-1))
+            out.append(bl)
+        return out
+    pol = as_boxlists(ref16)
+    m_gpu = [_match_rate(r, g) for r, g in zip(ref32, got)]
+    m_pol = [_match_rate(r, g) for r, g in zip(ref32, pol)]
+    m_gp = [_match_rate(r, g) for r, g in zip(ref16, got)]
+    ap_gpu, n_obj = _ap50_on_objects(ref32, got, size)
+    ap_pol, _ = _ap50_on_objects(ref32, pol, size)
+    ap_all_gpu, ap_all_pol = _ap50_vs_oracle(ref32, got, size), _ap50_vs_oracle(ref32, pol, size)
+    line = (f"[x4 free-running{' full size' if full else ''}, trained-like scores, {n_obj} fp32-oracle objects] per-frame match with the fp32 oracle: GPU {['%.2f' % v for v in m_gpu]}, "
+            f"fp16-policy oracle {['%.2f' % v for v in m_pol]}; GPU vs fp16-policy oracle {['%.2f' % v for v in m_gp]}; AP50 over the fp32 oracle's objects: "
+            f"GPU {ap_gpu:.4f}, fp16-policy oracle {ap_pol:.4f}; AP50 over all its detections: GPU {ap_all_gpu:.4f}, fp16-policy oracle {ap_all_pol:.4f}")
+    print(line)
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write(line + "\n")
+    assert n_obj >= 4
+    assert float(np.mean(m_gpu)) >= float(np.mean(m_pol)) - 0.1 and ap_gpu >= ap_pol - 0.1 and ap_all_gpu >= ap_all_pol - 0.1, line

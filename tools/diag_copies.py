@@ -13,11 +13,11 @@ from diffusionvid_amd.modeling.detector import build_detection_model
 from diffusionvid_amd.utils import synthetic
 
 device = torch.device("cuda", 0)
-cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", 13],
+cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", 38],
               os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
 cfg.freeze()
 model = build_detection_model(cfg).to(device).eval()
-model.noise_fn = synthetic.noise_fn
+model.noise_fn = synthetic.DeviceNoise()
 model.results_on_host = True
 ds = SyntheticVIDDataset([304], cfg, height=600, width=1000, device=device, emit_ref_ahead=False)
 ds.preload()
