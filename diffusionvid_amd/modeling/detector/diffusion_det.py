@@ -538,7 +538,12 @@ class DiffusionDet(nn.Module):
         g["graph"].replay()
         self.graph_replays += 1
         self.local_img_queue = []
-        return self._to_boxlists(*g["out"], (int(w), int(h)))
+        out = g["out"]
+        if not self.results_on_host:
+            # the BoxLists would be views of the graph's static output buffer, which the next replay overwrites: hand out copies
+            # (results_on_host copies the buffer to the host anyway)
+            out = tuple(t.clone() for t in out)
+        return self._to_boxlists(*out, (int(w), int(h)))
 
     def _capture_call(self, key, frames, whwh, w, h, pairs, batch, draws):
         M = self.num_proposals

@@ -1230,8 +1230,9 @@ def test_call_graph_replay_is_bit_identical(arch, sample_step, noise):
         res = []
         with torch.no_grad():
             for idx in range(len(ds)):
-                res += [r.to(torch.device("cpu")) for r in model(ds[idx][0])]
+                res += model(ds[idx][0])          # device tensors kept across calls: a replay must not overwrite what an earlier call returned
         assert len(res) == sum(lens)
+        res = [r.to(torch.device("cpu")) for r in res]
         outs[graphs], replays[graphs] = res, model.graph_replays
         del model, ds
         torch.cuda.empty_cache()
