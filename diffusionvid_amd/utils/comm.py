@@ -102,5 +102,5 @@ def bind_rank_to_cpus(local_rank, local_world):
         os.sched_setaffinity(0, cpus)
         torch.set_num_threads(max(1, min(len(cpus), 32)))
         return cpus
-    except OSError:
+    except (OSError, ValueError):
         return None

@@ -950,7 +950,8 @@ def test_checkpoint_ingest_reproduces_direct_load(tmp_path):
         assert torch.equal(a.get_field("labels"), b.get_field("labels"))
 
 
-def test_streaming_mode_online_memory_update():
+@pytest.mark.parametrize("free_running", [False, True])
+def test_streaming_mode_online_memory_update(free_running):
     """the latency-oriented variant -- demo/demo.py:60-68 (INFER_BATCH 1, ALL_FRAME_INTERVAL 1,
     MAX_OFFSET 0) with GLOBAL.STOP_UPDATE_AFTER_INIT_TEST False, i.e. one frame per call and one new global frame per call
     after the first (vid_mega.py:213-215): every call merges 75 / 25 new rows into the 900 / 150-row memories and prunes
@@ -959,7 +960,10 @@ def test_streaming_mode_online_memory_update():
     injects it), so what is compared is one call's work -- extraction, merge + pruning, final stage, detections -- not the
     drift two free-running memories accumulate over 30 re-prunings (measured last round: 0.87 -> 0.73 of the rows with a twin,
     while single calls agree as the other end-to-end tests do).  The GPU's pruning on the ORACLE's merged rows returns the
-    oracle's picks (integer work; cdist differs in the last bits, so exact near-ties may swap)."""
+    oracle's picks (integer work; cdist differs in the last bits, so exact near-ties may swap).
+    free_running = True: the GPU path keeps ITS OWN memory over all 30 calls, nothing is injected -- the drift
+    of two free-running memories through 30 re-prunings stays covered: at least half of the oracle's memory rows keep a GPU
+    twin at the end (measured 0.73-0.87), detections stay matched (mean >= 0.9)."""
     from diffusionvid_amd import ops
     from diffusionvid_amd.config import get_cfg
     from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
@@ -985,7 +989,7 @@ def test_streaming_mode_online_memory_update():
         images, oitem, ids = _oracle_items(ds, idx)
         assert len(images["ref_l"]) == 1 and len(images["ref_g"]) == (24 if idx == 0 else 1) and ids == [idx]
         mem_before = None if idx == 0 else [m.clone() for m in oracle.mem]
-        if idx > 0:
+        if idx > 0 and not free_running:
             model._set_global_memory([m.cuda() for m in mem_before])          # this call starts from the oracle's memory
         model.debug_taps = {}
         with torch.no_grad():
@@ -993,6 +997,10 @@ def test_streaming_mode_online_memory_update():
             got = model(images)
         assert len(ref) == len(got) == 1
         rates.append(_match_rate(ref[0], got[0]))
+        if free_running:
+            gm, om = model.head.proposal_feats_global[0].cpu(), oracle.mem[0]
+            mem_close.append((torch.cdist(om, gm).min(dim=1).values < 0.5).float().mean().item())
+            continue
         fin_ok.append(_stage_check(f"[streaming] call {idx} final stage", None, None, model.debug_taps["final_0"][0].cpu(), oracle.taps["final_0"][0],
                                    model.debug_taps["final_0"][1].cpu(), oracle.taps["final_0"][1], frac_ok=0.97))
         if idx > 0:
@@ -1012,11 +1020,14 @@ def test_streaming_mode_online_memory_update():
         gm, om = model.head.proposal_feats_global[0].cpu(), oracle.mem[0]
         assert gm.shape == om.shape == (900, 256)
         mem_close.append((torch.cdist(om, gm).min(dim=1).values < 0.5).float().mean().item())
-    print(f"[streaming] match rates min {min(rates):.2f} mean {sum(rates) / len(rates):.3f}; memory rows with a GPU twin: "
-          f"first {mem_close[0]:.3f} last {mem_close[-1]:.3f}")
+    print(f"[streaming{' free-running' if free_running else ''}] match rates min {min(rates):.2f} mean {sum(rates) / len(rates):.3f}; memory rows with a GPU twin: "
+          f"first {mem_close[0]:.3f} last {mem_close[-1]:.3f} min {min(mem_close):.3f}")
     with open("gpurun_out/parity_report.txt", "a") as f:
-        f.write(f"[streaming INFER_BATCH=1, online memory] detections matched min {min(rates):.2f} mean {sum(rates) / len(rates):.3f}; "
+        f.write(f"[streaming INFER_BATCH=1, online memory{', free-running (own memory over 30 calls)' if free_running else ''}] detections matched min {min(rates):.2f} mean {sum(rates) / len(rates):.3f}; "
                 f"memory twins first {mem_close[0]:.3f} last {mem_close[-1]:.3f}\n")
+    if free_running:
+        assert min(mem_close) > 0.5 and sum(rates) / len(rates) >= 0.9, (min(mem_close), rates)
+        return
     assert min(rates) >= 0.9 and sum(rates) / len(rates) >= 0.97
     # one call's merge + pruning from the same 900 rows: at most the 75 new rows (own fp16-path features) and near-tie picks differ
     assert min(mem_close[1:]) > 0.9 and mem_close[0] > 0.8
