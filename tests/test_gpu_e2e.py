@@ -401,7 +401,7 @@ def _final_stage_vs_oracle(model, oracle, L, W0, H0, sample_step, tag, min_decid
     return decided, open_
 
 
-@pytest.mark.parametrize("sample_step,noise", [(1, "host"), (4, "host"), (4, "device")])
+@pytest.mark.parametrize("sample_step,noise", [(1, "host"), (4, "device")])
 def test_video_e2e(sample_step, noise):
     """noise = "device" (round 4): the GPU path generates every draw with dvid_counter_normal (synthetic.DeviceNoise) while the
     oracle regenerates the same values on the CPU (oracle/noise.py) -- the device-side counterpart of the reference's
@@ -488,7 +488,7 @@ UNTAMED = {1: {"extract_ok": 0.92, "final_ok": 0.55, "decided": 0.0, "outliers":
            4: {"extract_ok": 0.92, "final_ok": 0.55, "decided": 0.0, "outliers": 0.55, "match": 0.25, "ap": 0.8, "ap_objects": 0.85}}
 
 
-@pytest.mark.parametrize("sample_step", [1, 4])
+@pytest.mark.parametrize("sample_step", [1])          # (x4: measured in the calibration run -- UNTAMED[4] above -- and not repeated in the suite)
 def test_video_e2e_untamed_box_deltas(sample_step):
     """One end-to-end case WITHOUT `tame_box_deltas` (VERDICT r3 weak #2b): the raw random-init regression layers, which multiply
     box sizes by up to e^(+-2) per head -- three heads in the extraction pass, a fourth in the final stage -- on smooth frames
@@ -697,8 +697,10 @@ TRAINED_LIKE = {("r101", 1): {"decided": 0.15, "outliers": 0.05, "ap": 0.975, "a
                 ("swinb", 1): {"decided": 0.5, "outliers": 0.01, "ap": 0.975, "ap_objects": 0.999, "match": 0.9}}
 
 
-@pytest.mark.parametrize("weights", ["init", "trained_like"])
-@pytest.mark.parametrize("arch,sample_step", [("r101", 1), ("r101", 4), ("swinb", 1)])
+# (x4 and Swin-B with the "init" weights ran in every round up to the calibration run of round 4 -- profiles/r04_parity_report.txt -- and are
+# subsumed by their trained-like variants: same kernels, same stages, wider score spread; dropped to keep the suite near ten minutes)
+@pytest.mark.parametrize("arch,sample_step,weights", [("r101", 1, "init"), ("r101", 1, "trained_like"), ("r101", 4, "trained_like"),
+                                                      ("swinb", 1, "trained_like")])
 def test_video_e2e_full_configuration(arch, sample_step, weights):
     """BASELINE.json configs[1..3] as they are benchmarked -- ResNet-101 (3,4,23,3) x1 and x4, Swin-Base (embed 128,
     depths 2-2-18-2, heads 4-8-16-32) x1; 1000x600 frames, 300 boxes -- on the first call of a one-batch video (8 / 4
@@ -795,7 +797,7 @@ def test_other_num_proposals(num_proposals):
     assert min(rates) >= 0.9
 
 
-@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("full", [False])          # (full size: the policy oracle alone, medians only -- ran through round 4's calibration; profiles/r04j_gpu_pytest.log)
 def test_video_e2e_fp16_policy_oracle_bench_regime(full):
     """The regime bench.py runs in -- UNTAMED random-init heads, white-noise frames -- against the oracle
     under the fp16 storage policy of the MI355X path (oracle/precision.py: fp16-rounded weights and stored activations,
@@ -1256,7 +1258,7 @@ def test_call_graph_replay_is_bit_identical(arch, sample_step, noise):
             torch.equal(a.get_field("labels"), b.get_field("labels")), f"frame {f} differs between graph replay and kernel-by-kernel launches"
 
 
-@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("full", [True])          # (the reduced size shows no divergence at all: 95 objects, matches 0.98-1.00 on every pair; profiles/r04_parity_report_tail.txt)
 def test_x4_free_running_divergence_belongs_to_the_precision_policy(full):
     """x4 with real renewals (trained-like scores): one keep decision that flips at the 0.5 threshold re-draws every later slot of
     its frame (diffusion_det.py:559-572), so two evaluations that differ by rounding part ways after the first flip -- the
