@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IgemmParams p, int ti
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 const int ks = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);          // transposed (D[n][m]): same sums, see the epilogue
                 if ((q & 3) == 1) {
                     const int k = q >> 2;
                     if (k < B_IT) issue_b(c3, tap3, k);
@@ -222,15 +222,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IgemmParams p, int ti
         if (pass) __syncthreads();
         if ((wm * TM * 32) / GR == pass) {
             const int rbase = wm * TM * 32 - pass * GR;
+            // the products are computed transposed (the weight fragment is the MFMA's first operand): a lane holds 4 consecutive channels of
+            // ONE pixel per register quad -- four 16-byte LDS writes per accumulator tile instead of sixteen scalar ones
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        const int col = wn * (BN / WN) + j * 32 + (lane & 31);
-                        Cs[row * CP + col] = acc[i][j][r];
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int row = rbase + i * 32 + (lane & 31);
+                        const int col = wn * (BN / WN) + j * 32 + 8 * r4 + 4 * (lane >> 5);
+                        *reinterpret_cast<float4v*>(Cs + row * CP + col) =
+                            (float4v){acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
                     }
         }
         __syncthreads();
