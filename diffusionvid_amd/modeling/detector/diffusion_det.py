@@ -535,6 +535,9 @@ class DiffusionDet(nn.Module):
                     pair[1].copy_(draws[step][1])
         if self.after_first_launch is not None:
             self.after_first_launch()
+        # the captured launches read the memory's K / V projections from the engine's buffers; projecting is not part of the capture
+        # (a memory adopted from another rank, or replaced in place, has not been through global_xattn yet)
+        self._get_engine().ensure_memory_projected(mem[0])
         g["graph"].replay()
         self.graph_replays += 1
         self.local_img_queue = []

@@ -374,6 +374,16 @@ class Model:
         which no tensor version counter sees): the next global_xattn projects K/V again."""
         self._kv_src = None
 
+    def ensure_memory_projected(self, memory):
+        """K / V projections of `memory` into the engine's buffers unless they are current (same tensor object, same version).
+        global_xattn calls it; a captured launch sequence that READS those buffers (DiffusionDet._graphed_call) calls it before
+        every replay, because the projection itself is not part of the capture."""
+        if self._kv_src is None or self._kv_src is not memory or self._kv_ver != memory._version:
+            mem = _cuda(memory, torch.float32)
+            call("dvid_global_memory_project", self.handle, ptr(mem), mem.shape[0], stream_ptr())
+            self._kv_src = memory            # holds the tensor: its storage cannot be recycled under the cache
+            self._kv_ver = memory._version
+
     def global_xattn(self, query, memory):
         """cond = MHA(query, memory, memory).  The K/V projections of `memory` are kept until `invalidate_memory()` (the
         detector calls it wherever it assigns the memory) or until another tensor object is passed, i.e. they are computed
@@ -381,11 +391,7 @@ class Model:
         the memory (copy_, index_put_, ...) bumps the counter and projects again; a write through a raw pointer, which no
         counter sees, needs `invalidate_memory()`."""
         query = _cuda(query, torch.float32)
-        if self._kv_src is None or self._kv_src is not memory or self._kv_ver != memory._version:
-            mem = _cuda(memory, torch.float32)
-            call("dvid_global_memory_project", self.handle, ptr(mem), mem.shape[0], stream_ptr())
-            self._kv_src = memory            # holds the tensor: its storage cannot be recycled under the cache
-            self._kv_ver = memory._version
+        self.ensure_memory_projected(memory)
         out = torch.empty_like(query)
         call("dvid_global_xattn", self.handle, ptr(query), query.shape[0], None, memory.shape[0], ptr(out), stream_ptr())
         return out

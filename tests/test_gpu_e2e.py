@@ -1317,3 +1317,34 @@ def test_x4_free_running_divergence_belongs_to_the_precision_policy(full):
         f.write(line + "\n")
     assert n_obj >= 4
     assert float(np.mean(m_gpu)) >= float(np.mean(m_pol)) - 0.1 and ap_gpu >= ap_pol - 0.1 and ap_all_gpu >= ap_all_pol - 0.1, line
+
+
+def test_call_graph_projects_an_adopted_memory():
+    """A captured steady-state call reads the memory's K / V projections from the engine's buffers, and the projection is not part
+    of the capture: a memory that never went through an eager final stage -- adopted from another rank
+    (engine.compute_on_video_sharded), or swapped by a caller -- must be projected before the replay.  After a video that left its
+    graph behind, another memory is adopted and the next batch runs as a replay and, for comparison, kernel by kernel."""
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.utils import synthetic
+    cfg, model = _build(1, (1, 1, 1, 1), "trained_like")
+    model.noise_fn = synthetic.DeviceNoise()
+    ds = SyntheticVIDDataset([40], cfg, height=120, width=200, device="cuda", smooth=True)
+    with torch.no_grad():
+        for idx in range(40):
+            model(ds[idx][0])
+    assert model.graph_replays >= 2
+    g = torch.Generator().manual_seed(3)
+    other = [torch.randn(900, 256, generator=g).cuda(), torch.randn(150, 256, generator=g).cuda()]
+    outs = {}
+    for graphs in (True, False):
+        model.use_call_graph = graphs
+        before = model.graph_replays
+        model.adopt_video_memory([m.clone() for m in other])
+        res = []
+        with torch.no_grad():
+            for idx in range(1, 17):                      # calls 1-7 queue frames, call 8 and call 16 each finish a batch
+                res += model(ds[idx][0])
+        assert len(res) == 16 and (model.graph_replays - before == (2 if graphs else 0))
+        outs[graphs] = [r.to(torch.device("cpu")) for r in res]
+    for a, b in zip(outs[True], outs[False]):
+        assert len(a) == len(b) > 0 and torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
