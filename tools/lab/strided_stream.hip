@@ -1,0 +1,123 @@
+// Does the ADDRESS PATTERN of the long-K 1x1 layers' A operand limit their HBM rate?   (round 5)
+//
+// res4 conv1 (M = 739328 rows x K = 1024 halves -> 256) runs at 4.0 TB/s of algorithmic bytes, its sibling conv3 + residual (contiguous
+// 16-KB tiles) at 5.9, the vendor GEMM on the same shape at conv1's rate.  In igemm2 a 256-row tile's K step reads 256 rows x 64 bytes at a
+// row pitch of 2 KB: every DMA piece is 16 half-lines 2 KB apart, all workgroups walk k together.  This probe streams that exact pattern into
+// an LDS ring with no MFMA, no fragment reads and no stores, next to variants of the pattern:
+//   mode 0  igemm2's: row-major [M][K], BKT = 32 (64 bytes per row and step), every workgroup starts at k = 0
+//   mode 1  the same with the K walk of workgroup g rotated by (5 g) mod nk steps           (would change the summation order)
+//   mode 2  BKT = 64: whole 128-byte lines per row and step
+//   mode 3  a K-tiled layout: [M / 256][K / 32][256 rows][64 bytes] -- every step of a tile is one contiguous 16 KB
+//           (the same addresses as reading a row-major 256 x 2-KB panel front to back: the weight-stationary order)
+// with and without the weight pieces (a 512-KB panel every workgroup re-reads: L2 hits).
+//   hipcc --offload-arch=gfx950 -O3 tools/lab/strided_stream.hip -o tools/lab/strided_stream
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void glds16(const void* g, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+constexpr int BM = 256, K = 1024, ROWB = K * 2;
+
+// 8 waves; a step stages 16 KB of A (+ 16 KB of B); ring of 4 stages, 3 steps in flight
+template <int MODE, bool DO_B>
+__global__ __launch_bounds__(512) void stream_kernel(const char* A, const char* B, int mtiles, unsigned* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-contiguous tile order as in the library: XCD x takes tiles [x T / 8, (x + 1) T / 8)
+    const int per = (mtiles + 7) / 8;
+    const int g0 = (int)blockIdx.x;
+    int g = (g0 & 7) * per + (g0 >> 3);
+    if (g >= mtiles) return;
+    constexpr int STEPB = MODE == 2 ? 128 : 64;              // bytes per row and step
+    constexpr int NK = ROWB / STEPB;
+    constexpr int RPP = 1024 / STEPB;                         // rows per 1-KiB piece
+    constexpr int PIECES = BM * STEPB / 1024 / 8;             // A pieces per wave per step (2, or 4 for BKT 64)
+    constexpr int STAGE = BM * STEPB * (DO_B ? 2 : 1);
+    const char* ap[PIECES];
+    const char* bp[PIECES];
+    const int rot = MODE == 1 ? (g * 5) % NK : 0;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int piece = wave + 8 * i;
+        const int row = RPP * piece + lane / (STEPB / 16);
+        const int ch = lane % (STEPB / 16);
+        if (MODE == 3) ap[i] = A + (long)g * BM * ROWB + piece * 1024 + lane * 16;                 // + kt * 16 KB
+        else ap[i] = A + ((long)g * BM + row) * ROWB + ch * 16;
+        bp[i] = B + (long)row * ROWB + ch * 16;
+    }
+    auto issue = [&](int kt, int stage) {
+        char* s = smem + stage * STAGE;
+        int kk = kt + rot;
+        if (kk >= NK) kk -= NK;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const long off = (MODE == 3) ? (long)kk * 16384 : (long)kk * STEPB;
+            glds16(ap[i] + off, s + (wave + 8 * i) * 1024);
+            if (DO_B) glds16(bp[i] + (long)kk * STEPB, s + BM * STEPB + (wave + 8 * i) * 1024);
+        }
+    };
+    constexpr int P = PIECES * (DO_B ? 2 : 1);
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+    for (int kt = 0; kt < NK; ++kt) {
+        if (kt + 2 < NK) wait_vmcnt<2 * P>(); else if (kt + 1 < NK) wait_vmcnt<P>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < NK) issue(kt + 3, (kt + 3) & 3);
+    }
+    __syncthreads();
+    if (reinterpret_cast<unsigned*>(smem)[threadIdx.x] == 0x12345678u) out[0] = 1;
+}
+
+template <int MODE, bool DO_B>
+void run(const char* name, const char* A, const char* B, int M, unsigned* out) {
+    const int mtiles = M / BM;
+    constexpr int STEPB = MODE == 2 ? 128 : 64;
+    constexpr int smem = 4 * BM * STEPB * (DO_B ? 2 : 1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kernel<MODE, DO_B>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    float best = 1e9, sum = 0;
+    const int grid = ((mtiles + 7) / 8) * 8;
+    for (int it = 0; it < 6; ++it) {
+        (void)hipEventRecord(a);
+        stream_kernel<MODE, DO_B><<<grid, 512, smem>>>(A, B, mtiles, out);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (it) sum += ms;
+        if (ms < best) best = ms;
+    }
+    const double bytes = (double)M * ROWB;
+    printf("%-58s weights %d  M %7d : best %7.1f us  mean %7.1f us  A stream %5.2f TB/s  (LDS %3d KB)\n", name, (int)DO_B, M, best * 1e3, sum / 5 * 1e3,
+           bytes / best / 1e9, smem / 1024);
+}
+
+int main() {
+    unsigned* out;
+    (void)hipMalloc(&out, 4);
+    const int M = 739328;          // 304 frames x 38 x 64
+    char *A, *B;
+    (void)hipMalloc(&A, (long)M * ROWB);
+    (void)hipMalloc(&B, (long)256 * ROWB);
+    (void)hipMemset(A, 1, (long)M * ROWB);
+    (void)hipMemset(B, 1, (long)256 * ROWB);
+    for (int rep = 0; rep < 2; ++rep) {
+        run<0, false>("0 row-major, 64 B per row and step (igemm2)", A, B, M, out);
+        run<1, false>("1 ... K walk rotated per workgroup", A, B, M, out);
+        run<2, false>("2 row-major, 128 B per row and step", A, B, M, out);
+        run<3, false>("3 K-tiled layout, contiguous 16 KB per step", A, B, M, out);
+        run<0, true>("0 row-major, 64 B per row and step (igemm2)", A, B, M, out);
+        run<1, true>("1 ... K walk rotated per workgroup", A, B, M, out);
+        run<2, true>("2 row-major, 128 B per row and step", A, B, M, out);
+        run<3, true>("3 K-tiled layout, contiguous 16 KB per step", A, B, M, out);
+    }
+    return 0;
+}
