@@ -404,7 +404,10 @@ def main():
     shared_tune = None
     if world > 1 and "DVID_IGEMM_TUNE_CACHE" not in os.environ:
         import tempfile
-        shared_tune = os.path.join(tempfile.gettempdir(), "dvid_tune_%s_%s.txt" % (os.environ.get("MASTER_PORT", "0"), os.getuid()))
+        # one file per (library build, launch): the build's md5 keeps a stale file of another build from being trusted, the launcher's
+        # pid (the parent of every local rank) and the rendezvous port keep concurrent runs of one user apart
+        shared_tune = os.path.join(tempfile.gettempdir(), "dvid_tune_%s_%s_%s_%s.txt" % ((LIB_MD5 or "nolib")[:12], os.environ.get("MASTER_PORT", "0"),
+                                                                                          os.getuid(), os.getppid()))
         os.environ["DVID_IGEMM_TUNE_CACHE"] = shared_tune
         os.environ.setdefault("DVID_IGEMM_TUNE", "1")
         if rank == 0 and os.path.exists(shared_tune):
@@ -420,7 +423,9 @@ def main():
             sk.close()
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        comm.init_dist("nccl", force=True)
+        # collectives are bounded: if one rank leaves a side measurement through an exception its peers' pending gather raises after
+        # 15 minutes (and is reported as that side measurement's error) instead of hanging the run
+        comm.init_dist("nccl", force=True, timeout_s=900)
         assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
 
     headline = args.arch == "r101" and args.sample_step == 1

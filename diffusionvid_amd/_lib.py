@@ -36,6 +36,7 @@ SIGNATURES = {
     "dvid_set_chains": (c_int, [c_void_p, c_int]),
     "dvid_set_stem_layout": (c_int, [c_void_p, c_int]),
     "dvid_workspace_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
+    "dvid_workspace_generation": (C.c_ulonglong, []),
     "dvid_backbone_resnet_fpn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvid_backbone_swin_fpn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvid_backbone_resnet_fpn_frames": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

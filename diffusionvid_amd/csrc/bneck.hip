@@ -395,6 +395,7 @@ int bn_launch(const BneckParams& p, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
     if (first_on_device(attr_set)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck64_tail_kernel<SC, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
+        mark_on_device(attr_set);
     }
     static const int lds_env = getenv("DVID_BNECK_LDS") ? atoi(getenv("DVID_BNECK_LDS")) : 0;          // diagnostics: less than the whole LDS (>= kBias + 4096)
     hipLaunchKernelGGL((bneck64_tail_kernel<SC, TN>), dim3(p.ntiles), dim3(512), lds_env >= kBias + 4096 && lds_env <= kBytes ? lds_env : kBytes, s, p);
@@ -717,6 +718,7 @@ int bn128_launch(const Bneck128Params& p, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
     if (first_on_device(attr_set)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck128_tail_kernel<CONV2, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, k8Bytes));
+        mark_on_device(attr_set);
     }
     static const int lds_env = getenv("DVID_BNECK_LDS") ? atoi(getenv("DVID_BNECK_LDS")) : 0;          // diagnostics: less than the whole LDS (>= k8Bias + 3072)
     hipLaunchKernelGGL((bneck128_tail_kernel<CONV2, TAIL>), dim3(p.ntiles), dim3(512), lds_env >= k8Bias + 3072 && lds_env <= k8Bytes ? lds_env : k8Bytes, s, p);

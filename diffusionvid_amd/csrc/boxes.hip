@@ -204,7 +204,9 @@ int dvid_noise_to_boxes_launch(const float* x, float* boxes, int n, float scale,
 int dvid_counter_normal_launch(float* out, long per_image, int n_images, uint64_t key0, hipStream_t s) {
     if (per_image <= 0 || n_images <= 0) return DVID_OK;
     const long quads = (per_image + 3) / 4;
-    hipLaunchKernelGGL(counter_normal_kernel, dim3((unsigned)ceil_div(quads, 256L), (unsigned)n_images), dim3(256), 0, s, out, per_image, n_images, key0);
+    const long nblk = ceil_div(quads, 256L);
+    if (nblk > 0x7fffffffL || n_images > 65535) return DVID_ERR_ARG;          // grid limits: x < 2^31, y < 2^16
+    hipLaunchKernelGGL(counter_normal_kernel, dim3((unsigned)nblk, (unsigned)n_images), dim3(256), 0, s, out, per_image, n_images, key0);
     LAUNCH_CHECK();
     return DVID_OK;
 }

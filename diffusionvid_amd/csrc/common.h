@@ -35,14 +35,18 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of a function ON a device: a process that runs models on
 // several devices (the detector scopes the device per call) has to set it once per device, not once per process.
-// `mask` holds one bit per device ordinal; -> true for the first caller on the current device.
-static inline bool first_on_device(std::atomic<unsigned long long>& mask) {
+// `mask` holds one bit per device ordinal.  first_on_device: the attribute has not been applied on the current device yet (a test
+// only); mark_on_device: it has -- called AFTER hipFuncSetAttribute succeeded, so a second host thread never launches ahead of the
+// attribute (it applies it again, which is harmless) and a failed call is retried by the next launch.
+static inline unsigned long long device_bit() {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    return (mask.load(std::memory_order_relaxed) & bit) == 0 && (mask.fetch_or(bit) & bit) == 0;
+    return 1ull << (dev & 63);
 }
+static inline bool first_on_device(const std::atomic<unsigned long long>& mask) { return (mask.load(std::memory_order_acquire) & device_bit()) == 0; }
+static inline void mark_on_device(std::atomic<unsigned long long>& mask) { mask.fetch_or(device_bit(), std::memory_order_release); }
 
+static inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -403,6 +403,7 @@ int launch_c64(IgemmParams p, hipStream_t s) {
     static std::atomic<unsigned long long> attr_done{0};          // one bit per device: the attribute belongs to (function, device)
     if (first_on_device(attr_done)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C64_BYTES));
+        mark_on_device(attr_done);
     }
     const int tiles_x = ceil_div(p.W, TW);
     p.tiles_m = tiles_x * ceil_div((p.M / (p.H * p.W)) * p.H, TH);
@@ -550,6 +551,7 @@ int launch(IgemmParams p, hipStream_t s) {
     static std::atomic<unsigned long long> attr_done{0};          // one bit per device: the attribute belongs to (function, device)
     if (first_on_device(attr_done)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, C::kBytes));
+        mark_on_device(attr_done);
     }
     const int tiles_x = ceil_div(p.W, TW), tiles_y = ceil_div((p.M / (p.H * p.W)) * p.H, TH);
     p.tiles_m = tiles_x * tiles_y;

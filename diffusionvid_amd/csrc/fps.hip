@@ -207,6 +207,7 @@ int dvid_fps_launch(const float* dist, int n, int m, int bs_emul, int* idx, hipS
     static std::atomic<unsigned long long> attr{0};          // one bit per device: the attribute belongs to (function, device)
     if (first_on_device(attr)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        mark_on_device(attr);
     }
     hipLaunchKernelGGL(fps_kernel, dim3(1), dim3(1024), smem, s, dist, n, m, bs, bits, idx);
     LAUNCH_CHECK();

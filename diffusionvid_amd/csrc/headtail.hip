@@ -383,6 +383,7 @@ int launch(const HeadTailParams& p, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
     if (first_on_device(attr_set) && smem > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_tail_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        mark_on_device(attr_set);
     }
     hipLaunchKernelGGL(head_tail_kernel<MT>, dim3((unsigned)((p.R + BM - 1) / BM)), dim3(512), smem, s, p);
     LAUNCH_CHECK();

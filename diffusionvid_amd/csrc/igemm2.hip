@@ -480,6 +480,7 @@ int launch2k(const IgemmParams& p, hipStream_t s) {
         if (first_on_device(attr_set)) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, BKT, NSTAGE, WN, AK, EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            mark_on_device(attr_set);
         }
     }
     const int nsplit = p.splitk > 1 ? p.splitk : 1;

@@ -147,11 +147,17 @@ struct HostTensor {
     }
 };
 
+// Bumped whenever a workspace buffer moves (DevBuf::ensure re-allocating).  A captured launch sequence holds raw pointers into the
+// workspace: the detector compares this counter with the value it saw at capture time and drops its graphs when it differs
+// (dvid_workspace_generation).
+static std::atomic<unsigned long long> g_workspace_generation{0};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     int ensure(size_t n) {
         if (n <= bytes) return DVID_OK;
+        g_workspace_generation.fetch_add(1, std::memory_order_relaxed);
         if (p) HIP_TRY(hipFree(p));
         p = nullptr;
         bytes = 0;
@@ -942,6 +948,8 @@ int dvid_model_finalize(dvid_model* m) {
     m->finalized = true;
     return DVID_OK;
 }
+
+unsigned long long dvid_workspace_generation(void) { return g_workspace_generation.load(std::memory_order_relaxed); }
 
 int dvid_set_chains(dvid_model* m, int nchain) {
     g_err[0] = 0;

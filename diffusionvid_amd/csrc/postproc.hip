@@ -308,6 +308,7 @@ int dvid_topk_candidates_launch(const float* logits, const float* boxes, int n_i
             if (first_on_device(attr2)) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             150 * 1024));
+                mark_on_device(attr2);
             }
             hipLaunchKernelGGL(topk_select_kernel, dim3(n_img, nsets), dim3(1024), smem2, s, logits, boxes, n_img, m, c, mpad, cand_boxes,
                                cand_scores, cand_labels);
@@ -322,6 +323,7 @@ int dvid_topk_candidates_launch(const float* logits, const float* boxes, int n_i
     if (first_on_device(attr)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_candidates_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        mark_on_device(attr);
     }
     hipLaunchKernelGGL(topk_candidates_kernel, dim3(n_img, nsets), dim3(1024), smem, s, logits, boxes, n_img, m, c, npad, cand_boxes,
                        cand_scores, cand_labels);
@@ -342,6 +344,7 @@ int dvid_nms_frames_launch(const float* cand_boxes, const float* cand_scores, co
     if (first_on_device(attr)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
+        mark_on_device(attr);
     }
     hipLaunchKernelGGL(nms_frame_kernel, dim3(n_img), dim3(1024), smem, s, cand_boxes, cand_scores, cand_labels, n, npad, img_w, img_h,
                        iou, use_nms, out_cap, out_boxes, out_scores, out_labels, out_counts);

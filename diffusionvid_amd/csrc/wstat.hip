@@ -464,6 +464,7 @@ int ws2_launch_k(const IgemmParams& p, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
     if (first_on_device(attr_set)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat2_kernel<K, D, HAS_RES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        mark_on_device(attr_set);
     }
     hipLaunchKernelGGL((wstat2_kernel<K, D, HAS_RES, RELU>), dim3(256), dim3(512), smem, s, p, p.Cout / 256);
     LAUNCH_CHECK();
@@ -484,6 +485,7 @@ int ws_launch_k(const IgemmParams& p, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
     if (first_on_device(attr_set)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat_kernel<K, D, TN, HAS_RES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        mark_on_device(attr_set);
     }
     hipLaunchKernelGGL((wstat_kernel<K, D, TN, HAS_RES, RELU>), dim3(256), dim3(512), smem, s, p, p.Cout / (256 * TN));
     LAUNCH_CHECK();

@@ -195,7 +195,7 @@ class DiffusionDet(nn.Module):
         # hipGraph replay of the steady-state call of the reference's own protocol (one INFER_BATCH batch per call, no look-ahead):
         # see _graphed_call.  DVID_CALL_GRAPH=0 / `use_call_graph = False` launches every call kernel by kernel (A/B, profiling).
         self.use_call_graph = os.environ.get("DVID_CALL_GRAPH", "1") != "0"
-        self._graphs, self._graph_seen = {}, {}
+        self._graphs, self._graph_seen, self._graph_generation = {}, {}, -1
         self.graph_replays = 0
         self.host_wait_s = 0.0      # seconds this process spent blocked in the per-batch device->host result copy
         self.video_index = 0
@@ -513,8 +513,15 @@ class DiffusionDet(nn.Module):
         dropped with its engine (load_state_dict).  Returns None when this call ran (or must run) the ordinary way."""
         frames = [im.tensors for im in ref_l]
         mem = self.head.proposal_feats_global
+        # A captured launch holds raw addresses inside the engine's workspace, and the workspace moves when it grows (a video of a larger
+        # frame size, a memory with more rows): every graph captured before such a move is dropped, never replayed into freed memory.
+        gen = ops.workspace_generation()
+        if gen != self._graph_generation:
+            self._graphs, self._graph_seen, self._graph_generation = {}, {}, gen
+        # ... and it bakes in every switch the eager path reads per call
         key = (tuple(frames[0].shape), len(frames), self.sampling_timesteps, int(mem[0].shape[0]), int(mem[1].shape[0]) if mem[1] is not None else 0,
-               id(self._engine), (float(w), float(h)))
+               id(self._engine), (float(w), float(h)), bool(self.skip_unobservable), bool(self.use_nms), self._engine.chains,
+               os.environ.get("DVID_HEAD_CHAINS", ""))
         M = self.num_proposals
         g = self._graphs.get(key)
         if g is None:
@@ -541,6 +548,10 @@ class DiffusionDet(nn.Module):
         g["graph"].replay()
         self.graph_replays += 1
         self.local_img_queue = []
+        # the local queue as the eager path leaves it (diffusion_det.py:491-506): this call's frames, whose extraction results are the
+        # graph's static buffers -- an eager call that follows never reads an older call's entries
+        for i in range(batch):
+            self.queue.append((g["local"], i))
         out = g["out"]
         if not self.results_on_host:
             # the BoxLists would be views of the graph's static output buffer, which the next replay overwrites: hand out copies
@@ -559,6 +570,7 @@ class DiffusionDet(nn.Module):
 
         def body():
             local, _, _ = self._extract(0, static_l, [], {}, whwh, box_init=[static["box_init"]])
+            static["local"] = local
             feats_cur, cached = local["feats"], (local["logits"], local["boxes"], local["obj"])
             return self._final_stage_launch(feats_cur, cached, whwh, w, h, pairs, [(0, batch)], {0: static["draws"]} if static["draws"] is not None else {}, slots=batch)
 
@@ -587,6 +599,9 @@ class DiffusionDet(nn.Module):
         finally:
             self.after_first_launch = hook
         static["graph"], static["out"] = graph, out
+        if ops.workspace_generation() != self._graph_generation:          # the capture's own warm-up run may have grown the workspace:
+            self._graphs, self._graph_seen = {}, {}                        # older graphs go; this one was captured after the move
+            self._graph_generation = ops.workspace_generation()
         self._graphs[key] = static
         return static
 

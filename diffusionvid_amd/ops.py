@@ -265,6 +265,12 @@ def update_erase_memory(feats_new, feats_mem, target_size):
     return gather_rows(merged, idx), idx
 
 
+def workspace_generation():
+    """re-allocations of workspace buffers in this process so far (include/dvid_hip.h: dvid_workspace_generation); a captured launch
+    sequence is valid only while this stays what it was at capture time"""
+    return int(_lib.load().dvid_workspace_generation())
+
+
 class Model:
     """Owns a dvid_model handle: repacked weights + activation workspace on the current device."""
 
@@ -296,11 +302,13 @@ class Model:
             _lib.check(lib.dvid_model_set_tensor(h, name.encode(), t.data_ptr(), shape, t.dim()), f"set_tensor({name})")
         _lib.check(lib.dvid_model_finalize(h), "dvid_model_finalize")
         self._ws = None
+        self.chains = -1                 # the library's default until set_chains
         self._kv_src = None
 
     def set_chains(self, n):
         """concurrent sub-batch chains inside the library (1 = sequential kernels, for per-kernel profiling)"""
         call("dvid_set_chains", self.handle, int(n))
+        self.chains = int(n)
 
     def set_stem_layout(self, space_to_depth=True):
         """ResNet stem over the 2x2 space-to-depth image (default) or the NHWC8 image; see dvid_set_stem_layout"""

@@ -16,19 +16,29 @@ def _carry_fields(src, dst, apply):
     return dst
 
 
+_MODES = ("xyxy", "xywh")
+
+
+def _same_kind(src, boxes):
+    """a BoxList of `src`'s image size and mode around other box rows"""
+    return BoxList(boxes, src.size, src.mode)
+
+
 class BoxList(object):
     def __init__(self, bbox, image_size, mode="xyxy"):
-        device = bbox.device if isinstance(bbox, torch.Tensor) else torch.device("cpu")
-        bbox = torch.as_tensor(bbox, dtype=torch.float32, device=device)
-        if bbox.ndimension() != 2:
-            raise ValueError("bbox should have 2 dimensions, got {}".format(bbox.ndimension()))
-        if bbox.size(-1) != 4:
-            raise ValueError("last dimension of bbox should have a size of 4, got {}".format(bbox.size(-1)))
-        if mode not in ("xyxy", "xywh"):
-            raise ValueError("mode should be 'xyxy' or 'xywh'")
-        self.bbox = bbox
-        self.size = image_size  # (image_width, image_height)
-        self.mode = mode
+        # same contract and messages as the reference's constructor (bounding_box.py:20-37): fp32 [n, 4] rows on the device they came from
+        on = bbox.device if torch.is_tensor(bbox) else torch.device("cpu")
+        rows = torch.as_tensor(bbox, dtype=torch.float32, device=on)
+        problem = None
+        if rows.dim() != 2:
+            problem = "bbox should have 2 dimensions, got {}".format(rows.dim())
+        elif rows.shape[-1] != 4:
+            problem = "last dimension of bbox should have a size of 4, got {}".format(rows.shape[-1])
+        elif mode not in _MODES:
+            problem = "mode should be 'xyxy' or 'xywh'"
+        if problem:
+            raise ValueError(problem)
+        self.bbox, self.size, self.mode = rows, image_size, mode          # size = (image_width, image_height)
         self.extra_fields = {}
 
     def add_field(self, field, field_data):
@@ -54,7 +64,7 @@ class BoxList(object):
         return x1, y1, x1 + (a - 1).clamp(min=0), y1 + (b - 1).clamp(min=0)
 
     def convert(self, mode):
-        if mode not in ("xyxy", "xywh"):
+        if mode not in _MODES:
             raise ValueError("mode should be 'xyxy' or 'xywh'")
         if mode == self.mode:
             return self
@@ -109,42 +119,40 @@ class BoxList(object):
         return b[:, 2] * b[:, 3]
 
     def copy_with_fields(self, fields, skip_missing=False):
-        out = BoxList(self.bbox, self.size, self.mode)
-        for name in (fields if isinstance(fields, (list, tuple)) else [fields]):
-            if self.has_field(name):
-                out.add_field(name, self.get_field(name))
-            elif not skip_missing:
-                raise KeyError("Field '{}' not found in {}".format(name, self))
+        wanted = fields if isinstance(fields, (list, tuple)) else [fields]
+        missing = [f for f in wanted if f not in self.extra_fields]
+        if missing and not skip_missing:
+            raise KeyError("Field '{}' not found in {}".format(missing[0], self))
+        out = _same_kind(self, self.bbox)
+        out.extra_fields.update({f: self.extra_fields[f] for f in wanted if f in self.extra_fields})
+        return out
+
+    def _mapped(self, boxes, pick):
+        out = _same_kind(self, boxes)
+        out.extra_fields.update({name: pick(value) for name, value in self.extra_fields.items()})
         return out
 
     def to(self, device):
-        bbox = BoxList(self.bbox.to(device), self.size, self.mode)
-        for k, v in self.extra_fields.items():
-            if hasattr(v, "to"):
-                v = v.to(device)
-            bbox.add_field(k, v)
-        return bbox
+        """boxes and every field that can move (bounding_box.py:197-204)"""
+        return self._mapped(self.bbox.to(device), lambda v: v.to(device) if hasattr(v, "to") else v)
 
     def __getitem__(self, item):
-        bbox = BoxList(self.bbox[item], self.size, self.mode)
-        for k, v in self.extra_fields.items():
-            bbox.add_field(k, v[item])
-        return bbox
+        """row selection, applied to every field alike (bounding_box.py:206-210)"""
+        return self._mapped(self.bbox[item], lambda v: v[item])
 
     def __len__(self):
-        return self.bbox.shape[0]
+        return int(self.bbox.shape[0])
 
     def clip_to_image(self, remove_empty=True):
-        TO_REMOVE = 1
-        self.bbox[:, 0].clamp_(min=0, max=self.size[0] - TO_REMOVE)
-        self.bbox[:, 1].clamp_(min=0, max=self.size[1] - TO_REMOVE)
-        self.bbox[:, 2].clamp_(min=0, max=self.size[0] - TO_REMOVE)
-        self.bbox[:, 3].clamp_(min=0, max=self.size[1] - TO_REMOVE)
-        if remove_empty:
-            box = self.bbox
-            keep = (box[:, 3] > box[:, 1]) & (box[:, 2] > box[:, 0])
-            return self[keep]
-        return self
+        """in place: corners into [0, width - 1] x [0, height - 1] (pixel-counting convention, bounding_box.py:215-225); with
+        `remove_empty` the boxes that keep a positive width and height are returned"""
+        limit = (self.size[0] - 1, self.size[1] - 1)
+        for col in range(4):
+            self.bbox[:, col].clamp_(min=0, max=limit[col & 1])
+        if not remove_empty:
+            return self
+        b = self.bbox
+        return self[(b[:, 2] > b[:, 0]) & (b[:, 3] > b[:, 1])]
 
     def __repr__(self):
         return "BoxList(num_boxes={}, image_width={}, image_height={}, mode={})".format(

@@ -23,9 +23,11 @@ def synchronize():
         dist.barrier()
 
 
-def init_dist(backend=None, force=False):
+def init_dist(backend=None, force=False, timeout_s=None):
     """env:// rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK.  A single process normally needs no
-    group; force=True builds a one-rank group anyway (the RCCL path exercised on one GPU: tests, bench.py --force-dist)."""
+    group; force=True builds a one-rank group anyway (the RCCL path exercised on one GPU: tests, bench.py --force-dist).
+    timeout_s bounds every collective: a rank that died (or left a side measurement through an exception) makes its peers' pending
+    collective raise after that long instead of waiting for ever."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if (world <= 1 and not force) or dist.is_initialized():
         return
@@ -33,7 +35,11 @@ def init_dist(backend=None, force=False):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group(backend=backend, init_method="env://")
+    kw = {}
+    if timeout_s:
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+    dist.init_process_group(backend=backend, init_method="env://", **kw)
 
 
 def _parse_cpulist(text):

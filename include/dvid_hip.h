@@ -83,6 +83,11 @@ int dvid_model_finalize(dvid_model* m);
 /* (re)allocate the activation workspace for batches of up to max_frames frames of height x width
  * (multiples of 32) and boxes_per_frame boxes. */
 int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width, int boxes_per_frame);
+/* Counts the re-allocations of workspace buffers in this process (any model: dvid_workspace_reserve growing the arena,
+ * dvid_global_memory_project / dvid_global_xattn growing the memory's projection buffers).  A caller that captured launches into a
+ * hipGraph holds addresses inside the workspace; when the counter differs from its value at capture time the graph must be dropped.
+ * (The reference has no counterpart: its workspace is torch's caching allocator, mega_core/modeling/detector/diffusion_det.py:418-476.) */
+unsigned long long dvid_workspace_generation(void);
 
 /* Number of concurrent sub-batch chains (separate HIP streams inside the library, joined back to the caller's
  * stream before returning) used by the backbone and the heads; 1 = strictly sequential kernels (profiling). */

@@ -15,6 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+OUT = os.environ.get("DVID_GOLDEN_OUT", HERE)          # tests/test_golden_regeneration.py regenerates into a scratch directory
 import _ref_shims as S  # noqa: E402
 
 S.install()
@@ -36,7 +37,7 @@ def save(name, **arrs):
         if isinstance(v, torch.Tensor):
             v = v.detach().cpu().numpy()
         out[k] = v
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items() if not k.startswith("sd.")})
 
 
@@ -410,6 +411,11 @@ def g14_vid_dataset_protocol():
     os.makedirs(os.path.join(root, "cache"))
     pickle.dump(annos, open(os.path.join(root, "cache", "VID_val_videos_anno.pkl"), "wb"))
     arrs = {"lens": np.array(lens), "index_lines": np.array(lines)}
+    # the dataset class reads the reference's GLOBAL config node: what this generator sets on it is put back before it returns, so that
+    # a later generator (g17 dumps the merged configs) sees the reference's defaults whatever the call order is
+    M = RC.MODEL.VID.MEGA
+    saved = (M.MAX_OFFSET, M.MIN_OFFSET, M.ALL_FRAME_INTERVAL, M.KEY_FRAME_LOCATION, M.GLOBAL.ENABLE, M.GLOBAL.SIZE, M.GLOBAL.SHUFFLE,
+             M.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST, M.SHUFFLED_CUR_TEST, RC.INPUT.INFER_BATCH)
     for tag, stop in (("shipped", True), ("streaming", False)):
         M = RC.MODEL.VID.MEGA
         M.MAX_OFFSET, M.MIN_OFFSET, M.ALL_FRAME_INTERVAL, M.KEY_FRAME_LOCATION = (7, -0, 8, 0) if stop else (0, 0, 1, 0)
@@ -436,6 +442,8 @@ def g14_vid_dataset_protocol():
     rs = T.Resize(600, 1000)
     sizes = [(1280, 720), (720, 1280), (640, 480), (500, 375), (1000, 600), (600, 1000), (1920, 1080), (320, 240), (1001, 599),
              (2000, 500), (600, 600), (333, 500), (176, 144), (1280, 960), (853, 480)]
+    (M.MAX_OFFSET, M.MIN_OFFSET, M.ALL_FRAME_INTERVAL, M.KEY_FRAME_LOCATION, M.GLOBAL.ENABLE, M.GLOBAL.SIZE, M.GLOBAL.SHUFFLE,
+     M.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST, M.SHUFFLED_CUR_TEST, RC.INPUT.INFER_BATCH) = saved
     arrs["resize.wh"] = np.array(sizes, dtype=np.int64)
     arrs["resize.out_hw"] = np.array([rs.get_size(wh) for wh in sizes], dtype=np.int64)
     save("g14_vid_dataset_protocol", **arrs)
@@ -608,7 +616,7 @@ def g17_boundary_types():
     arrs["vid.nframes"] = np.array(len(ds))
     arrs["vid.ap"], arrs["vid.map"] = res[0]["ap"], np.array(res[0]["map"])
     arrs["vid.result_txt"] = np.array(open(os.path.join(out, "result.txt")).read())
-    torch.save(preds[:3], os.path.join(HERE, "g17_predictions_ref.pth"))
+    torch.save(preds[:3], os.path.join(OUT, "g17_predictions_ref.pth"))
     # -- the reference's own config node for the two shipped model files: defaults.py merged with BASE_RCNN_1gpu.yaml and the
     #    model yaml exactly as tools/test_net.py:76-82 does, flattened to {dotted key: value}
     import json

@@ -1258,6 +1258,42 @@ def test_call_graph_replay_is_bit_identical(arch, sample_step, noise):
             torch.equal(a.get_field("labels"), b.get_field("labels")), f"frame {f} differs between graph replay and kernel-by-kernel launches"
 
 
+def test_call_graph_dropped_when_the_workspace_moves():
+    """A captured call holds raw addresses inside the engine's workspace, and the workspace is re-allocated when it grows (a VID-val
+    run mixes 4:3 and 16:9 videos): small video (captures), larger video (grows the workspace, captures its own shape), small
+    video again -- whose key finds the FIRST graph unless graphs are dropped with the workspace they point into
+    (dvid_workspace_generation).  Graphs on against graphs off, every detection bit for bit; the third video must
+    have replayed (a re-captured graph), and the detector must have seen the generation change."""
+    from diffusionvid_amd import ops
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.utils import synthetic
+    sizes = [(250, 380), (330, 500), (250, 380)]
+    outs, replays, gens = {}, {}, {}
+    for graphs in (False, True):
+        cfg, model = _build(1, (1, 1, 2, 1), "trained_like")
+        model.noise_fn = synthetic.DeviceNoise()
+        model.use_call_graph = graphs
+        res, per_video, seen = [], [], set()
+        with torch.no_grad():
+            for v, (hh, ww) in enumerate(sizes):
+                ds = SyntheticVIDDataset([36], cfg, height=hh, width=ww, device="cuda", smooth=True, video_base=v)
+                before = model.graph_replays
+                for idx in range(len(ds)):
+                    res += [r.to(torch.device("cpu")) for r in model(ds[idx][0])]
+                    seen.add(ops.workspace_generation())
+                per_video.append(model.graph_replays - before)
+        outs[graphs], replays[graphs], gens[graphs] = res, per_video, seen
+        del model
+        torch.cuda.empty_cache()
+    assert replays[False] == [0, 0, 0]
+    assert len(gens[True]) >= 2, "the larger video did not move the workspace: the test does not exercise what it is for"
+    assert all(r >= 1 for r in replays[True]), replays          # the third video replays a graph captured AFTER the move
+    for f, (a, b) in enumerate(zip(outs[False], outs[True])):
+        assert len(a) == len(b) and len(a) > 0, f
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores")) and \
+            torch.equal(a.get_field("labels"), b.get_field("labels")), f"frame {f} differs between graph replay and kernel-by-kernel launches"
+
+
 @pytest.mark.parametrize("full", [True])          # (the reduced size shows no divergence at all: 95 objects, matches 0.98-1.00 on every pair; profiles/r04_parity_report_tail.txt)
 def test_x4_free_running_divergence_belongs_to_the_precision_policy(full):
     """x4 with real renewals (trained-like scores): one keep decision that flips at the 0.5 threshold re-draws every later slot of
