@@ -74,6 +74,7 @@ SIGNATURES = {
     "dvid_igemm_set_conv3x3": (c_int, [c_int]),
     "dvid_igemm_set_wstat": (c_int, [c_int]),
     "dvid_igemm_set_bottleneck_fusion": (c_int, [c_int]),
+    "dvid_set_stem_pool": (c_int, [c_int]),
     "dvid_profile_enable": (c_int, [c_int]),
     "dvid_profile_reset": (c_int, []),
     "dvid_profile_dump": (c_int, [C.c_char_p]),

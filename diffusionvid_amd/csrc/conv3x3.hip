@@ -22,6 +22,8 @@
 // one row a slot behind the other, one barrier per slot.  Weights: 4-stage ring of BN x 32 tiles.  Pixels: two halo buffers; the 3
 // pieces per wave of chunk c + 1 go out in the MFMA slots of taps 0, 1, 2 of chunk c.  In-order retirement makes one counted
 // s_waitcnt per read slot enough: B(s + 1) has landed when at most the pieces issued in M(s - 1) are outstanding.
+#include <stdlib.h>
+
 #include "common.h"
 #include "igemm_epilogue.h"
 #include "kernels.h"
@@ -545,6 +547,179 @@ int launch_s2d(IgemmParams p, hipStream_t s) {
     return DVID_OK;
 }
 
+// ---- the stem and its max pool as one launch ------------------------------------------------------------------------------------------
+// The stem writes 64 channels at HALF resolution (304 x 512 pixels per 608 x 1024 frame: 19.9 MB, the largest activation of the net) only
+// for the 3x3 / stride-2 max pool to read it back and keep a quarter: 6.5 GB out + 6.5 GB in per 304-frame video, against 1.6 GB for the
+// space-to-depth image going in and 1.6 GB for the pooled map going out.  Here a workgroup owns an 8 x 16 patch of POOLED pixels of one
+// image: it computes the 17 x 33 stem pixels under it (conv rows 2 py0 - 1 .. 2 py0 + 15, columns 2 px0 - 1 .. 2 px0 + 31: the pool's
+// one-pixel halo is recomputed, +12.5 % MFMA work on a layer that is far from the MFMA roof), rounds them to fp16 exactly as the stem's
+// epilogue does (fp32 sum + bias, round, ReLU), parks them in LDS -- in the bytes the input halo and the weights occupied -- and pools
+// from there.  Same products in the same order (tap by tap, 16 channels per MFMA; a tap outside the image multiplies zeros, which the
+// layer-by-layer kernel skips: the same fp32 value), the same rounding, and max is exact: bit-identical to stem + max pool
+// (tests/test_gpu_kernels.py::test_stem_pool_fusion_bit_identical).  Stem pixels outside the map enter the pool as 0, which is below or
+// equal to every value behind a ReLU.
+// M blocks of 32 stem pixels: block r < 17 = stem row r, columns 0 .. 31 of the patch; block 17 = column 32 of the 17 rows.  6 waves x 3
+// blocks x 64 channels; products transposed (D[n][m]: a lane holds 4 consecutive channels of one pixel -> 8-byte LDS writes).
+constexpr int SP_PW = 16, SP_CC = 2 * SP_PW + 1, SP_HW = 36;          // pooled patch width; stem columns under it (33); input halo pitch
+// PH pooled rows per patch -> 2 PH + 1 stem rows (+ 1 block for column 32) over NW waves of BPW blocks:
+//   PH 8: 18 blocks = 6 waves x 3, 72 KB of LDS (2 workgroups per CU), 12.5 % of the stem pixels computed twice
+//   PH 4: 10 blocks = 5 waves x 2, 46 KB (3 per CU), 25 %
+template <int PH>
+struct StemPool {
+    static constexpr int CR = 2 * PH + 1;                    // stem rows
+    static constexpr int NBLK = CR + 1;
+    static constexpr int BPW = PH == 8 ? 3 : 2;
+    static constexpr int NW = NBLK / BPW;
+    static constexpr int HH = CR + 3;                        // input halo rows
+    static constexpr int A_PIECES = (HH * SP_HW + 31) / 32;  // 32 pixels of 32 bytes per 1-KiB piece
+    static constexpr int A_IT = (A_PIECES + NW - 1) / NW, B_IT = (32 + NW - 1) / NW;
+    static constexpr int A = A_IT * NW * 1024;
+    static constexpr int C = CR * SP_CC * 128;               // fp16 stem pixels, 64 channels each
+    static constexpr int kBytes = C > A + S2D_B ? C : A + S2D_B;
+    static_assert(NW * BPW == NBLK, "blocks divide over the waves");
+};
+
+template <int PH>
+__global__ __launch_bounds__(StemPool<PH>::NW * 64) void stem_pool_kernel(IgemmParams p, int tiles_x, int tiles_y, int hp, int wp) {
+    using C = StemPool<PH>;
+    constexpr int CR = C::CR, BPW = C::BPW, NW = C::NW, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per_img = tiles_x * tiles_y;
+    const int lid = igemm_xcd_remap((int)blockIdx.x, p.tiles_m);
+    const int img = lid / per_img, t = lid - img * per_img;
+    const int py0 = (t / tiles_x) * PH, px0 = (t % tiles_x) * SP_PW;
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;          // stem pixel of patch position (0, 0)
+    const char* zero = reinterpret_cast<const char*>(g_zero16);
+    char* const a_lds = smem;
+    char* const b_lds = smem + C::A;
+    const half_t* const in_img = p.in + (long)img * p.H * p.W * 16;
+
+    // ---- prologue DMA: input halo (origin = stem pixel (0, 0) - 2), all 16 taps' weights
+#pragma unroll
+    for (int i = 0; i < C::A_IT; ++i) {
+        const int q = wave + NW * i;
+        const int pidx = 32 * q + (lane >> 1);
+        const int hy = pidx / SP_HW, hx = pidx - hy * SP_HW;
+        const int gy = cy0 - 2 + hy, gx = cx0 - 2 + hx;
+        const bool ok = pidx < C::HH * SP_HW && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const int half = (lane & 1) ^ ((hx >> 3) & 1);
+        glds16(ok ? reinterpret_cast<const char*>(in_img + ((long)gy * p.W + gx) * 16 + half * 8) : zero, a_lds + q * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < C::B_IT; ++i) {
+        const int q = wave + NW * i;                         // piece: tap q >> 1, output channels 32 (q & 1) ..
+        if (q < 32) {                                       // wave-uniform
+            const int n = 32 * (q & 1) + (lane >> 1);
+            const int half = (lane & 1) ^ ((n >> 3) & 1);
+            glds16(reinterpret_cast<const char*>(p.w + (long)n * p.Kpad + (q >> 1) * 16 + half * 8), b_lds + q * 1024);
+        }
+    }
+
+    // ---- this lane's stem pixel in each of the wave's blocks
+    const int frow = lane & 31, hsel = lane >> 5;
+    int pr[BPW], pc[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int blk = BPW * wave + i;
+        pr[i] = blk < CR ? blk : (frow < CR ? frow : CR - 1);
+        pc[i] = blk < CR ? frow : SP_CC - 1;
+    }
+    const int b_off = frow * S2D_PX + ((hsel ^ ((frow >> 3) & 1)) << 4);
+
+    float16v acc[BPW][2];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    wait_vmcnt<0>();
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+        const int ty = tap >> 2, tx = tap & 3;
+        half8 fb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const half8*>(b_lds + tap * (64 * S2D_PX) + j * 32 * S2D_PX + b_off);
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int hx = pc[i] + tx;
+            const half8 fa = *reinterpret_cast<const half8*>(a_lds + ((pr[i] + ty) * SP_HW + hx) * S2D_PX + ((hsel ^ ((hx >> 3) & 1)) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j], fa, acc[i][j], 0, 0, 0);      // D[channel][pixel]
+        }
+    }
+    __syncthreads();                           // every wave is done with the halo and the weights: their bytes become the stem-pixel image
+
+    // ---- stem epilogue into LDS: + bias, round to fp16, ReLU; pixel (r, c) at (r * 33 + c) * 128, 16-byte slot = channel group ^ key(pixel)
+    char* const c_lds = smem;
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int blk = BPW * wave + i;
+        const bool lane_ok = blk < CR || frow < CR;                                // the last block has CR pixels
+        const int gy = cy0 + pr[i], gx = cx0 + pc[i];
+        const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;      // a stem pixel of the map (else it pools as 0)
+        const int pix = pr[i] * SP_CC + pc[i];
+        const int key = (pix >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int ch = 32 * j + 8 * r4 + 4 * hsel;
+                float4v v = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
+                if (p.bias) v += *reinterpret_cast<const float4v*>(p.bias + ch);
+                half4 hv = __builtin_convertvector(v, half4);
+                hv = __builtin_elementwise_max(hv, half4{0, 0, 0, 0});
+                if (!inside) hv = half4{0, 0, 0, 0};
+                if (lane_ok) *reinterpret_cast<half4*>(c_lds + pix * 128 + (((ch >> 3) ^ key) << 4) + (ch & 4) * 2) = hv;
+            }
+    }
+    __syncthreads();
+
+    // ---- 3x3 / stride-2 max pool out of LDS: item = (pooled pixel, 8-channel group); 8 lanes write one pixel's 128 bytes
+    half_t* const out_img = reinterpret_cast<half_t*>(p.out) + (long)img * hp * wp * 64;
+    for (int it = tid; it < PH * SP_PW * 8; it += NT) {
+        const int g = it & 7, q = it >> 3;
+        const int qy = q / SP_PW, qx = q - qy * SP_PW;
+        half8 best = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int pix = (2 * qy + dy) * SP_CC + 2 * qx + dx;
+                const half8 x = *reinterpret_cast<const half8*>(c_lds + pix * 128 + ((g ^ ((pix >> 1) & 7)) << 4));
+                best = __builtin_elementwise_max(best, x);
+            }
+        const int py = py0 + qy, px = px0 + qx;
+        if (py < hp && px < wp) *reinterpret_cast<half8*>(out_img + ((long)py * wp + px) * 64 + g * 8) = best;
+    }
+}
+
+template <int PH>
+int launch_stem_pool_k(IgemmParams p, hipStream_t s) {
+    using C = StemPool<PH>;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (C::kBytes > 64 * 1024 && first_on_device(attr_done)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<PH>), hipFuncAttributeMaxDynamicSharedMemorySize, C::kBytes));
+        mark_on_device(attr_done);
+    }
+    const int n = p.M / (p.H * p.W);
+    const int hp = (p.H + 2 - 3) / 2 + 1, wp = (p.W + 2 - 3) / 2 + 1;
+    const int tiles_x = (int)ceil_div(wp, SP_PW), tiles_y = (int)ceil_div(hp, PH);
+    p.tiles_m = n * tiles_x * tiles_y;
+    p.tiles_n = 1;
+    hipLaunchKernelGGL(stem_pool_kernel<PH>, dim3(p.tiles_m), dim3(C::NW * 64), C::kBytes, s, p, tiles_x, tiles_y, hp, wp);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+int launch_stem_pool(const IgemmParams& p, hipStream_t s) {
+    static const int ph = getenv("DVID_STEM_POOL_PH") ? atoi(getenv("DVID_STEM_POOL_PH")) : 8;          // both patch heights give the same values
+    return ph == 4 ? launch_stem_pool_k<4>(p, s) : launch_stem_pool_k<8>(p, s);
+}
+
 template <int BN, int WN>
 int launch(IgemmParams p, hipStream_t s) {
     using C = Halo<BN, WN>;
@@ -601,4 +776,12 @@ int dvid_conv3x3_halo_launch(const IgemmParams& p, hipStream_t s) {
     // fewer 256-wide workgroups than half the CUs (8 frames of 608 x 1024 at res4: 76) the narrower tile doubles the workgroups.
     const long patches = (long)ceil_div(p.W, TW) * ceil_div(p.M / p.W, TH);
     return ((p.Cout & 255) == 0 && patches * (p.Cout >> 8) > 128) ? launch<256, 4>(p, s) : launch<128, 2>(p, s);
+}
+
+// The space-to-depth stem (bias + ReLU) and the 3x3 / stride-2 / pad-1 max pool behind it as one launch: `p` = the stem's parameters with
+// `out` = the POOLED map [n][(H + 1) / 2][(W + 1) / 2][64].  Bit-identical to dvid_conv3x3_halo_launch + dvid_maxpool3x3s2_launch.
+bool dvid_stem_pool_supported(const IgemmParams& p) { return s2d_stem_shape(p) && p.relu == 1; }
+int dvid_stem_pool_launch(const IgemmParams& p, hipStream_t s) {
+    if (!dvid_stem_pool_supported(p)) return DVID_ERR_UNSUPPORTED;
+    return launch_stem_pool(p, s);
 }

@@ -23,6 +23,9 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s);  // igemm2.hip: the
 bool dvid_conv3x3_halo_supported(const IgemmParams& p);   // the layer type fits the kernel
 bool dvid_conv3x3_halo_preferred(const IgemmParams& p);   // ... and the shape rule (patch grid waste, patches per CU) picks it
 int dvid_conv3x3_halo_launch(const IgemmParams& p, hipStream_t s);
+// ... the space-to-depth stem + ReLU + 3x3 / stride-2 max pool as one launch (p.out = the pooled map); bit-identical to the two launches
+bool dvid_stem_pool_supported(const IgemmParams& p);
+int dvid_stem_pool_launch(const IgemmParams& p, hipStream_t s);
 
 // wstat.hip: short-K / wide-N 1x1 layers with the weights stationary in registers (bit-identical to igemm2)
 bool dvid_wstat_supported(const IgemmParams& p);

@@ -44,6 +44,9 @@ struct ProfRec {
     hipEvent_t a, b;
     double flop, bytes;
     int M, N, K, taps, stride, res_mode;
+    const char* kind;      // kernel family the launch ran on (dump / bench.py's top_kernels)
+    bool family;           // counts towards the implicit-GEMM family's sums (dvid_profile_read); the other records are the heads' and the
+                           // backbone's non-GEMM kernels, timed for the per-kernel table only
 };
 bool g_prof_on = false;
 std::mutex g_prof_mu;                 // models on different host threads may launch concurrently
@@ -82,6 +85,9 @@ int igemm(const IgemmParams& p, hipStream_t s) {
     r.taps = p.ntaps;
     r.stride = p.stride;
     r.res_mode = p.res_mode;
+    r.family = true;
+    // the kernel the shape rules of dvid_igemm_launch pick (a forced tile configuration / DVID_WSTAT=0 / DVID_CONV3X3_HALO=0 runs are labelled by the rule)
+    r.kind = dvid_wstat_preferred(p) ? (p.res_mode == 1 ? "wstat2" : "wstat") : dvid_conv3x3_halo_preferred(p) ? (p.Cin == 16 ? "conv4x4_s2d" : p.Cout == 64 ? "conv3x3_c64" : "conv3x3_halo") : "igemm2";
     HIP_TRY(hipEventRecord(r.a, s));
     const int rc = dvid_igemm_launch(p, s);
     HIP_TRY(hipEventRecord(r.b, s));
@@ -105,6 +111,8 @@ int bneck_tail(const half_t* t1, const half_t* w2, const float* b2, const half_t
     r.N = 256;
     r.K = kk;
     r.taps = 9;
+    r.family = true;
+    r.kind = "bneck64_tail";
     r.stride = 1;
     r.res_mode = ws ? 4 : 3;                  // CSV marker: 3 = fused block tail, 4 = with the shortcut convolution
     HIP_TRY(hipEventRecord(r.a, s));
@@ -127,10 +135,38 @@ int bneck128_tail(const half_t* t1, const half_t* w2, const float* b2, const hal
     r.N = 512;
     r.K = kk;
     r.taps = w2 ? 9 : 1;
+    r.family = true;
+    r.kind = "bneck128_tail";
     r.stride = 1;
     r.res_mode = 3;
     HIP_TRY(hipEventRecord(r.a, s));
     const int rc = dvid_bneck128_tail_launch(t1, w2, b2, w3, b3, res, w1n, b1n, out, t1n, n, H, W, s);
+    HIP_TRY(hipEventRecord(r.b, s));
+    prof_push(r);
+    return rc;
+}
+
+int g_stem_pool_mode = -1;          // dvid_set_stem_pool: -1 follow DVID_STEM_POOL (default 1), 0 two launches, 1 one launch
+
+// A launch outside the implicit-GEMM family (RoIAlign, DynamicConv, attention, the head tail, max pool) as a record of the per-kernel
+// table: `rows` units, algorithmic FLOP and bytes of the whole launch.  Not part of the family's sums.
+template <typename F>
+int prof_other(const char* kind, long rows, int n, int k, double flop, double bytes, hipStream_t s, F&& launch) {
+    if (!g_prof_on) return launch();
+    ProfRec r;
+    if (prof_take(&r) != DVID_OK) return DVID_ERR_HIP;
+    r.flop = flop;
+    r.bytes = bytes;
+    r.M = (int)rows;
+    r.N = n;
+    r.K = k;
+    r.taps = 0;
+    r.stride = 0;
+    r.res_mode = 0;
+    r.kind = kind;
+    r.family = false;
+    HIP_TRY(hipEventRecord(r.a, s));
+    const int rc = launch();
     HIP_TRY(hipEventRecord(r.b, s));
     prof_push(r);
     return rc;
@@ -548,7 +584,8 @@ bool bneck128_stage(const std::vector<Block>& blocks) {
 }
 
 int conv_run(const ConvW& w, const half_t* in, int n, int h, int wd, void* out, int relu, int out_f32, const void* res,
-             int res_mode, int res_f32, hipStream_t s, int* ho_out = nullptr, int* wo_out = nullptr, int ldc = 0, int splitk = 1) {
+             int res_mode, int res_f32, hipStream_t s, int* ho_out = nullptr, int* wo_out = nullptr, int ldc = 0, int splitk = 1,
+             bool pooled = false) {
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.in = in;
@@ -582,6 +619,12 @@ int conv_run(const ConvW& w, const half_t* in, int n, int h, int wd, void* out, 
     }
     if (ho_out) *ho_out = p.Ho;
     if (wo_out) *wo_out = p.Wo;
+    if (pooled) {          // the space-to-depth stem with its max pool in the same launch: `out` is the pooled map; ho / wo stay the stem's
+        if (!dvid_stem_pool_supported(p)) return DVID_ERR_UNSUPPORTED;
+        // algorithmic bytes: the space-to-depth image in, the pooled map out, the weights
+        return prof_other("stem_pool", p.M, 64, p.Kpad, 2.0 * p.M * 64.0 * p.alg_k, (double)p.M * 32.0 + (double)p.M / 4 * 128.0 + 64.0 * p.Kpad * 2.0, s,
+                          [&] { return dvid_stem_pool_launch(p, s); });
+    }
     return igemm(p, s);
 }
 
@@ -645,20 +688,32 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
         lv.scale[l] = 1.f / (float)(8 << l);
     }
     float* pro32 = f32a;
-    TRY(dvid_roialign_launch(lv, d, boxes, nf, M, roi16, pro_features ? nullptr : pro32, s));
+    {
+        // algorithmic bytes: the three maps of the launch's frames once + one 49 x d tile per box (the 784 taps per box go through L1)
+        double map_px = 0;
+        for (int l = 0; l < 3; ++l) map_px += (double)lv.h[l] * lv.w[l];
+        TRY(prof_other("roialign", R, d, 49, 0.0, (double)nf * map_px * d * 2.0 + (double)R * 49 * d * 2.0, s,
+                       [&] { return dvid_roialign_launch(lv, d, boxes, nf, M, roi16, pro_features ? nullptr : pro32, s); }));
+    }
     const float* pro = pro_features ? pro_features : pro32;
     // --- self attention + norm1 ---
     TRY(dvid_f32_to_f16_launch(pro, h16a, (long)R * d, s));
     TRY(linear_run(hw.in_proj, h16a, R, qkv16, 0, 0, s));          // fp16 q|k|v, MFMA operands
-    TRY(dvid_mha_mfma_launch(qkv16, qkv16 + d, qkv16 + 2 * d, attn16, vt, nf, M, M, m->cfg.nheads, 3 * d, 3 * d, d, (long)M * 3 * d,
-                             (long)M * 3 * d, (long)M * d, s));
+    TRY(prof_other("mha_mfma", R, d, M, 4.0 * R * (double)M * d, (double)R * d * 2.0 * 4.0, s, [&] {
+        return dvid_mha_mfma_launch(qkv16, qkv16 + d, qkv16 + 2 * d, attn16, vt, nf, M, M, m->cfg.nheads, 3 * d, 3 * d, d, (long)M * 3 * d,
+                                    (long)M * 3 * d, (long)M * d, s);
+    }));
     TRY(linear_run(hw.out_proj, attn16, R, f32b, 0, 1, s));
     float* x1 = f32c;
     TRY(dvid_add_layernorm_launch(pro, f32b, hw.norm1.g, hw.norm1.b, x1, h16a, R, d, 0, s));
     // --- DynamicConv ---
     // dynamic_layer writes 64 KB of parameters per box that DynamicConv reads straight back (csrc/dynconv.hip)
     TRY(linear_run(hw.dynamic_layer, h16a, R, params16, 0, 0, s));
-    TRY(dvid_dynconv_launch(roi16, params16, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn16, R, s));
+    {
+        const int dd = m->cfg.dim_dynamic;
+        TRY(prof_other("dynconv", R, d, dd, 2.0 * R * 49.0 * d * dd * 2.0, (double)R * (2.0 * 49 * d * 2.0 + 2.0 * d * dd * 2.0), s,
+                       [&] { return dvid_dynconv_launch(roi16, params16, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn16, R, s); }));
+    }
     // out_layer: K = 49*d = 12544 on only R x d outputs -> split K over 7 workgroups per tile; the partial slabs
     // and the bias are summed inside the norm3 kernel that consumes them.
     const int osplit = ((hw.out_layer.kpad / 64) % 7 == 0) ? 7 : 1;
@@ -721,7 +776,11 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
         q.ww = 1.f;
         q.wh = 1.f;
         q.clamp = logf(100000.f / 16.f);
-        return dvid_head_tail_launch(q, s);
+        {
+            const double dff = m->cfg.dim_feedforward, nt = (double)hw.cls.size() + (double)hw.reg.size() + (is_cond ? 1.0 : 0.0);
+            return prof_other("head_tail", R, d, (int)dff, 2.0 * R * d * (2.0 * dff + nt * d + 64.0),
+                              (double)R * (d * 6.0 + d * 4.0 + m->cfg.num_classes * 4.0 + 32.0), s, [&] { return dvid_head_tail_launch(q, s); });
+        }
     }
     // --- FFN + norm3 ---
     TRY(linear_run(hw.linear1, h16a, R, hid16, 1, 0, s));
@@ -949,6 +1008,12 @@ int dvid_model_finalize(dvid_model* m) {
     return DVID_OK;
 }
 
+int dvid_set_stem_pool(int mode) {
+    if (mode < -1 || mode > 1) return DVID_ERR_ARG;
+    g_stem_pool_mode = mode;
+    return DVID_OK;
+}
+
 unsigned long long dvid_workspace_generation(void) { return g_workspace_generation.load(std::memory_order_relaxed); }
 
 int dvid_set_chains(dvid_model* m, int nchain) {
@@ -1087,16 +1152,24 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
         for (int l = 0; l < 3; ++l) lat[l] = m->lat[l].as<half_t>() + fo * (px4 / (4 << (2 * l))) * 256;
 
         int h = height, w = width;
+        bool pooled = false;
         if (m->use_s2d) {
             // normalise + 2x2 space-to-depth (16 halves per block: the same bytes per frame as half an NHWC8 image), then the stem
             // as a 4x4 / stride-1 convolution on the half-resolution grid
             TRY(dvid_prep_images_s2d_launch(frames + f0, img8, nf, height, width, mean, inv_std, cs));
-            TRY(conv_run(m->stem_s2d, img8, nf, h / 2, w / 2, t1, 1, 0, nullptr, 0, 0, cs, &h, &w));
+            static const int sp_env = getenv("DVID_STEM_POOL") ? atoi(getenv("DVID_STEM_POOL")) : 1;
+            if (g_stem_pool_mode >= 0 ? g_stem_pool_mode : sp_env) {
+                // stem + ReLU + max pool as one launch (csrc/conv3x3.hip: stem_pool_kernel): the half-resolution 64-channel map never exists
+                TRY(conv_run(m->stem_s2d, img8, nf, h / 2, w / 2, bx, 1, 0, nullptr, 0, 0, cs, &h, &w, 0, 1, /*pooled=*/true));
+                pooled = true;
+            } else {
+                TRY(conv_run(m->stem_s2d, img8, nf, h / 2, w / 2, t1, 1, 0, nullptr, 0, 0, cs, &h, &w));
+            }
         } else {
             TRY(dvid_prep_images_launch(frames + f0, img8, nf, height, width, mean, inv_std, cs));
             TRY(conv_run(m->stem, img8, nf, h, w, t1, 1, 0, nullptr, 0, 0, cs, &h, &w));
         }
-        TRY(dvid_maxpool3x3s2_launch(t1, bx, nf, h, w, 64, cs));
+        if (!pooled) TRY(prof_other("maxpool", (long)nf * h * w, 64, 9, 0.0, (double)nf * h * w * 64 * 2.0 * 1.25, cs, [&] { return dvid_maxpool3x3s2_launch(t1, bx, nf, h, w, 64, cs); }));
         h = (h + 2 - 3) / 2 + 1;
         w = (w + 2 - 3) / 2 + 1;
         half_t* cur = bx;  // block input
@@ -1598,7 +1671,8 @@ int dvid_profile_reset(void) {
 int dvid_profile_read_bytes(double* igemm_alg_bytes) {
     g_err[0] = 0;
     double b = 0;
-    for (auto& r : g_prof) b += r.bytes;
+    for (auto& r : g_prof)
+        if (r.family) b += r.bytes;
     if (igemm_alg_bytes) *igemm_alg_bytes = b;
     return DVID_OK;
 }
@@ -1607,6 +1681,7 @@ static int profile_sum(double* ms_out, double* flop_out, double* bytes_out, int6
     double ms = 0, fl = 0, by = 0;
     int64_t n = 0;
     for (auto& r : g_prof) {
+        if (!r.family) continue;
         HIP_TRY(hipEventSynchronize(r.b));
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
@@ -1632,12 +1707,13 @@ int dvid_profile_dump(const char* path) {
     g_err[0] = 0;
     FILE* f = fopen(path, "w");
     if (!f) FAIL(DVID_ERR_ARG, "cannot open %s", path);
-    fprintf(f, "M,N,K,taps,stride,res_mode,ms,tflops\n");
+    fprintf(f, "kernel,family,M,N,K,taps,stride,res_mode,ms,tflops,alg_mbytes,alg_gbs\n");
     for (auto& r : g_prof) {
         HIP_TRY(hipEventSynchronize(r.b));
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
-        fprintf(f, "%d,%d,%d,%d,%d,%d,%.5f,%.2f\n", r.M, r.N, r.K, r.taps, r.stride, r.res_mode, t, r.flop / (t * 1e-3) / 1e12);
+        fprintf(f, "%s,%d,%d,%d,%d,%d,%d,%d,%.5f,%.2f,%.3f,%.1f\n", r.kind, (int)r.family, r.M, r.N, r.K, r.taps, r.stride, r.res_mode, t, r.flop / (t * 1e-3) / 1e12,
+                r.bytes / 1e6, r.bytes / (t * 1e-3) / 1e9);
     }
     fclose(f);
     return DVID_OK;

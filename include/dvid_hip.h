@@ -232,6 +232,11 @@ int dvid_igemm_set_wstat(int mode);
  * -1 = follow DVID_BNECK_FUSE (default 1).  res2: bit-identical to the layer-by-layer launches; res3: to those on igemm2 (see above). */
 int dvid_igemm_set_bottleneck_fusion(int mode);
 
+/* The ResNet stem (7x7 / stride 2 as a 4x4 convolution over the space-to-depth image, + FrozenBN + ReLU) and the 3x3 / stride-2 max pool
+ * behind it (detectron2 BasicStem, reached from mega_core/modeling/detector/diffusion_det.py:427) as ONE launch: 1 = on, 0 = two launches,
+ * -1 = follow DVID_STEM_POOL (default 1).  Bit-identical either way (csrc/conv3x3.hip: stem_pool_kernel). */
+int dvid_set_stem_pool(int mode);
+
 /* When enabled, every igemm launch is bracketed by HIP events on its stream; dvid_profile_read
  * synchronises those events and returns totals since the last reset. */
 int dvid_profile_enable(int on);
@@ -239,7 +244,8 @@ int dvid_profile_reset(void);
 int dvid_profile_read(double* igemm_ms, double* igemm_flop, int64_t* igemm_launches);
 /* sum over the recorded launches of the algorithmic HBM bytes (input + weights + output + residual, each touched once) */
 int dvid_profile_read_bytes(double* igemm_alg_bytes);
-/* CSV (M,N,K,taps,stride,res_mode,ms,tflops), one line per recorded igemm launch */
+/* CSV (kernel,family,M,N,K,taps,stride,res_mode,ms,tflops,alg_mbytes,alg_gbs), one line per recorded launch: the implicit-GEMM family
+ * (family = 1: what dvid_profile_read sums) and the heads' / backbone's other kernels (RoIAlign, DynamicConv, attention, head tail, max pool) */
 int dvid_profile_dump(const char* path);
 
 #ifdef __cplusplus

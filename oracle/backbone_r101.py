@@ -89,4 +89,5 @@ def fpn(feats, sd, pfx="backbone.", in_features=("res3", "res4", "res5")):
 
 def backbone_r101_fpn(images_norm, sd, pfx="backbone.", blocks=R101_BLOCKS):
     """images_norm: normalised NCHW fp32, H and W multiples of 32.  Returns {p3,p4,p5,p6}."""
-    return fpn(resnet_bottom_up(images_norm, sd, pfx + "bottom_up.", blocks), sd, pfx)
+    with precision.stage("backbone"):
+        return fpn(resnet_bottom_up(images_norm, sd, pfx + "bottom_up.", blocks), sd, pfx)

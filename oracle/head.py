@@ -140,10 +140,14 @@ def rcnn_head(sd, pfx, features, bboxes, pro_features, time_emb, cfg, cond=None,
     """
     d = cfg.hidden_dim
     N, nr = bboxes.shape[:2]
+    # stage tags for a scoped precision policy (precision.use(..., only=...)): "head.<module prefix>.<part>"
+    tag = "head." + pfx.split("head.", 1)[-1] + "."
+    stage = precision.stage
     roi = roi_pooler(features, bboxes, cfg.pooler_resolution, cfg.scales, cfg.sampling_ratio)
     if pro_features is None:
         pro_features = roi.view(N, nr, d, -1).mean(-1)          # fp16 policy: mean of the un-rounded bins (csrc/roialign.hip)
-    roi = a16(roi)
+    with stage(tag + "roi"):
+        roi = a16(roi)
     roi_features = roi.view(N * nr, d, -1).permute(2, 0, 1)
     if taps is not None:
         taps["roi"] = roi
@@ -151,18 +155,21 @@ def rcnn_head(sd, pfx, features, bboxes, pro_features, time_emb, cfg, cond=None,
 
     # self_att.
     pro_features = pro_features.view(N, nr, d).permute(1, 0, 2)
-    pro_features2 = _mha(sd, pfx + ".self_attn", pro_features, pro_features, pro_features, cfg.nheads)
+    with stage(tag + "attn"):
+        pro_features2 = _mha(sd, pfx + ".self_attn", pro_features, pro_features, pro_features, cfg.nheads)
     pro_features = _ln(pro_features + pro_features2, sd, pfx + ".norm1")
     # inst_interact.
     pro_features = pro_features.view(nr, N, d).permute(1, 0, 2).reshape(1, N * nr, d)
     if taps is not None:
         taps["after_attn"] = pro_features[0].clone()
-    pro_features2 = dynamic_conv(sd, pfx + ".inst_interact", pro_features, roi_features, cfg)
+    with stage(tag + "dynconv"):
+        pro_features2 = dynamic_conv(sd, pfx + ".inst_interact", pro_features, roi_features, cfg)
     if taps is not None:
         taps["dynconv"] = pro_features2.clone()
     obj_features = _ln(pro_features + pro_features2, sd, pfx + ".norm2")
     # obj_feature.
-    obj_features2 = _lin(a16(F.relu(_lin(a16(obj_features), sd, pfx + ".linear1"))), sd, pfx + ".linear2")
+    with stage(tag + "ffn"):
+        obj_features2 = _lin(a16(F.relu(_lin(a16(obj_features), sd, pfx + ".linear1"))), sd, pfx + ".linear2")
     obj_features = _ln(obj_features + obj_features2, sd, pfx + ".norm3")
 
     fc_feature = obj_features.transpose(0, 1).reshape(N * nr, -1)
@@ -171,21 +178,27 @@ def rcnn_head(sd, pfx, features, bboxes, pro_features, time_emb, cfg, cond=None,
         scale_shift = torch.repeat_interleave(scale_shift, nr, dim=0)
         scale, shift = scale_shift.chunk(2, dim=1)
     else:
-        shift = _lin(a16(F.silu(cond)), sd, pfx + ".c_mlp.1")
+        with stage(tag + "mod"):
+            shift = _lin(a16(F.silu(cond)), sd, pfx + ".c_mlp.1")
         scale = F.linear(F.silu(time_emb), sd[pfx + ".block_time_mlp.1.weight"], sd[pfx + ".block_time_mlp.1.bias"])
         scale = torch.repeat_interleave(scale, nr, dim=0)
-    fc_feature = a16(fc_feature * (scale + 1) + shift)
+    with stage(tag + "mod"):
+        fc_feature = a16(fc_feature * (scale + 1) + shift)
     if taps is not None:
         taps["fc_feature"] = fc_feature.clone()
 
     cls_feature = fc_feature
     reg_feature = fc_feature
-    for i in range(cfg.num_cls):
-        cls_feature = a16(F.relu(_ln(_lin(cls_feature, sd, f"{pfx}.cls_module.{3 * i}", bias=False), sd, f"{pfx}.cls_module.{3 * i + 1}")))
-    for i in range(cfg.num_reg):
-        reg_feature = a16(F.relu(_ln(_lin(reg_feature, sd, f"{pfx}.reg_module.{3 * i}", bias=False), sd, f"{pfx}.reg_module.{3 * i + 1}")))
-    class_logits = _lin(cls_feature, sd, pfx + ".class_logits")
-    bboxes_deltas = _lin(reg_feature, sd, pfx + ".bboxes_delta")
+    with stage(tag + "cls_tower"):
+        for i in range(cfg.num_cls):
+            cls_feature = a16(F.relu(_ln(_lin(cls_feature, sd, f"{pfx}.cls_module.{3 * i}", bias=False), sd, f"{pfx}.cls_module.{3 * i + 1}")))
+    with stage(tag + "reg_tower"):
+        for i in range(cfg.num_reg):
+            reg_feature = a16(F.relu(_ln(_lin(reg_feature, sd, f"{pfx}.reg_module.{3 * i}", bias=False), sd, f"{pfx}.reg_module.{3 * i + 1}")))
+    with stage(tag + "class_logits"):
+        class_logits = _lin(cls_feature, sd, pfx + ".class_logits")
+    with stage(tag + "bboxes_delta"):
+        bboxes_deltas = _lin(reg_feature, sd, pfx + ".bboxes_delta")
     if taps is not None:
         taps["deltas"] = bboxes_deltas.clone()
     pred_bboxes = apply_deltas(bboxes_deltas, bboxes.reshape(-1, 4), cfg)
@@ -227,7 +240,8 @@ def global_attention(sd, pfx, proposal_features, memory, cfg):
     query [R,1,d] against kv = memory[0] [Lk,1,d]; returns cond [R, d]."""
     query_ = proposal_features.permute(1, 0, 2)
     kv = memory[0].unsqueeze(1)
-    attn_ = _mha(sd, pfx + "global_attention.0.0", query_, kv, kv, cfg.nheads)
+    with precision.stage("head.global_attention"):
+        attn_ = _mha(sd, pfx + "global_attention.0.0", query_, kv, kv, cfg.nheads)
     return attn_.reshape(-1, proposal_features.shape[-1])
 
 

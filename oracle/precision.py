@@ -17,30 +17,48 @@ import contextlib
 import torch
 
 _POLICY = "fp32"
+_ONLY = None          # fp16 policy restricted to the stages whose tag starts with one of these prefixes (None: everywhere)
+_STAGE = ""           # tag of the stage the oracle is in (backbone_r101 / head set it: "backbone", "head.<series index>.<part>")
 
 
 def policy():
     return _POLICY
 
 
+def _active():
+    return _POLICY == "fp16" and (_ONLY is None or any(_STAGE.startswith(p) for p in _ONLY))
+
+
 def is_fp16():
-    return _POLICY == "fp16"
+    return _active()
 
 
 @contextlib.contextmanager
-def use(name):
-    global _POLICY
+def use(name, only=None):
+    """`only`: stage-tag prefixes -- the storage policy applies inside those stages and nowhere else (tools/diag_logit_error_stages.py:
+    which stage's fp16 stores account for the path's logit differences)"""
+    global _POLICY, _ONLY
     assert name in ("fp32", "fp16")
-    old, _POLICY = _POLICY, name
+    old, _POLICY, old_only, _ONLY = _POLICY, name, _ONLY, (tuple(only) if only is not None else None)
     try:
         yield
     finally:
-        _POLICY = old
+        _POLICY, _ONLY = old, old_only
+
+
+@contextlib.contextmanager
+def stage(tag):
+    global _STAGE
+    old, _STAGE = _STAGE, tag
+    try:
+        yield
+    finally:
+        _STAGE = old
 
 
 def r16(t):
-    """round to fp16 storage and back (identity under the fp32 policy)"""
-    if _POLICY != "fp16":
+    """round to fp16 storage and back (identity under the fp32 policy, and outside the selected stages)"""
+    if not _active():
         return t
     return t.to(torch.float16).to(torch.float32)
 

@@ -689,6 +689,34 @@ def test_backbone_bottleneck_fusion_bit_identical(dv, size):
     model.close()
 
 
+@pytest.mark.parametrize("size", [(96, 128), (160, 224), (608, 800), (608, 1024)])
+def test_stem_pool_fusion_bit_identical(dv, size):
+    """The ResNet stem + ReLU + 3x3 / stride-2 max pool as one launch (csrc/conv3x3.hip: stem_pool_kernel -- the half-resolution 64-channel
+    map never reaches memory) against the two launches: p3 / p4 / p5 of a shallow backbone bit for bit; 3 frames; pooled maps whose width
+    is not a multiple of the 16-pixel patch (56, 100) and whose height is not a multiple of 8 (20); the bench's frame size."""
+    from diffusionvid_amd import _lib
+    from diffusionvid_amd.utils import synthetic
+    lib = _lib.load()
+    blocks = (1, 1, 1, 1)
+    sd = synthetic.make_state_dict(5, blocks=blocks)
+    g = torch.Generator().manual_seed(size[1])
+    imgs = torch.rand(3, 3, size[0], size[1], generator=g)
+    model = dv.Model(sd, res_blocks=blocks)
+    model.reserve(3, size[0], size[1], 300)
+    try:
+        _lib.check(lib.dvid_set_stem_pool(1), "set_stem_pool")
+        fused = [t.clone() for t in model.backbone(imgs.cuda())]
+        _lib.check(lib.dvid_set_stem_pool(0), "set_stem_pool")
+        plain = [t.clone() for t in model.backbone(imgs.cuda())]
+    finally:
+        lib.dvid_set_stem_pool(-1)
+    torch.cuda.synchronize()
+    for name, a, b in zip(("p3", "p4", "p5"), fused, plain):
+        print("stem + pool in one launch vs two, %s: identical %.6f" % (name, (a == b).float().mean().item()))
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b), name
+    model.close()
+
+
 def test_backbone_swin_small(dv):
     """Swin-Transformer + FPN (same kernels/graph as Swin-B, reduced widths/depths) vs the CPU oracle:
     patch embed, (shifted-)window MFMA attention with padding + relative-position bias + shift mask,
