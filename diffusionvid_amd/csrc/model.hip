@@ -149,9 +149,9 @@ int bneck128_tail(const half_t* t1, const half_t* w2, const float* b2, const hal
 int g_stem_pool_mode = -1;          // dvid_set_stem_pool: -1 follow DVID_STEM_POOL (default 1), 0 two launches, 1 one launch
 
 // A launch outside the implicit-GEMM family (RoIAlign, DynamicConv, attention, the head tail, max pool) as a record of the per-kernel
-// table: `rows` units, algorithmic FLOP and bytes of the whole launch.  Not part of the family's sums.
+// table: `rows` units, algorithmic FLOP and bytes of the whole launch.  Not part of the family's sums unless `family`.
 template <typename F>
-int prof_other(const char* kind, long rows, int n, int k, double flop, double bytes, hipStream_t s, F&& launch) {
+int prof_other(const char* kind, long rows, int n, int k, double flop, double bytes, hipStream_t s, F&& launch, bool family = false) {
     if (!g_prof_on) return launch();
     ProfRec r;
     if (prof_take(&r) != DVID_OK) return DVID_ERR_HIP;
@@ -164,7 +164,7 @@ int prof_other(const char* kind, long rows, int n, int k, double flop, double by
     r.stride = 0;
     r.res_mode = 0;
     r.kind = kind;
-    r.family = false;
+    r.family = family;
     HIP_TRY(hipEventRecord(r.a, s));
     const int rc = launch();
     HIP_TRY(hipEventRecord(r.b, s));
@@ -623,7 +623,7 @@ int conv_run(const ConvW& w, const half_t* in, int n, int h, int wd, void* out, 
         if (!dvid_stem_pool_supported(p)) return DVID_ERR_UNSUPPORTED;
         // algorithmic bytes: the space-to-depth image in, the pooled map out, the weights
         return prof_other("stem_pool", p.M, 64, p.Kpad, 2.0 * p.M * 64.0 * p.alg_k, (double)p.M * 32.0 + (double)p.M / 4 * 128.0 + 64.0 * p.Kpad * 2.0, s,
-                          [&] { return dvid_stem_pool_launch(p, s); });
+                          [&] { return dvid_stem_pool_launch(p, s); }, /*family=*/true);          // an implicit-GEMM launch like the stem it replaces
     }
     return igemm(p, s);
 }

@@ -30,7 +30,7 @@ from oracle import detector as odet  # noqa: E402
 from oracle import memory as omem  # noqa: E402
 
 
-def _weights(model, weights="init"):
+def _weights(model, weights="init", **trained_like):
     """"init": random-init heads with box-delta layers x0.1 (class scores 0.010 +- 0.003); "trained_like": additionally class layers
     with a trained detector's score spread (synthetic.trained_like_scores); "untamed": the raw random-init state dict"""
     from diffusionvid_amd.utils import synthetic
@@ -38,7 +38,7 @@ def _weights(model, weights="init"):
     if weights != "untamed":
         sd = synthetic.tame_box_deltas(sd, 0.1)
     if weights == "trained_like":
-        sd = synthetic.trained_like_scores(sd)
+        sd = synthetic.trained_like_scores(sd, **trained_like)
     model.load_state_dict(sd)
     return model
 
@@ -731,7 +731,10 @@ def test_video_e2e_full_configuration(arch, sample_step, weights):
     else:
         cfg = get_cfg("configs/vid_Swin_B_DiffusionVID.yaml", ["MODEL.DiffusionDet.SAMPLE_STEP", sample_step], "configs/BASE_RCNN_1gpu.yaml")
         cfg.freeze()
-        model = _weights(build_detection_model(cfg), weights).to("cuda").eval()
+        # Swin-B's random-init features give final logits 2 lower than R101's (per-box maximum: median -2.0, 99th percentile -0.24 with the
+        # R101 bias of -6.5: 4 boxes above 0.5 in 4 frames, measured on the CPU oracle); a class bias of -5.25 puts ~50 boxes per frame above the
+        # threshold, so that the AP50-over-objects gate rests on > 100 objects here as well (a uniform logit shift: no ranking changes)
+        model = _weights(build_detection_model(cfg), weights, **({"bias": -5.25} if weights == "trained_like" else {})).to("cuda").eval()
         L = 4
     H0, W0 = 600, 1000
     tag = f"[{arch} x{sample_step} full size, {weights} weights]"
@@ -1383,7 +1386,8 @@ def test_x4_free_running_statistics():
     the memory's size) -- each through the GPU path, the fp32 oracle and the fp16-policy oracle.  Gate, on the means over the videos:
     AP50 of the GPU path over the fp32 oracle's objects (its detections with score >= 0.5) >= that of the policy oracle - 0.02, and
     the mean per-frame match rate >= the policy oracle's - 0.05: the HIP kernels add nothing measurable to what the precision policy costs."""
-    cfg, model = _build(4, None, "trained_like", extra=["MODEL.VID.MEGA.GLOBAL.SIZE", 4])
+    cfg, model = _build(4, None, "trained_like", extra=["MODEL.VID.MEGA.GLOBAL.SIZE", 4, "INPUT.INFER_BATCH", 4, "MODEL.VID.MEGA.MAX_OFFSET", 3,
+                                                         "MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 4])          # batches of 4 on both sides: the draws are keyed by (split, image)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     rows = []
     for v in range(X4_STAT_VIDEOS):

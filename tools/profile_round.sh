@@ -38,9 +38,9 @@ with open(f"{out}/{tag}_kernel_stats_{suf}.txt", "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-fed --no-side-configs  (DVID_CHAINS=1; 5 videos of 304 frames:\n")
     o.write("# set-up, warm-up, timed step, chains=1 pass and instrumented pass)\n")
     o.write("total kernel time %.1f ms\n" % (tot / 1e6))
-    ig = [r for r in rows if "igemm2_kernel" in r["Name"] or "conv3x3_" in r["Name"] or "wstat" in r["Name"] or "bneck" in r["Name"]]
+    ig = [r for r in rows if "igemm2_kernel" in r["Name"] or "conv3x3_" in r["Name"] or "conv4x4_" in r["Name"] or "stem_pool" in r["Name"] or "wstat" in r["Name"] or "bneck" in r["Name"]]
     igt = sum(float(r["TotalDurationNs"]) for r in ig); igc = sum(int(r["Calls"]) for r in ig)
-    o.write("implicit-GEMM kernels (igemm2_kernel, conv3x3_halo_kernel, conv3x3_c64_kernel, wstat_kernel, wstat2_kernel, bneck64_tail_kernel; all instantiations): calls %d total %.2f ms avg %.2f us  %.1f%%\n" % (igc, igt / 1e6, igt / igc / 1e3, 100 * igt / tot))
+    o.write("implicit-GEMM kernels (igemm2_kernel, conv3x3_halo_kernel, conv3x3_c64_kernel, conv4x4_s2d / stem_pool_kernel, wstat_kernel, wstat2_kernel, bneck64 / bneck128_tail_kernel; all instantiations): calls %d total %.2f ms avg %.2f us  %.1f%%\n" % (igc, igt / 1e6, igt / igc / 1e3, 100 * igt / tot))
     for r in rows[:40]:
         o.write("%-100s calls %7s total %9.2f ms avg %9.1f us %5.1f%%\n" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 res = {}
@@ -49,14 +49,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     s = n = 0.0
     for fn in fs:
         for r in csv.DictReader(open(fn)):
-            if ("igemm2_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck" in r["Kernel_Name"]) and r["Counter_Name"] == c:
+            if ("igemm2_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "conv4x4_" in r["Kernel_Name"] or "stem_pool" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck" in r["Kernel_Name"]) and r["Counter_Name"] == c:
                 s += float(r["Counter_Value"]); n += 1
     res[c] = (s, n)
 def per_kernel(c):
     s = n = 0.0
     for fn in glob.glob(f"/tmp/prof_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
-            if ("igemm2_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck" in r["Kernel_Name"]) and r["Counter_Name"] == c:
+            if ("igemm2_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "conv4x4_" in r["Kernel_Name"] or "stem_pool" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck" in r["Kernel_Name"]) and r["Counter_Name"] == c:
                 s += float(r["Counter_Value"]); n += 1
     return s, n
 mb, _ = per_kernel("SQ_VALU_MFMA_BUSY_CYCLES")
@@ -69,7 +69,7 @@ if res["FETCH_SIZE"][1] and res["WRITE_SIZE"][1]:
     fetch = res["FETCH_SIZE"][0] / res["FETCH_SIZE"][1] * 1024 * 2       # KiB units; gfx950 counts 128-B requests at 64 B
     write = res["WRITE_SIZE"][0] / res["WRITE_SIZE"][1] * 1024
     same = json.loads([l for l in open("/tmp/prof_FETCH_SIZE.log") if l.startswith('{"metric"')][-1])["roofline"]
-    json.dump({"kernel": "implicit-GEMM kernels (igemm2_kernel + conv3x3_* + wstat*_kernel + bneck*_tail_kernel; all instantiations)", "launches": int(res["FETCH_SIZE"][1]),
+    json.dump({"kernel": "implicit-GEMM kernels (igemm2_kernel + conv3x3_* + stem_pool_kernel + wstat*_kernel + bneck*_tail_kernel; all instantiations)", "launches": int(res["FETCH_SIZE"][1]),
                "configuration": suf, "library_md5": lib_md5,
                "alg_bytes_per_launch_same_run": same["layerwise_alg_mbytes_per_launch"] * 1e6,
                "mfma_busy_fraction": mfma_busy,
