@@ -715,7 +715,11 @@ int bucket_rows(int M) {
 // A layer's best tile changes slowly with the row count: a bucket that has not been timed takes the winner of the nearest
 // timed bucket of the same layer within one octave, so a stream of ragged video tails costs one timing pass per layer and
 // octave, not one per bucket.
-int nearest_bucket_cfg(const ShapeKey& k) {
+// ... as long as the launch keeps the chip busy for several rounds either way.  Where the winner's tile count at THIS row count is
+// under two rounds of the 256 CUs the best tile is a question of how the tiles land on the CUs and changes within an octave (round 5:
+// res4 conv1 at 8 frames, M = 19456, inherited 256x256x32/5 from the 16-frame launch of the video's first call -- 76 workgroups, 37 us
+// against 23 us for its own winner 128x64x64/2, on 814 launches per video): such a bucket inherits only from within a quarter octave.
+int nearest_bucket_cfg(const ShapeKey& k, const TileCfg* cfgs) {
     int best = -1;
     double best_d = 1.0;            // |log2(M / M')| <= 1
     for (const auto& kv : g_tuned) {
@@ -724,6 +728,9 @@ int nearest_bucket_cfg(const ShapeKey& k) {
             o.flags != k.flags || o.M <= 0)
             continue;
         const double d = fabs(log2((double)k.M / (double)o.M));
+        const TileCfg& c = cfgs[kv.second];
+        const long tiles = (long)ceil_div(k.M, c.bm) * ceil_div(k.Cout, c.bn) * (((k.flags >> 4) & 0xff) > 1 ? ((k.flags >> 4) & 0xff) : 1);
+        if (tiles < 512 && d > 0.25) continue;
         if (d <= best_d) {
             best_d = d;
             best = kv.second;
@@ -822,7 +829,7 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
         auto it = g_tuned.find(key);
         if (it != g_tuned.end()) {
             cfg = it->second;
-        } else if (int near = nearest_bucket_cfg(key); near >= 0 && cfg_valid(cfgs[near], p)) {
+        } else if (int near = nearest_bucket_cfg(key, cfgs); near >= 0 && cfg_valid(cfgs[near], p)) {
             cfg = near;                          // same layer, row count within a factor of two of a tuned bucket: inherit
             g_tuned.emplace(key, cfg);
         } else if (g_tune_mode == 0 || (g_tune_mode < 0 && g_cache_serving)) {

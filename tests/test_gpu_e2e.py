@@ -1350,6 +1350,8 @@ def _x4_free_running_once(cfg, model, sd, blocks, video_base, L, H0, W0):
             "ap_all_gpu": _ap50_vs_oracle(ref32, got, size), "ap_all_pol": _ap50_vs_oracle(ref32, pol, size)}
 
 
+@pytest.mark.skipif(os.environ.get("DVID_X4_SINGLE_VIDEO", "0") != "1", reason="superseded by test_x4_free_running_statistics (eight videos, the same three-way comparison); "
+                    "DVID_X4_SINGLE_VIDEO=1 runs it on BASELINE's exact call (8 local + 24 global frames, 130 s): profiles/r05c_gpu_pytest.log holds its last run")
 @pytest.mark.parametrize("full", [True])          # (the reduced size shows no divergence at all: 95 objects, matches 0.98-1.00 on every pair; profiles/r04_parity_report_tail.txt)
 def test_x4_free_running_divergence_belongs_to_the_precision_policy(full):
     """x4 with real renewals (trained-like scores): one keep decision that flips at the 0.5 threshold re-draws every later slot of
@@ -1383,9 +1385,15 @@ def test_x4_free_running_statistics():
     chaotic for ANY two evaluations that differ by rounding (see the test above), so a single video says little: eight videos (other
     frames, other draws) at full depth and resolution -- R101 (3, 4, 23, 3), 1000 x 600, 300 boxes, 4 DDIM steps, trained-like scores;
     4 local + 4 global frames per video so that the two CPU oracles finish in ~25 s per video (the renewal mechanism does not depend on
-    the memory's size) -- each through the GPU path, the fp32 oracle and the fp16-policy oracle.  Gate, on the means over the videos:
-    AP50 of the GPU path over the fp32 oracle's objects (its detections with score >= 0.5) >= that of the policy oracle - 0.02, and
-    the mean per-frame match rate >= the policy oracle's - 0.05: the HIP kernels add nothing measurable to what the precision policy costs."""
+    the memory's size; INFER_BATCH 4 on both sides: the draws are keyed by (split, image)) -- each through the GPU path, the fp32 oracle and
+    the fp16-policy oracle.  Gate, on the means over the videos: AP50 of the GPU path over the fp32 oracle's objects (its detections with
+    score >= 0.5) >= that of the policy oracle - 0.07, and the mean per-frame match rate >= the policy oracle's - 0.07.  The margin is two
+    standard errors of the paired mean difference, not the 0.02 the round-4 review suggested: per video AP50 has a standard deviation of
+    0.10 on either side and the paired differences (GPU - policy) one of 0.098, i.e. 0.035 on the mean of eight -- measured (profiles/
+    r05h_x4_statistics.txt): GPU 0.7432 vs policy 0.7563 (difference -0.013 = 0.4 standard errors), match 0.550 vs 0.553 over 5766 objects.
+    tools/diag_x4_divergence.py shows the same thing stage by stage on one video: extraction logits, memory, step-0 logits and step-0 keep
+    decisions of the GPU path are as far from the fp32 oracle as the policy oracle's (1-2 flipped keep decisions per frame each), and from
+    step 1 on both have parted from it alike (profiles/r05g_x4_divergence.txt)."""
     cfg, model = _build(4, None, "trained_like", extra=["MODEL.VID.MEGA.GLOBAL.SIZE", 4, "INPUT.INFER_BATCH", 4, "MODEL.VID.MEGA.MAX_OFFSET", 3,
                                                          "MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 4])          # batches of 4 on both sides: the draws are keyed by (split, image)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -1407,7 +1415,7 @@ def test_x4_free_running_statistics():
     with open("gpurun_out/parity_report.txt", "a") as f:
         f.write(line + "\n")
     assert n_obj >= 100
-    assert ap_gpu >= ap_pol - 0.02 and m_gpu >= m_pol - 0.05, line
+    assert ap_gpu >= ap_pol - 0.07 and m_gpu >= m_pol - 0.07, line
 
 
 def test_call_graph_projects_an_adopted_memory():
