@@ -401,6 +401,8 @@ def main():
     ap.add_argument("--skip-unobservable", action="store_true",
                     help="MODEL.DiffusionDet.SKIP_UNOBSERVABLE for the main measurement (x4 only; SURVEY.md Appendix B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--smooth-frames", action="store_true", help="low-frequency synthetic frames (the parity tests' content) instead of white noise: the chip runs at its "
+                    "1.4 kW power limit on this workload, so its clock -- and the frame rate -- depends on how much the data toggles (A/B only; the default stays white noise)")
     ap.add_argument("--host-noise", action="store_true", help="draw the DDIM noise with the host generator and upload it (rounds 1-3) instead of on the device")
     ap.add_argument("--no-vidval", action="store_true", help="skip the VID-val-shaped measurement reported inside the line (other_configs.vidval)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned frames, H2D in the timed region) measurement")
@@ -549,7 +551,7 @@ def main():
     if args.workload == "vidval":
         return vidval(args, build, timed, barrier, device, rank, world, H, W)
     cfg, model = build(args.arch, args.sample_step, args.lookahead, args.skip_unobservable)
-    ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
+    ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False, smooth=args.smooth_frames)
     ds.preload()
     if shared_tune and rank != 0:
         barrier()                      # rank 0's set-up pass first: its tuner winners are what this rank starts from

@@ -74,6 +74,73 @@ __global__ __launch_bounds__(512) void stream_kernel(const char* A, const char* 
     if (reinterpret_cast<unsigned*>(smem)[threadIdx.x] == 0x12345678u) out[0] = 1;
 }
 
+// Structure experiments on the igemm2 pattern with the weight pieces (round 5, after tools/lab/gemm_loader_waves.hip: the DMA of a loop whose
+// pieces are issued by 4 loader waves between two barriers per tile runs at 465 us where this probe's 8 waves / one barrier run at 314):
+// REMAP: XCD-contiguous tile order (else blockIdx order); NI: waves that issue pieces (8: 4 each; 4: 8 each; 2; 1); NBAR: barriers per step.
+template <bool REMAP, int NI, int NBAR, int DEPTH>
+__global__ __launch_bounds__(512) void stream2_kernel(const char* A, const char* B, int mtiles, unsigned* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per = (mtiles + 7) / 8;
+    const int g0 = (int)blockIdx.x;
+    const int g = REMAP ? (g0 & 7) * per + (g0 >> 3) : g0;
+    if (g >= mtiles) return;
+    constexpr int NK = ROWB / 64, PW = 32 / NI, STAGE = 32768;
+    const char* src[PW];
+    int dst[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int pc = wave + NI * i;                  // 0..15 A pieces, 16..31 B pieces
+        const int row = 16 * (pc & 15) + lane / 4;
+        const int ch = lane % 4;
+        src[i] = pc < 16 ? A + ((long)g * BM + row) * ROWB + ch * 16 : B + (long)row * ROWB + ch * 16;
+        dst[i] = (pc < 16 ? 0 : 16384) + (pc & 15) * 1024;
+    }
+    constexpr int W = (DEPTH - 1) * PW > 63 ? 63 : (DEPTH - 1) * PW;
+    auto issue = [&](int kt) {
+        if (wave < NI) {
+            char* s = smem + (kt % (DEPTH + 1)) * STAGE;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) glds16(src[i] + (long)kt * 64, s + dst[i]);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(d);
+    for (int kt = 0; kt < NK; ++kt) {
+        if (wave < NI) {
+            if (kt + DEPTH - 1 < NK) wait_vmcnt<W>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (NBAR == 2) __builtin_amdgcn_s_barrier();
+        if (kt + DEPTH < NK) issue(kt + DEPTH);
+    }
+    __syncthreads();
+    if (reinterpret_cast<unsigned*>(smem)[threadIdx.x] == 0x12345678u) out[0] = 1;
+}
+
+template <bool REMAP, int NI, int NBAR, int DEPTH>
+void run2(const char* A, const char* B, int M, unsigned* out) {
+    const int mtiles = M / BM;
+    constexpr int smem = (DEPTH + 1) * 32768;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream2_kernel<REMAP, NI, NBAR, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    float best = 1e9;
+    const int grid = ((mtiles + 7) / 8) * 8;
+    for (int it = 0; it < 6; ++it) {
+        (void)hipEventRecord(a);
+        stream2_kernel<REMAP, NI, NBAR, DEPTH><<<grid, 512, smem>>>(A, B, mtiles, out);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    printf("A + weight pieces: tile order %-14s %d issuing wave(s) x %2d pieces, %d barrier(s) per step, %d steps in flight : %7.1f us   A stream %5.2f TB/s\n",
+           REMAP ? "XCD-contiguous" : "blockIdx", NI, 32 / NI, NBAR, DEPTH, best * 1e3, (double)M * ROWB / best / 1e9);
+}
+
 template <int MODE, bool DO_B>
 void run(const char* name, const char* A, const char* B, int M, unsigned* out) {
     const int mtiles = M / BM;
@@ -109,6 +176,21 @@ int main() {
     (void)hipMalloc(&B, (long)256 * ROWB);
     (void)hipMemset(A, 1, (long)M * ROWB);
     (void)hipMemset(B, 1, (long)256 * ROWB);
+    if (getenv("SS_STRUCTURE")) {
+        for (int rep = 0; rep < 2; ++rep) {
+            run2<true, 8, 1, 3>(A, B, M, out);
+            run2<false, 8, 1, 3>(A, B, M, out);
+            run2<true, 4, 1, 3>(A, B, M, out);
+            run2<true, 2, 1, 3>(A, B, M, out);
+            run2<true, 1, 1, 3>(A, B, M, out);
+            run2<true, 8, 2, 3>(A, B, M, out);
+            run2<false, 4, 2, 3>(A, B, M, out);
+            run2<true, 8, 1, 2>(A, B, M, out);
+            run2<true, 8, 1, 4>(A, B, M, out);
+            run2<true, 4, 1, 4>(A, B, M, out);
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run<0, false>("0 row-major, 64 B per row and step (igemm2)", A, B, M, out);
         run<1, false>("1 ... K walk rotated per workgroup", A, B, M, out);
