@@ -53,8 +53,8 @@ from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
 # measured HBM bytes per implicit-GEMM launch (rocprofv3 --pmc passes of tools/profile_round.sh), one file PER CONFIGURATION: a line
 # only ever carries the traffic collected on its own workload, never another configuration's
-TRAFFIC_FILES = {("r101", 1): "r04_pmc_igemm_traffic_r101_x1.json", ("r101", 4): "r04_pmc_igemm_traffic_r101_x4.json",
-                 ("swinb", 1): "r04_pmc_igemm_traffic_swinb_x1.json", ("r101", 1, "lookahead1"): "r04_pmc_igemm_traffic_r101_x1_lookahead1.json"}
+TRAFFIC_FILES = {("r101", 1): "r05_pmc_igemm_traffic_r101_x1.json", ("r101", 4): "r05_pmc_igemm_traffic_r101_x4.json",
+                 ("swinb", 1): "r05_pmc_igemm_traffic_swinb_x1.json", ("r101", 1, "lookahead1"): "r05_pmc_igemm_traffic_r101_x1_lookahead1.json"}
 
 
 def _md5(path):
