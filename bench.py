@@ -164,6 +164,9 @@ def cpu_baseline(cfg, sd, frames, height, width):
         all_cpus = round(nb / call(frames[nb:2 * nb], 16), 4)
         torch.set_num_threads(best_t)
     return {"value": round(nb / dt, 4), "unit": "frames/sec", "cores": best_t, "host_cpus": os.cpu_count(),
+            # the container's CPU-time quota in CPUs (cgroup cpu.max; null = none): the GPU boxes of this pool show 256 CPUs and grant 16, which
+            # is why the probe lands on 16 threads and every larger pool is slower
+            "cpu_quota_cpus": comm.cpu_quota(),
             "value_all_host_cpus": all_cpus if os.cpu_count() != best_t else round(nb / dt, 4),
             "thread_probe_s": {str(k): v for k, v in probe.items()},
             "kind": "port",
@@ -269,7 +272,7 @@ def real_data_feed_rate(device, n_files=48, passes=4, feed_workers=None):
                 m += 1
         torch.cuda.synchronize()
         dev_fps = m / (time.perf_counter() - t0)
-        return {"decode_workers": workers, "host_cpus": os.cpu_count(), "decode_frames_per_sec": round(decode_fps, 1),
+        return {"decode_workers": workers, "host_cpus": os.cpu_count(), "cpu_quota_cpus": comm.cpu_quota(), "decode_frames_per_sec": round(decode_fps, 1),
                 "decode_frames_per_sec_by_workers": {str(w): round(r, 1) for w, r in rates.items()}, "decode_workers_knee": knee,
                 "upload_resize_frames_per_sec": round(dev_fps, 1), "frame": "1280x720 JPEG q90 -> uint8 HWC -> fp32 CHW 576x1000 padded to 576x1024",
                 "delivered_frames_per_sec": round(min(decode_fps, dev_fps), 1),

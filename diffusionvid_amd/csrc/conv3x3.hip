@@ -780,7 +780,7 @@ int dvid_conv3x3_halo_launch(const IgemmParams& p, hipStream_t s) {
 
 // The space-to-depth stem (bias + ReLU) and the 3x3 / stride-2 / pad-1 max pool behind it as one launch: `p` = the stem's parameters with
 // `out` = the POOLED map [n][(H + 1) / 2][(W + 1) / 2][64].  Bit-identical to dvid_conv3x3_halo_launch + dvid_maxpool3x3s2_launch.
-bool dvid_stem_pool_supported(const IgemmParams& p) { return s2d_stem_shape(p) && p.relu == 1; }
+bool dvid_stem_pool_supported(const IgemmParams& p) { return s2d_stem_shape(p) && p.relu == 1 && p.ldc == 64; }          // the pooled map is written densely
 int dvid_stem_pool_launch(const IgemmParams& p, hipStream_t s) {
     if (!dvid_stem_pool_supported(p)) return DVID_ERR_UNSUPPORTED;
     return launch_stem_pool(p, s);

@@ -671,7 +671,7 @@ int tune_shape(const IgemmParams& p, hipStream_t s, const TileCfg* cfgs, int ncf
         if (!cfg_valid(cfgs[c], p)) continue;
         int rc = cfgs[c].launch(q, s);           // warm-up: code object load, L2 / MALL state
         if (rc != DVID_OK) continue;
-        // three launches; a short launch (the 20-40 us layers of a one-batch call) is timed again over enough launches to fill ~0.6 ms, and
+        // three launches; a short launch (the 20-40 us layers of a one-batch call) is timed again over enough launches to fill ~0.3 ms (unless it is already 30 % behind the best so far), and
         // the lower mean counts: three 25-us launches are inside the noise of the clock ramp and of the event pair itself, and a wrong winner
         // there costs 10-15 us on each of ~900 launches per video (round 5: res4 conv1 at 8 frames ran 37 us in one process, 23 in another)
         float ms = 1e30f;
@@ -685,8 +685,9 @@ int tune_shape(const IgemmParams& p, hipStream_t s, const TileCfg* cfgs, int ncf
             HIP_TRY(hipEventElapsedTime(&t, a, b));
             t /= reps;
             if (t < ms) ms = t;
-            if (t * reps >= 0.6f) break;
-            reps = (int)fminf(48.f, ceilf(0.6f / fmaxf(t, 1e-3f)));
+            // long enough already, or clearly not the winner: no second measurement (a stream of ragged video tails pays for every timing launch)
+            if (t * reps >= 0.3f || t > 1.3f * best_ms) break;
+            reps = (int)fminf(32.f, ceilf(0.3f / fmaxf(t, 1e-3f)));
         }
         if (log)
             fprintf(stderr, "[igemm tune] M %d N %d K %d taps %d res %d split %d : %dx%dx%d/%d  %.2f us\n", p.M, p.Cout, p.Kpad, p.ntaps,

@@ -42,6 +42,26 @@ def init_dist(backend=None, force=False, timeout_s=None):
     dist.init_process_group(backend=backend, init_method="env://", **kw)
 
 
+def cpu_quota():
+    """CPUs' worth of run time the container may use per period (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cfs_period_us`), or None
+    without a limit.  A host that shows 256 CPUs may schedule a container on 16 of them at a time: thread pools and decode pools sized by
+    os.cpu_count() then run slower than pools sized by the quota."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def _parse_cpulist(text):
     cpus = []
     for part in text.strip().split(","):

@@ -90,6 +90,8 @@ def main():
         for p in procs:
             p.join()
         total = sum(r[1] for r in res)
+        from diffusionvid_amd.utils import comm
+        print(f"container CPU quota (cgroup cpu.max): {comm.cpu_quota()} CPUs -- every figure below is what THAT many CPUs decode, however many workers share them")
         print(f"host CPUs {os.cpu_count()}; {args.groups} feeder groups x {args.workers} decode workers at the same time, 1280x720 JPEG q90 -> uint8 frames in shared memory")
         for g, fps, ncpu in res:
             print(f"  group {g}: {fps:8.1f} frames/s on {ncpu} CPUs")
