@@ -196,6 +196,10 @@ class DiffusionDet(nn.Module):
         # see _graphed_call.  DVID_CALL_GRAPH=0 / `use_call_graph = False` launches every call kernel by kernel (A/B, profiling).
         self.use_call_graph = os.environ.get("DVID_CALL_GRAPH", "1") != "0"
         self._graphs, self._graph_seen, self._graph_generation = {}, {}, -1
+        # the streaming mode's steady call as a graph (_stream_graph_applies): built, bit-identical, and NOT faster -- 247 against 252 frames/s
+        # (profiles/r05n_streaming_graph_ab.txt): that call is 4 ms of kernels (two-frame launches, two dependent farthest-point sweeps), the
+        # host's launching hides behind them.  Off unless asked for (DVID_STREAM_GRAPH=1, tests).
+        self.use_stream_graph = os.environ.get("DVID_STREAM_GRAPH", "0") == "1"
         self.graph_replays = 0
         self.host_wait_s = 0.0      # seconds this process spent blocked in the per-batch device->host result copy
         self.video_index = 0
@@ -357,6 +361,10 @@ class DiffusionDet(nn.Module):
             out = self._graphed_call(frame_id, ref_l, whwh, w, h, pairs, batch, ddim_draws.get(frame_id))
             if out is not None:
                 return out
+        elif self._stream_graph_applies(infos, ref_l, ref_g, ahead, batch, frame_id):
+            out = self._graphed_call(frame_id, ref_l, whwh, w, h, pairs, batch, ddim_draws.get(frame_id), ref_g=ref_g)
+            if out is not None:
+                return out
 
         # 1. features + extraction pass over [local frames | global frames] (+ the look-ahead batches)
         local_split = self._ahead.pop(frame_id, None)
@@ -501,7 +509,29 @@ class DiffusionDet(nn.Module):
         return all(f.tensors.is_cuda and f.tensors.device == self.device and f.tensors.dtype == torch.float32
                    and f.tensors.shape == f0.shape and f.tensors.shape[0] == 1 for f in ref_l)
 
-    def _graphed_call(self, frame_id, ref_l, whwh, w, h, pairs, batch, draws):
+    def _stream_graph_applies(self, infos, ref_l, ref_g, ahead, batch, frame_id):
+        """The steady-state call of the STREAMING mode (demo/demo.py:60-68: INFER_BATCH 1, one new global frame per call, the memory
+        updated and pruned back on every call, GLOBAL.STOP_UPDATE_AFTER_INIT_TEST False) once both memories have reached their full
+        size: backbone + extraction on [the frame | the new global frame], both memory updates (merge, distances, farthest-point sweep,
+        gather), K / V projection, final stage, post-processing -- ~200 launches whose shapes no longer change.  Such a call is 3-4 ms
+        of kernels beside ~1 ms of host-side launching with a result hand-over per call (bench.py: host_blocked_on_gpu_frac 0.76).
+        Measured: the replay is bit-identical and no faster (see `use_stream_graph`): the kernels, not the launching, are the 4 ms."""
+        if not self.use_call_graph or not self.use_stream_graph or self.lookahead != 1 or self.debug_taps is not None or self.demo:
+            return False
+        mega = self.cfg.MODEL.VID.MEGA
+        if not (self.key_frame_location == 0 and self.all_frame_interval == self.infer_batch == 1 and self.global_enable
+                and not mega.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST):
+            return False
+        if infos["frame_category"] == 0 or ahead or frame_id in self._ahead or self._mem_side_pending or len(ref_l) != 1 or len(ref_g) != 1 or batch != 1:
+            return False
+        mem = self.head.proposal_feats_global
+        if mem[0] is None or mem[1] is None or mem[0].shape[0] != self.mem_management_size_test or mem[1].shape[0] != 150:
+            return False          # the memories still grow: shapes change from call to call
+        f0 = ref_l[0].tensors
+        return all(f.tensors.is_cuda and f.tensors.device == self.device and f.tensors.dtype == torch.float32
+                   and f.tensors.shape == f0.shape and f.tensors.shape[0] == 1 for f in list(ref_l) + list(ref_g))
+
+    def _graphed_call(self, frame_id, ref_l, whwh, w, h, pairs, batch, draws, ref_g=None):
         """One batch of the reference's call protocol (mega_core/engine/inference.py:22-94: 8 frames per working call) is ~180
         kernel launches of 10-90 us -- backbone, 3 + 1 heads, attention, post-processing -- that differ from call to call only in
         their INPUT VALUES: the frames and the random draws.  The first steady call of a shape runs kernel by kernel (tuner,
@@ -519,21 +549,31 @@ class DiffusionDet(nn.Module):
         if gen != self._graph_generation:
             self._graphs, self._graph_seen, self._graph_generation = {}, {}, gen
         # ... and it bakes in every switch the eager path reads per call
+        gframes = [im.tensors for im in ref_g] if ref_g else []
         key = (tuple(frames[0].shape), len(frames), self.sampling_timesteps, int(mem[0].shape[0]), int(mem[1].shape[0]) if mem[1] is not None else 0,
                id(self._engine), (float(w), float(h)), bool(self.skip_unobservable), bool(self.use_nms), self._engine.chains,
-               os.environ.get("DVID_HEAD_CHAINS", ""))
+               os.environ.get("DVID_HEAD_CHAINS", ""), len(gframes))
         M = self.num_proposals
         g = self._graphs.get(key)
         if g is None:
             self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
             if self._graph_seen[key] < 2:
                 return None                      # the first steady call of this shape: eager (it also warms everything a capture may not do)
-            g = self._capture_call(key, frames, whwh, w, h, pairs, batch, draws)
+            g = self._capture_call(key, frames, whwh, w, h, pairs, batch, draws, gframes)
             if g is None:
                 return None
         # this call's inputs into the graph's static buffers (device-to-device, on the launch stream), then ONE launch
         torch._foreach_copy_(g["frames"], frames)
         g["box_init"].copy_(self._noise("box_init", frame_id, 0, 0, (batch, M, 4)))
+        if gframes:
+            # streaming: the new global frame and its draw (split 1 of this call); the memories live in the graph's static buffers from
+            # one replay to the next -- after an eager call (a new video's first calls) they are brought up to date first
+            torch._foreach_copy_(g["gframes"], gframes)
+            g["box_init_g"].copy_(self._noise("box_init", frame_id, 1, 0, (len(gframes), M, 4)))
+            for i in range(2):
+                if mem[i] is not g["mem"][i]:
+                    g["mem"][i].copy_(mem[i])
+            self.head.proposal_feats_global = list(g["mem"])
         if draws is not None:
             g["draws"]["img"].copy_(draws["img"])
             for step, pair in g["draws"].items():
@@ -543,9 +583,13 @@ class DiffusionDet(nn.Module):
         if self.after_first_launch is not None:
             self.after_first_launch()
         # the captured launches read the memory's K / V projections from the engine's buffers; projecting is not part of the capture
-        # (a memory adopted from another rank, or replaced in place, has not been through global_xattn yet)
-        self._get_engine().ensure_memory_projected(mem[0])
+        # (a memory adopted from another rank, or replaced in place, has not been through global_xattn yet) -- except in the streaming
+        # graph, whose memory changes inside the capture and is projected there
+        if not gframes:
+            self._get_engine().ensure_memory_projected(mem[0])
         g["graph"].replay()
+        if gframes:
+            self._get_engine().invalidate_memory()          # the projection buffers hold this replay's memory; no tensor version says so
         self.graph_replays += 1
         self.local_img_queue = []
         # the local queue as the eager path leaves it (diffusion_det.py:491-506): this call's frames, whose extraction results are the
@@ -559,17 +603,35 @@ class DiffusionDet(nn.Module):
             out = tuple(t.clone() for t in out)
         return self._to_boxlists(*out, (int(w), int(h)))
 
-    def _capture_call(self, key, frames, whwh, w, h, pairs, batch, draws):
+    def _capture_call(self, key, frames, whwh, w, h, pairs, batch, draws, gframes=()):
         M = self.num_proposals
         static = {"frames": [torch.empty_like(f) for f in frames], "box_init": torch.empty((batch, M, 4), device=self.device),
                   "draws": None}
+        if gframes:
+            static["gframes"] = [torch.empty_like(f) for f in gframes]
+            static["box_init_g"] = torch.empty((len(gframes), M, 4), device=self.device)
+            static["mem"] = [m.clone() for m in self.head.proposal_feats_global]
         if draws is not None:
             static["draws"] = {k: (torch.empty_like(v) if k == "img" else (torch.empty_like(v[0]), torch.empty_like(v[1]))) for k, v in draws.items()}
         static_l = [ImageList(f, im.image_sizes) for f, im in zip(static["frames"], [to_image_list(f) for f in frames])]
         hook, self.after_first_launch = self.after_first_launch, None
 
+        static_g = [ImageList(f, im.image_sizes) for f, im in zip(static.get("gframes", []), [to_image_list(f) for f in gframes])]
+        side_mem, self.memory_on_side_stream = self.memory_on_side_stream, (self.memory_on_side_stream and not gframes)          # one stream inside the streaming capture
+        mem_orig = list(self.head.proposal_feats_global)
+
         def body():
-            local, _, _ = self._extract(0, static_l, [], {}, whwh, box_init=[static["box_init"]])
+            if gframes:
+                # [frame | new global frame] through backbone + extraction, then both memory updates on the STATIC memory buffers: the
+                # pruned memories are written back into them, so that the next replay starts from this one's result
+                self.head.proposal_feats_global = list(static["mem"])
+                local, gsplit, _ = self._extract(0, static_l, static_g, {}, whwh, box_init=[static["box_init"], static["box_init_g"]])
+                self._build_memory(gsplit)
+                for i in range(2):
+                    static["mem"][i].copy_(self.head.proposal_feats_global[i])
+                self._set_global_memory(static["mem"])
+            else:
+                local, _, _ = self._extract(0, static_l, [], {}, whwh, box_init=[static["box_init"]])
             static["local"] = local
             feats_cur, cached = local["feats"], (local["logits"], local["boxes"], local["obj"])
             return self._final_stage_launch(feats_cur, cached, whwh, w, h, pairs, [(0, batch)], {0: static["draws"]} if static["draws"] is not None else {}, slots=batch)
@@ -577,6 +639,10 @@ class DiffusionDet(nn.Module):
         try:
             torch._foreach_copy_(static["frames"], frames)
             static["box_init"].normal_()
+            if gframes:
+                torch._foreach_copy_(static["gframes"], gframes)
+                static["box_init_g"].normal_()
+                mem_before = [m.clone() for m in static["mem"]]          # the warm-up run and the capture itself must not advance the memory
             if static["draws"] is not None:
                 for v in static["draws"].values():
                     for t in (v if isinstance(v, tuple) else (v,)):
@@ -591,13 +657,19 @@ class DiffusionDet(nn.Module):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):          # other host threads (a data loader's copies) stay legal
                 out = body()
+            if gframes:
+                for i in range(2):
+                    static["mem"][i].copy_(mem_before[i])
         except Exception as e:                       # a platform that cannot capture falls back to kernel-by-kernel launches, loudly
             import warnings
             warnings.warn("DiffusionDet: hipGraph capture of the steady-state call failed (%r); calls are launched kernel by kernel" % (e,))
             self.use_call_graph = False
+            if gframes:
+                self._set_global_memory(mem_orig)          # the streaming body advances the memory: the eager call that follows starts from the old one
             return None
         finally:
             self.after_first_launch = hook
+            self.memory_on_side_stream = side_mem
         static["graph"], static["out"] = graph, out
         if ops.workspace_generation() != self._graph_generation:          # the capture's own warm-up run may have grown the workspace:
             self._graphs, self._graph_seen = {}, {}                        # older graphs go; this one was captured after the move

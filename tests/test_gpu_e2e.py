@@ -1272,6 +1272,49 @@ def test_call_graph_replay_is_bit_identical(arch, sample_step, noise):
             torch.equal(a.get_field("labels"), b.get_field("labels")), f"frame {f} differs between graph replay and kernel-by-kernel launches"
 
 
+@pytest.mark.parametrize("sample_step", [1, 4])
+def test_streaming_call_graph_replay_is_bit_identical(sample_step):
+    """The steady-state call of the streaming mode (INFER_BATCH 1, one new global frame per call, both memories merged and pruned back
+    on every call) replayed as one hipGraph against the same calls launched kernel by kernel: two videos (the second re-uses the first
+    one's graph with a memory that started over), every detection and the final memories bit for bit.  The memory lives in the graph's
+    static buffers from replay to replay and is brought up to date after the eager calls at a video's start."""
+    from diffusionvid_amd.config import get_cfg
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.modeling.detector import build_detection_model
+    from diffusionvid_amd.utils import synthetic
+    lens = [14, 9]
+    outs, replays, mems = {}, {}, {}
+    for graphs in (False, True):
+        cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml",
+                      ["INPUT.INFER_BATCH", 1, "MODEL.VID.MEGA.MAX_OFFSET", 0, "MODEL.VID.MEGA.MIN_OFFSET", 0,
+                       "MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 1, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 0,
+                       "MODEL.VID.MEGA.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST", False, "MODEL.DiffusionDet.SAMPLE_STEP", sample_step], "configs/BASE_RCNN_1gpu.yaml")
+        cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
+        cfg.freeze()
+        model = _weights(build_detection_model(cfg), "trained_like").to("cuda").eval()
+        model.noise_fn = synthetic.DeviceNoise()
+        model.use_call_graph = model.use_stream_graph = graphs          # (the streaming graph is opt-in: bit-identical, not faster)
+        ds = SyntheticVIDDataset(lens, cfg, height=120, width=200, device="cuda", smooth=True)
+        res = []
+        with torch.no_grad():
+            for idx in range(len(ds)):
+                res += model(ds[idx][0])
+        assert len(res) == sum(lens)
+        outs[graphs] = [r.to(torch.device("cpu")) for r in res]
+        replays[graphs] = model.graph_replays
+        mems[graphs] = [m.clone().cpu() for m in model.head.proposal_feats_global]
+        del model, ds
+        torch.cuda.empty_cache()
+    # per video: call 0 resets, call 1 is the eager steady call (first video only: the second finds the graph), the rest replay
+    assert replays[False] == 0 and replays[True] >= sum(lens) - len(lens) - 2, replays
+    for f, (a, b) in enumerate(zip(outs[False], outs[True])):
+        assert len(a) == len(b) and len(a) > 0, f
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores")) and \
+            torch.equal(a.get_field("labels"), b.get_field("labels")), f"frame {f} differs between graph replay and kernel-by-kernel launches"
+    for a, b in zip(mems[False], mems[True]):
+        assert torch.equal(a, b), "the memories of the two runs parted"
+
+
 def test_call_graph_dropped_when_the_workspace_moves():
     """A captured call holds raw addresses inside the engine's workspace, and the workspace is re-allocated when it grows (a VID-val
     run mixes 4:3 and 16:9 videos): small video (captures), larger video (grows the workspace, captures its own shape), small

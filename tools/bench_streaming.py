@@ -20,7 +20,7 @@ cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"),
                "MODEL.VID.MEGA.GLOBAL.STOP_UPDATE_AFTER_INIT_TEST", False], os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
 cfg.freeze()
 model = build_detection_model(cfg).to("cuda").eval()
-model.noise_fn = synthetic.noise_fn
+model.noise_fn = synthetic.DeviceNoise() if os.environ.get("DVID_HOST_NOISE", "0") != "1" else synthetic.noise_fn
 model.results_on_host = True
 ds = SyntheticVIDDataset([L], cfg, device="cuda")
 ds.preload()
