@@ -97,6 +97,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise DvidError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
                         "there is no CPU fallback")
+    # torch first: it carries its own copy of the HIP runtime, and whichever copy a process loads first is the one the device belongs to.
+    # Loaded after libdvid_hip's (the system's libamdhip64), torch's copy takes the GPU and the library's hipGetDeviceCount answers 0 --
+    # `__graft_entry__.build(); smoke()` in ONE process failed that way ("no HIP device available") while either call alone worked.
+    try:
+        import torch  # noqa: F401
+    except ImportError:          # symbol / build checks without torch still work
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing

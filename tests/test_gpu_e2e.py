@@ -1315,6 +1315,17 @@ def test_streaming_call_graph_replay_is_bit_identical(sample_step):
         assert torch.equal(a, b), "the memories of the two runs parted"
 
 
+def test_build_then_smoke_in_one_process():
+    """`__graft_entry__.build(); smoke()` as ONE process (README quick start; how a driver may chain them): build() dlopens the library
+    before anything imported torch, and torch brings its own copy of the HIP runtime -- loaded in that order the library's copy saw no
+    device ("no HIP device available", round 5) while either call alone worked.  `_lib.load()` imports torch first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_call_graph_dropped_when_the_workspace_moves():
     """A captured call holds raw addresses inside the engine's workspace, and the workspace is re-allocated when it grows (a VID-val
     run mixes 4:3 and 16:9 videos): small video (captures), larger video (grows the workspace, captures its own shape), small
