@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 typedef _Float16 half_t;
@@ -214,6 +215,135 @@ __global__ __launch_bounds__((MODE != 0 && NL == 1) ? 512 : 512 + 64 * NL) void 
     }
 }
 
+// ---- FOUR waves, one per SIMD, 128 x 128 of the tile each (256 accumulator registers) ------------------------------------------------
+// With one wave per SIMD a wave may hold 512 registers: 256 accumulators + the fragments of TWO K tiles (the next tile's are read while
+// this one's 32 MFMAs run).  Fragment reads per MFMA drop from 0.75 (128 x 64 per wave) to 0.5, there is no partner wave to share the
+// matrix pipe with and one barrier per K tile; every latency the partner used to cover must be covered by the software pipeline instead.
+// Same MFMA and K order: bit-identical to the 8-wave schedule.
+template <bool DMA>
+__global__ __launch_bounds__(256) void gemm_w4(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = N / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = K / BK;
+    // DMA: wave w stages A pieces {w, w + 4, w + 8, w + 12} and the same B pieces (16 rows x 64 B each)
+    const char* a_src[4];
+    const char* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 16 * (wave + 4 * i) + (lane >> 2);
+        const int lch = (lane & 3) ^ ((row >> 2) & 3);
+        a_src[i] = reinterpret_cast<const char*>(A + (long)(m0 + row) * K + lch * 8);
+        b_src[i] = reinterpret_cast<const char*>(B + (long)(n0 + row) * K + lch * 8);
+    }
+    auto piece = [&](int t, int pc) {          // pc 0..3: A, 4..7: B
+        char* d = smem + (t % NSTAGE) * STAGE;
+        if (pc < 4) glds16(a_src[pc] + (long)t * BK * 2, d + (wave + 4 * pc) * 1024);
+        else glds16(b_src[pc - 4] + (long)t * BK * 2, d + A_BYTES + (wave + 4 * (pc - 4)) * 1024);
+    };
+    const int frow = lane & 31;
+    const int sw = (frow >> 2) & 3;
+    const int fa_off = (wm * 128 + frow) * 64;
+    const int fb_off = A_BYTES + (wn * 128 + frow) * 64;
+    int choff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) choff[ks] = ((2 * ks + (lane >> 5)) ^ sw) * 16;
+
+    float16v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    half8 fa[2][2][4], fb[2][2][4];          // [buffer][K half][block]
+    auto read_frags = [&](int t, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        const char* st = smem + (t % NSTAGE) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[buf][ks][i] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * 64 + choff[ks]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[buf][ks][j] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * 64 + choff[ks]);
+        }
+    };
+    if (DMA) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < nk)
+#pragma unroll
+                for (int pc = 0; pc < 8; ++pc) piece(d, pc);
+        if (nk > 2) wait_vmcnt<16>(); else if (nk > 1) wait_vmcnt<8>(); else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, std::integral_constant<int, 0>{});
+    wait_lgkm0();
+    if (DMA) {
+        if (nk > 2) wait_vmcnt<8>(); else wait_vmcnt<0>();          // tile 1
+    }
+    __builtin_amdgcn_s_barrier();
+
+    auto step = [&](int t, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        const bool more = t + 1 < nk, dma = DMA && t + 3 < nk;
+        const char* st = smem + ((t + 1) % NSTAGE) * STAGE;
+        // 32 MFMAs; the 16 fragment reads of tile t + 1 and the 8 DMA pieces of tile t + 3 go between them
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int ks = q >> 4, i = (q >> 2) & 3, j = q & 3;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[buf][ks][i], fb[buf][ks][j], acc[i][j], 0, 0, 0);
+            if (more && (q & 1) == 0) {          // reads 0..15 after MFMAs 0, 2, .., 30
+                const int r = q >> 1, rks = r >> 3, rb = r & 7;
+                if (rb < 4) fa[buf ^ 1][rks][rb] = *reinterpret_cast<const half8*>(st + fa_off + rb * 32 * 64 + choff[rks]);
+                else fb[buf ^ 1][rks][rb - 4] = *reinterpret_cast<const half8*>(st + fb_off + (rb - 4) * 32 * 64 + choff[rks]);
+            }
+            if (dma && (q & 3) == 3) piece(t + 3, q >> 2);
+        }
+        wait_lgkm0();
+        if (DMA) {
+            if (t + 3 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();          // own pieces of tile t + 2 landed
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        step(t, std::integral_constant<int, 0>{});
+        step(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (t < nk) step(t, std::integral_constant<int, 0>{});
+    __syncthreads();
+
+    // ---- epilogue: each wave stages 32 rows x 128 cols fp32 (16 KiB) at a time in its own LDS slice
+    float* cs = reinterpret_cast<float*>(smem) + wave * (32 * 128);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = j * 32 + (lane & 31);
+                cs[row * 128 + col] = acc[i][j][r];
+            }
+        wait_lgkm0();
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 4 + (lane >> 4), c8 = (lane & 15) * 8;
+            half8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = (half_t)cs[row * 128 + c8 + e];
+            const long m = m0 + wm * 128 + i * 32 + row;
+            *reinterpret_cast<half8*>(C + m * N + n0 + wn * 128 + c8) = hv;
+        }
+        wait_lgkm0();
+    }
+}
+
 __global__ void gemm_naive(const half_t* A, const half_t* B, float* C, int M, int N, int K) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (n >= N) return;
@@ -239,6 +369,8 @@ int main() {
         {"no DMA at all, 8 waves (ceiling)", gemm_lw<1, 1>, 512, false},
         {"no DMA at all, 8 + 4 idle waves", gemm_lw<4, 1>, 768, false},
         {"DMA only (4 loader waves), no reads, no MFMA", gemm_lw<4, 3>, 768, false},
+        {"4 waves x 128x128 (one per SIMD, 512 regs)", gemm_w4<true>, 256, true},
+        {"4 waves x 128x128, no DMA (ceiling)", gemm_w4<false>, 256, false},
     };
     for (const Variant& v : vs) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     struct Shape { int M, N, K; };
