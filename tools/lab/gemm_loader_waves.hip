@@ -344,6 +344,143 @@ __global__ __launch_bounds__(256) void gemm_w4(const half_t* __restrict__ A, con
     }
 }
 
+// ---- PERSISTENT workgroups: the DMA ring runs across tile boundaries, the epilogue leaves from the accumulator layout -------------------
+// One workgroup per CU pays a prologue fill (~2.5 us: nothing to multiply until the first K tiles land) and an epilogue (~4 us: fp32 tile
+// through LDS, barriers, stores; no DMA in flight because the ring's LDS is the staging buffer) per 256-row tile of ~40 us, and nothing
+// overlaps them.  Here a workgroup walks tiles g, g + G, ...: the pieces of the NEXT tile's first three K tiles are issued in the last three
+// MFMA slots of the current one (the ring never drains), and the epilogue uses no LDS and no barrier -- products are computed transposed
+// (D[n][m]: a lane holds 4 consecutive channels of one row), a v_permlane32_swap per register pair makes that 8 channels = one 16-byte
+// store.  Same MFMA, same K order: bit-identical.  igemm2's anti-phase schedule otherwise (each wave issues its own 4 pieces per K tile).
+__global__ __launch_bounds__(512) void gemm_persist(const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int ntile = M / BM;                    // N == BN: one tile column
+    const int nk = K / BK;
+    const int G = gridDim.x;
+    int tile = blockIdx.x;
+    if (tile >= ntile) return;
+    const int my_tiles = (ntile - tile + G - 1) / G;
+    const long total = (long)my_tiles * nk;      // K steps of this workgroup, all tiles
+    // piece sources: A pieces follow the tile, B pieces do not
+    const int prow[2] = {16 * wave + (lane >> 2), 16 * (wave + 8) + (lane >> 2)};
+    const char* b_src[2];
+    long a_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lch = (lane & 3) ^ ((prow[i] >> 2) & 3);
+        b_src[i] = reinterpret_cast<const char*>(B + (long)prow[i] * K + lch * 8);
+        a_off[i] = ((long)prow[i] * K + lch * 8) * 2;
+    }
+    const char* const Ab = reinterpret_cast<const char*>(A);
+    // piece pc of global step s (tile index s / nk of this workgroup's list, K tile s % nk)
+    // the issue cursor walks (tile of this workgroup's list, K tile) three steps ahead of the multiply: no division in the loop
+    const char* cur_a = Ab + (long)tile * BM * K * 2;          // A base of the cursor's tile
+    const long tile_stride = (long)G * BM * K * 2;
+    int cur_k = 0;
+    long cur_s = 0;
+    auto piece = [&](int pc) {
+        char* d = smem + (cur_s & 3) * STAGE;
+        if (pc < 2) glds16(cur_a + a_off[pc] + (long)cur_k * BK * 2, d + (wave + 8 * pc) * 1024);
+        else glds16(b_src[pc - 2] + (long)cur_k * BK * 2, d + A_BYTES + (wave + 8 * (pc - 2)) * 1024);
+    };
+    auto advance = [&]() {
+        ++cur_s;
+        if (++cur_k == nk) {
+            cur_k = 0;
+            cur_a += tile_stride;
+        }
+    };
+    const int frow = lane & 31, hsel = lane >> 5;
+    const int sw = (frow >> 2) & 3;
+    const int fa_off = (grp * 128 + frow) * 64;
+    const int fb_off = A_BYTES + (wn * 64 + frow) * 64;
+    int choff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) choff[ks] = ((2 * ks + hsel) ^ sw) * 16;
+
+    float16v acc[4][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (d < total) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) piece(pc);
+            advance();
+        }
+    if (total > 2) wait_vmcnt<8>(); else if (total > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    long s = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int t = 0; t < nk; ++t, ++s) {
+            const char* st = smem + (s & 3) * STAGE;
+            half8 fa[4][2], fb[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i][ks] = *reinterpret_cast<const half8*>(st + fa_off + i * 32 * 64 + choff[ks]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j][ks] = *reinterpret_cast<const half8*>(st + fb_off + j * 32 * 64 + choff[ks]);
+            }
+            wait_lgkm0();
+            if (s + 2 < total) wait_vmcnt<4>(); else wait_vmcnt<0>();          // own pieces of step s + 1 landed (step s + 2's may be in flight)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool dma = s + 3 < total;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ks = q >> 3, i = (q >> 1) & 3, j = q & 1;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);          // D[channel][row]
+                if (dma && (q & 3) == 1) piece(q >> 2);
+            }
+            if (dma) advance();
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue of tile ti straight from the accumulators: acc[i][j][4 r4 + e] = channel 64 wn + 32 j + 8 r4 + 4 hsel + e of row
+        // 128 grp + 32 i + frow; after the half-wave exchange a lane holds channels 16 g + 8 hsel + [0, 8)
+        const long m0 = (long)(tile + ti * G) * BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                unsigned int u[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float f = acc[i][j][r];
+                    u[r] = __float_as_uint(f);
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto swp = __builtin_amdgcn_permlane32_swap(u[8 * g + r], u[8 * g + 4 + r], false, false);
+                        u[8 * g + r] = swp[0];
+                        u[8 * g + 4 + r] = swp[1];
+                    }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    half8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (half_t)__uint_as_float(u[8 * g + e]);
+                    *reinterpret_cast<half8*>(C + (m0 + grp * 128 + i * 32 + frow) * N + wn * 64 + j * 32 + 16 * g + 8 * hsel) = hv;
+                }
+            }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
 __global__ void gemm_naive(const half_t* A, const half_t* B, float* C, int M, int N, int K) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (n >= N) return;
@@ -357,6 +494,7 @@ struct Variant {
     void (*kern)(const half_t*, const half_t*, half_t*, int, int, int);
     int threads;
     bool checked;
+    int grid = 0;          // > 0: persistent workgroups (N == 256 shapes only)
 };
 
 int main() {
@@ -371,6 +509,7 @@ int main() {
         {"DMA only (4 loader waves), no reads, no MFMA", gemm_lw<4, 3>, 768, false},
         {"4 waves x 128x128 (one per SIMD, 512 regs)", gemm_w4<true>, 256, true},
         {"4 waves x 128x128, no DMA (ceiling)", gemm_w4<false>, 256, false},
+        {"persistent, ring across tiles, direct epilogue", gemm_persist, 512, true, 256},
     };
     for (const Variant& v : vs) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     struct Shape { int M, N, K; };
@@ -420,9 +559,11 @@ int main() {
         CHECK(hipMalloc(&dA, na * 2)); CHECK(hipMalloc(&dB, nb * 2)); CHECK(hipMalloc(&dC, nc * 2));
         CHECK(hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(dB, hb.data(), nb * 2, hipMemcpyHostToDevice));
-        const int grid = (sh.M / BM) * (sh.N / BN);
+        const int grid_all = (sh.M / BM) * (sh.N / BN);
         std::vector<half_t> href;
         for (const Variant& v : vs) {
+            if (v.grid && sh.N != BN) continue;
+            const int grid = v.grid ? (v.grid < (sh.M / BM) ? v.grid : sh.M / BM) : grid_all;
             // threads beyond the variant's wave count would run the loader branch: launch exactly what the variant is built for
             CHECK(hipMemset(dC, 0, nc * 2));
             hipLaunchKernelGGL(v.kern, dim3(grid), dim3(v.threads), smem, 0, dA, dB, dC, sh.M, sh.N, sh.K);
