@@ -33,6 +33,7 @@ SIGNATURES = {
     "dvid_model_destroy": (c_int, [c_void_p]),
     "dvid_model_set_tensor": (c_int, [c_void_p, C.c_char_p, c_void_p, C.POINTER(c_int64), c_int]),
     "dvid_model_finalize": (c_int, [c_void_p]),
+    "dvid_model_set_precision": (c_int, [c_void_p, c_int]),
     "dvid_set_chains": (c_int, [c_void_p, c_int]),
     "dvid_set_stem_layout": (c_int, [c_void_p, c_int]),
     "dvid_workspace_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
@@ -47,6 +48,11 @@ SIGNATURES = {
     "dvid_global_memory_project": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "dvid_roialign_v2_multilevel": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                             c_void_p, c_void_p, c_void_p]),
+    "dvid_roialign_v2_multilevel_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                                c_void_p, c_void_p, c_void_p]),
+    "dvid_conv2d_nhwc_f32": (c_int, [c_void_p] * 5 + [c_int] * 12 + [c_void_p]),
+    "dvid_mha_f32": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_int64] * 3 + [c_void_p]),
+    "dvid_dynconv_f32": (c_int, [c_void_p] * 7 + [c_int, c_void_p]),
     "dvid_select_topk_features": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                           c_void_p]),
     "dvid_counter_normal": (c_int, [c_void_p, C.c_int64, c_int, C.c_uint64, c_void_p]),

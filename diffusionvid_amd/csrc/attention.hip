@@ -307,16 +307,11 @@ int dvid_swin_window_attn_launch(const half_t* qkv, const half_t* qkv_bias16, co
                                  int W, int C, int nheads, int shift, hipStream_t s) {
     if (C != nheads * 32) return DVID_ERR_UNSUPPORTED;
     const int nwy = (H + 6) / 7, nwx = (W + 6) / 7;
-    static const int head_major = getenv("DVID_SWIN_ATTN_ORDER") ? atoi(getenv("DVID_SWIN_ATTN_ORDER")) : 1;      // 0: A/B measurements
-    static const int wpb = getenv("DVID_SWIN_ATTN_WPB") ? atoi(getenv("DVID_SWIN_ATTN_WPB")) : 4;                  // 1: one window per workgroup (A/B)
     const long nwin = (long)batch * nwy * nwx;
     if (nwin * nheads > 0x7fffffffL) return DVID_ERR_UNSUPPORTED;
-    if (wpb == 1)
-        hipLaunchKernelGGL(swin_window_attn_kernel<1>, dim3((unsigned)(nwin * nheads)), dim3(256), 0, s, qkv, qkv_bias16, relbias, out, H, W, C,
-                           nheads, shift, 1.0f / sqrtf(32.f), (int)nwin, head_major);
-    else
-        hipLaunchKernelGGL(swin_window_attn_kernel<4>, dim3((unsigned)((nwin + 3) / 4 * nheads)), dim3(256), 0, s, qkv, qkv_bias16, relbias, out,
-                           H, W, C, nheads, shift, 1.0f / sqrtf(32.f), (int)nwin, head_major);
+    // four windows per workgroup, head-major order (one window per workgroup and window-major order were measured slower: profiles/r02e_*)
+    hipLaunchKernelGGL(swin_window_attn_kernel<4>, dim3((unsigned)((nwin + 3) / 4 * nheads)), dim3(256), 0, s, qkv, qkv_bias16, relbias, out,
+                       H, W, C, nheads, shift, 1.0f / sqrtf(32.f), (int)nwin, 1);
     LAUNCH_CHECK();
     return DVID_OK;
 }

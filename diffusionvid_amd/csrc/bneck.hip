@@ -31,6 +31,7 @@
 #include "common.h"
 #include "igemm_epilogue.h"
 #include "kernels.h"
+#include "options.h"
 
 namespace {
 
@@ -397,8 +398,8 @@ int bn_launch(const BneckParams& p, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck64_tail_kernel<SC, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
         mark_on_device(attr_set);
     }
-    static const int lds_env = getenv("DVID_BNECK_LDS") ? atoi(getenv("DVID_BNECK_LDS")) : 0;          // diagnostics: less than the whole LDS (>= kBias + 4096)
-    hipLaunchKernelGGL((bneck64_tail_kernel<SC, TN>), dim3(p.ntiles), dim3(512), lds_env >= kBias + 4096 && lds_env <= kBytes ? lds_env : kBytes, s, p);
+    const int lds_opt = g_opt.bneck_lds;          // diagnostics: less than the whole LDS (>= kBias + 4096)
+    hipLaunchKernelGGL((bneck64_tail_kernel<SC, TN>), dim3(p.ntiles), dim3(512), lds_opt >= kBias + 4096 && lds_opt <= kBytes ? lds_opt : kBytes, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
 }
@@ -720,8 +721,8 @@ int bn128_launch(const Bneck128Params& p, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck128_tail_kernel<CONV2, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, k8Bytes));
         mark_on_device(attr_set);
     }
-    static const int lds_env = getenv("DVID_BNECK_LDS") ? atoi(getenv("DVID_BNECK_LDS")) : 0;          // diagnostics: less than the whole LDS (>= k8Bias + 3072)
-    hipLaunchKernelGGL((bneck128_tail_kernel<CONV2, TAIL>), dim3(p.ntiles), dim3(512), lds_env >= k8Bias + 3072 && lds_env <= k8Bytes ? lds_env : k8Bytes, s, p);
+    const int lds_opt = g_opt.bneck_lds;          // diagnostics: less than the whole LDS (>= k8Bias + 3072)
+    hipLaunchKernelGGL((bneck128_tail_kernel<CONV2, TAIL>), dim3(p.ntiles), dim3(512), lds_opt >= k8Bias + 3072 && lds_opt <= k8Bytes ? lds_opt : k8Bytes, s, p);
     LAUNCH_CHECK();
     return DVID_OK;
 }
@@ -730,20 +731,13 @@ int bn128_launch(const Bneck128Params& p, hipStream_t s) {
 
 // The shape rule: the map is at least as large as conv3x3.hip asks for its patch kernels (W within 1/8 of a multiple of 32, 512
 // pixels) -- a function of the image size only.  Values do not depend on it (bit-identical to the layer-by-layer launches).
-static int g_bneck_mode = -1;          // -1: follow DVID_BNECK_FUSE (default 1); 0 off; 1 by the shape rule; 2 wherever the stage fits
-int dvid_igemm_set_bottleneck_fusion(int mode) {
+int dvid_igemm_set_bottleneck_fusion(int mode) {          // g_opt.bneck_fuse: 0 off; 1 by the shape rule; 2 wherever the stage fits; -1 the default (1)
     if (mode < -1 || mode > 2) return DVID_ERR_ARG;
-    g_bneck_mode = mode;
+    g_opt.bneck_fuse = mode < 0 ? DvidOptions().bneck_fuse : mode;
     return DVID_OK;
 }
-// DVID_BNECK_STAGES (diagnostics): bit 0 = res2, bit 1 = res3 take the fused path (default 3)
-bool dvid_bneck_stage_enabled(int stage) {
-    static const int mask = getenv("DVID_BNECK_STAGES") ? atoi(getenv("DVID_BNECK_STAGES")) : 3;
-    return (mask >> stage) & 1;
-}
 bool dvid_bneck64_tail_preferred(int H, int W) {
-    static const int env = getenv("DVID_BNECK_FUSE") ? atoi(getenv("DVID_BNECK_FUSE")) : 1;
-    const int mode = g_bneck_mode >= 0 ? g_bneck_mode : env;
+    const int mode = g_opt.bneck_fuse;
     if (!mode) return false;
     if (mode >= 2) return true;
     return ceil_div(W, TW) * TW * 7 <= W * 8 && H * W >= 512;

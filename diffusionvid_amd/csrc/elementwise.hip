@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "options.h"
 
 namespace {
 
@@ -431,8 +432,7 @@ int dvid_add_layernorm_launch(const float* x, const float* r, const float* g, co
                               int d, int relu, hipStream_t s, int nsplit, long split_stride, const float* xbias) {
     if (d % 4 || d > 1024) return DVID_ERR_ARG;
     const int wpb = 4;
-    static const int rows_env = getenv("DVID_LN_ROWS") ? atoi(getenv("DVID_LN_ROWS")) : 1;      // 0: one row per wave everywhere (A/B)
-    if (rows_env && nsplit == 1 && rows > 0 && (d == 128 || d == 256)) {
+    if (g_opt.ln_rows && nsplit == 1 && rows > 0 && (d == 128 || d == 256)) {
         constexpr int R = 4;
         const dim3 blk(64 * wpb);
         if (d == 128)

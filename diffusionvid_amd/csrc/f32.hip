@@ -1,0 +1,660 @@
+// The DTYPE float32 path: fp32 storage end to end and exact fp32 products.
+//
+// The reference runs fp32 unless `DTYPE float16` is given (mega_core/config/defaults.py:582; tools/test_net.py:97-98 switches apex amp
+// on for float16 only).  The fp16 path of this library (igemm2 / conv3x3 / wstat / bneck / headtail / dynconv / attention) rounds every
+// stored activation and every weight to fp16 -- the apex O1 policy -- which is where its distance from an fp32 evaluation comes from
+// (profiles/r05_logit_error_stages.txt).  The kernels here keep every tensor in fp32 and multiply on v_mfma_f32_32x32x2_f32: f32 in,
+// f32 accumulate, bit-for-bit a k-ordered fmaf chain (MI355X_MICROARCH.md), 157 TFLOP/s dense peak = 1/16 of the fp16 MFMA rate.
+// They are deliberately plain -- one implicit-GEMM kernel for every convolution and linear layer, VALU kernels for the reductions --
+// because the mode exists for conformance (the fp32 CPU oracle's results to ~1e-5), not for the headline rate.
+//
+//   f32_igemm_kernel      conv / linear: NHWC fp32 in, [Cout][Kpad] fp32 weights, + bias, + residual (same shape or FPN nearest-x2
+//                         top-down), ReLU / exact GELU, fp32 out; 128 x BN x 16 tiles through LDS, 2 x 2 waves
+//   f32_roialign_kernel   detectron2 ROIPooler(ROIAlignV2) as called at box_head.py:507/:617 on fp32 pyramids (csrc/roialign.hip's walk)
+//   f32_mha_kernel        nn.MultiheadAttention's softmax(q k^T / sqrt(32)) v per head, one query per lane, keys through LDS
+//   f32_dynconv_kernel    DynamicConv.forward (box_head.py:687-711): two per-box products + LayerNorm + ReLU, one workgroup per box
+//   elementwise           image normaliser -> NHWC4, 3x3/2 max pool, SiLU, scale / shift modulation
+#include <stdlib.h>
+
+#include "common.h"
+#include "igemm_epilogue.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float16v mfma_f32(float a, float b, float16v c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// implicit GEMM.  D[m][n] = sum_k A[m][k] W[n][k]; A is the im2col view of the NHWC input (k = (ky * KW + kx) * Cin + c, Cin % 4 == 0),
+// W rows are zero-padded to Kpad (a multiple of 16).  Workgroup = 4 waves as 2 x 2, wave tile 64 x (BN / 2), K step 16:
+// global -> registers -> LDS (rows of 16 floats at a pitch of 20: the ds_read_b128 fragment reads are conflict-free), one barrier
+// per step, the next step's global loads in flight under this step's 32 (BN 128) MFMAs of 64 cycles each.
+// MFMA operand maps (cdna_hip_programming.md): A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31]; a lane
+// reads 4 consecutive k of its row as one float4, so the MFMA of element e multiplies k = 8 j + e (lanes 0-31) and 8 j + 4 + e.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int F32_BM = 128, F32_BK = 16, F32_LDT = 20;
+
+template <int BN>
+__global__ __launch_bounds__(256) void f32_igemm_kernel(F32GemmParams p) {
+    constexpr int NB = BN / 64;          // 32-column blocks per wave
+    __shared__ float As[2][F32_BM * F32_LDT];
+    __shared__ float Bs[2][BN * F32_LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int t = igemm_xcd_remap((int)blockIdx.x, p.tiles_m * p.tiles_n);          // an XCD owns a contiguous run of row tiles
+    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m0 = tm * F32_BM, n0 = tn * BN;
+    const int lr = tid >> 2, kq = (tid & 3) * 4;
+    const bool pointwise = p.KH == 1 && p.KW == 1 && p.pad == 0;
+
+    // this thread's two A rows
+    long abase[2];
+    int ay[2], ax[2];
+    bool aok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + lr + 64 * i;
+        aok[i] = m < p.M;
+        const int mm = aok[i] ? m : 0;
+        const int ox = mm % p.Wo;
+        const int t2 = mm / p.Wo;
+        const int oy = t2 % p.Ho;
+        const int img = t2 / p.Ho;
+        ay[i] = oy * p.stride - p.pad;
+        ax[i] = ox * p.stride - p.pad;
+        abase[i] = (long)img * p.H * p.W;
+    }
+    const float* wrow[NB];
+    bool wok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + lr + 64 * i;
+        wok[i] = n < p.Cout;
+        wrow[i] = p.w + (long)(wok[i] ? n : 0) * p.Kpad + kq;
+    }
+
+    float4v ra[2], rb[NB];
+    auto fetch = [&](int kt) {
+        const int k = kt * F32_BK + kq;
+        int c = k, ky = 0, kx = 0;
+        if (!pointwise) {
+            const int tap = k / p.Cin;
+            c = k - tap * p.Cin;
+            ky = tap / p.KW;
+            kx = tap - ky * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = ay[i] + ky, ix = ax[i] + kx;
+            const bool ok = aok[i] && k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            ra[i] = (float4v){0.f, 0.f, 0.f, 0.f};
+            if (ok) ra[i] = *reinterpret_cast<const float4v*>(p.in + (abase[i] + (long)iy * p.W + ix) * p.Cin + c);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            rb[i] = (float4v){0.f, 0.f, 0.f, 0.f};
+            if (wok[i]) rb[i] = *reinterpret_cast<const float4v*>(wrow[i] + kt * F32_BK);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4v*>(&As[buf][(lr + 64 * i) * F32_LDT + kq]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4v*>(&Bs[buf][(lr + 64 * i) * F32_LDT + kq]) = rb[i];
+    };
+
+    float16v acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = p.Kpad / F32_BK;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int fr = lane & 31, fk = (lane >> 5) * 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch(kt + 1);
+        float4v a[2][2], b[NB][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) a[mb][j] = *reinterpret_cast<const float4v*>(&As[buf][(wm * 64 + mb * 32 + fr) * F32_LDT + j * 8 + fk]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[nb][j] = *reinterpret_cast<const float4v*>(&Bs[buf][(wn * (BN / 2) + nb * 32 + fr) * F32_LDT + j * 8 + fk]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_f32(a[mb][j][e], b[nb][j][e], acc[mb][nb]);
+        if (kt + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue straight from the accumulator layout: register r of a block = row (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3), column
+    // lane & 31 -- a store instruction writes two rows x 32 consecutive floats
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + wn * (BN / 2) + nb * 32 + fr;
+        if (n >= p.Cout) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mb * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                if (m >= p.M) continue;
+                float v = acc[mb][nb][r] + bias;
+                if (p.res_mode == 1) {
+                    v += p.res[(long)m * p.Cout + n];
+                } else if (p.res_mode == 2) {
+                    const int ox = m % p.Wo;
+                    const int t2 = m / p.Wo;
+                    const int oy = t2 % p.Ho;
+                    const int img = t2 / p.Ho;
+                    v += p.res[((long)(img * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + n];
+                }
+                if (p.relu == 1) v = fmaxf(v, 0.f);
+                else if (p.relu == 2) v = gelu_erf(v);
+                p.out[(long)m * p.ldc + n] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// elementwise
+// ---------------------------------------------------------------------------------------------------------------------------------
+// fp32 NCHW frames in [0, 1] (a table of per-frame pointers, as csrc/elementwise.hip) -> normalised fp32 NHWC4 (channel 3 zero).
+// (x - mean) / std as the reference's normalizer divides (diffusion_det.py:301-303).
+__global__ void f32_prep_images_kernel(FrameTable in, float* __restrict__ out, long npix, long hw, float m0, float m1, float m2, float s0,
+                                       float s1, float s2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const long img = i / hw, pix = i - img * hw;
+    const float* q = in.p[img] + pix;
+    *reinterpret_cast<float4v*>(out + i * 4) = (float4v){(q[0] - m0) / s0, (q[hw] - m1) / s1, (q[2 * hw] - m2) / s2, 0.f};
+}
+
+__global__ void f32_maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h, int w, int c, int ho, int wo) {
+    const int cv = c >> 2;
+    const long total = (long)n * ho * wo * cv;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int v = i % cv;
+    long t = i / cv;
+    const int ox = t % wo;
+    t /= wo;
+    const int oy = t % ho;
+    const int img = t / ho;
+    float4v best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox * 2 - 1 + dx;
+            if ((unsigned)ix >= (unsigned)w) continue;
+            const float4v x = *reinterpret_cast<const float4v*>(in + (((long)img * h + iy) * w + ix) * c + v * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], x[e]);
+        }
+    }
+    *reinterpret_cast<float4v*>(out + i * 4) = best;
+}
+
+__global__ void f32_silu_kernel(const float* __restrict__ x, float* __restrict__ y, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4v v = *reinterpret_cast<const float4v*>(x + i * 4);
+    float4v o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = v[e] / (1.f + expf(-v[e]));
+    *reinterpret_cast<float4v*>(y + i * 4) = o;
+}
+
+// box_head.py:533-536 / :643-647: fc = x * (scale + 1) + shift
+__global__ void f32_modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale, int scale_ld, const float* __restrict__ shift,
+                                    int shift_per_row, int shift_ld, float* __restrict__ y, long n4, int rows_per_frame, int d) {
+#pragma clang fp contract(off)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int dv = d >> 2;
+    const long row = i / dv;
+    const int col = (int)(i - row * dv) * 4;
+    const long frame = row / rows_per_frame;
+    const float4v v = *reinterpret_cast<const float4v*>(x + i * 4);
+    const float4v sc = *reinterpret_cast<const float4v*>(scale + frame * scale_ld + col);
+    const float4v sh = *reinterpret_cast<const float4v*>(shift + (shift_per_row ? row : frame) * shift_ld + col);
+    float4v o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = v[e] * (sc[e] + 1.f) + sh[e];
+    *reinterpret_cast<float4v*>(y + i * 4) = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// RoIAlignV2 (aligned, 7 x 7 bins, 2 x 2 samples), fp32 pyramids: csrc/roialign.hip's kernel with fp32 taps -- one workgroup per box,
+// 32 lanes x 8 channels cover a tap's 256 channels, the 8 lane groups walk the 49 bins
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int RP = 7, RG = 2;
+
+struct Tap32 {
+    int lo, hi;
+    float wl, wh;
+    bool ok;
+};
+__device__ __forceinline__ Tap32 axis_tap32(float y, int limit) {          // torchvision bilinear_interpolate, one axis
+    Tap32 t;
+    t.ok = !(y < -1.0f || y > (float)limit);
+    if (y <= 0.f) y = 0.f;
+    int lo = (int)y;
+    int hi;
+    if (lo >= limit - 1) {
+        hi = lo = limit - 1;
+        y = (float)lo;
+    } else {
+        hi = lo + 1;
+    }
+    const float l = y - (float)lo;
+    t.lo = lo;
+    t.hi = hi;
+    t.wl = 1.f - l;
+    t.wh = l;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void f32_roialign_kernel(RoiLevels32 lv, const float* __restrict__ boxes, int boxes_per_img,
+                                                            float* __restrict__ roi_out, float* __restrict__ mean_out, int nbox) {
+#pragma clang fp contract(off)
+    __shared__ float red[8][256];
+    const int box = igemm_xcd_remap((int)blockIdx.x, nbox);
+    const int img = box / boxes_per_img;
+    const int tid = threadIdx.x;
+    const int grp = tid >> 5, ln = tid & 31;
+    const float bx1 = boxes[box * 4 + 0], by1 = boxes[box * 4 + 1], bx2 = boxes[box * 4 + 2], by2 = boxes[box * 4 + 3];
+    const float area = (bx2 - bx1) * (by2 - by1);          // detectron2 assign_boxes_to_levels (canonical 224 / level 4, levels 3..5)
+    const bool valid_box = area >= 0.f;
+    float lvf = floorf(4.f + log2f(sqrtf(area) / 224.f + 1e-8f));
+    lvf = fminf(fmaxf(lvf, 3.f), 5.f);
+    const int level = valid_box ? (int)lvf - 3 : 0;
+    const int H = lv.h[level], W = lv.w[level];
+    const float sc = lv.scale[level];
+    const float* feat = lv.feat[level] + (long)img * H * W * 256;
+    const float x1 = bx1 * sc - 0.5f, y1 = by1 * sc - 0.5f;
+    const float x2 = bx2 * sc - 0.5f, y2 = by2 * sc - 0.5f;
+    const float bin_w = (x2 - x1) / RP, bin_h = (y2 - y1) / RP;
+    float macc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) macc[e] = 0.f;
+    for (int pb = grp; pb < RP * RP; pb += 8) {
+        const int ph = pb / RP, pw = pb - ph * RP;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (valid_box) {
+#pragma unroll
+            for (int iy = 0; iy < RG; ++iy) {
+                const float y = y1 + ph * bin_h + (iy + 0.5f) * bin_h / RG;
+                const Tap32 ty = axis_tap32(y, H);
+#pragma unroll
+                for (int ix = 0; ix < RG; ++ix) {
+                    const float x = x1 + pw * bin_w + (ix + 0.5f) * bin_w / RG;
+                    const Tap32 tx = axis_tap32(x, W);
+                    if (!(ty.ok && tx.ok)) continue;
+                    const float w4[4] = {ty.wl * tx.wl, ty.wl * tx.wh, ty.wh * tx.wl, ty.wh * tx.wh};
+                    const long o4[4] = {(long)ty.lo * W + tx.lo, (long)ty.lo * W + tx.hi, (long)ty.hi * W + tx.lo, (long)ty.hi * W + tx.hi};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4v a = *reinterpret_cast<const float4v*>(feat + o4[q] * 256 + ln * 8);
+                        const float4v b = *reinterpret_cast<const float4v*>(feat + o4[q] * 256 + ln * 8 + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[e] += w4[q] * a[e];
+                            acc[4 + e] += w4[q] * b[e];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[e] *= 1.f / (RG * RG);
+            macc[e] += acc[e];
+        }
+        float* o = roi_out + ((long)box * (RP * RP) + pb) * 256 + ln * 8;
+        *reinterpret_cast<float4v*>(o) = (float4v){acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<float4v*>(o + 4) = (float4v){acc[4], acc[5], acc[6], acc[7]};
+    }
+    if (mean_out) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[grp][ln * 8 + e] = macc[e];
+        __syncthreads();
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += red[g][tid];
+        mean_out[(long)box * 256 + tid] = s / (RP * RP);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// attention, head dim 32: out[b][q][h*32 ..] = softmax_k(q . k / sqrt(32)) v.  One query per lane (its 32 q values and 32 output
+// accumulators in registers), keys and values in chunks of 64 through LDS (every lane reads the same key: broadcast reads), the
+// running maximum / sum of the streaming softmax updated once per 16 keys.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void f32_mha_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                     float* __restrict__ out, int lq, int lk, int q_ld, int kv_ld, int out_ld, long q_bs,
+                                                     long kv_bs, long out_bs, float scale) {
+    __shared__ float Ks[64 * 32];
+    __shared__ float Vs[64 * 32];
+    const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int qi = blockIdx.x * 64 + tid;
+    const bool live = qi < lq;
+    float qv[32], acc[32];
+    {
+        const float* qp = q + b * q_bs + (long)(live ? qi : 0) * q_ld + head * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4v t = *reinterpret_cast<const float4v*>(qp + j * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qv[j * 4 + e] = t[e] * scale;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc[e] = 0.f;
+    float mx = -INFINITY, den = 0.f;
+    const float* kb = k + b * kv_bs + head * 32;
+    const float* vb = v + b * kv_bs + head * 32;
+    for (int k0 = 0; k0 < lk; k0 += 64) {
+        const int nk = lk - k0 < 64 ? lk - k0 : 64;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {          // 64 keys x 8 float4: lane -> (key = (i * 64 + tid) / 8, quarter = .. % 8)
+            const int idx = i * 64 + tid, kr = idx >> 3, c4 = (idx & 7) * 4;
+            float4v kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (kr < nk) {
+                kk = *reinterpret_cast<const float4v*>(kb + (long)(k0 + kr) * kv_ld + c4);
+                vv = *reinterpret_cast<const float4v*>(vb + (long)(k0 + kr) * kv_ld + c4);
+            }
+            *reinterpret_cast<float4v*>(&Ks[kr * 32 + c4]) = kk;
+            *reinterpret_cast<float4v*>(&Vs[kr * 32 + c4]) = vv;
+        }
+        __syncthreads();
+        // sub-chunks of 16 keys: scores into registers, one maximum / rescale per sub-chunk, then the weighted values
+#pragma unroll 1
+        for (int c0 = 0; c0 < nk; c0 += 16) {
+            float sc16[16];
+            float cmx = -INFINITY;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4v t = *reinterpret_cast<const float4v*>(&Ks[(c0 + kk) * 32 + j * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d = __builtin_fmaf(qv[j * 4 + e], t[e], d);
+                }
+                sc16[kk] = c0 + kk < nk ? d : -INFINITY;
+                cmx = fmaxf(cmx, sc16[kk]);
+            }
+            const float nmx = fmaxf(mx, cmx);
+            const float rescale = expf(mx - nmx);          // first sub-chunk: exp(-inf) = 0 on zero accumulators
+            den *= rescale;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) acc[e] *= rescale;
+            mx = nmx;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const float pr = expf(sc16[kk] - mx);          // masked keys: exp(-inf) = 0
+                den += pr;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4v t = *reinterpret_cast<const float4v*>(&Vs[(c0 + kk) * 32 + j * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j * 4 + e] = __builtin_fmaf(pr, t[e], acc[j * 4 + e]);
+                }
+            }
+        }
+    }
+    if (live) {
+        const float inv = 1.f / den;
+        float* op = out + b * out_bs + (long)qi * out_ld + head * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            *reinterpret_cast<float4v*>(op + j * 4) = (float4v){acc[j * 4] * inv, acc[j * 4 + 1] * inv, acc[j * 4 + 2] * inv, acc[j * 4 + 3] * inv};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// DynamicConv (box_head.py:687-711), one workgroup per box: F1 = roi[49 x 256] . param1[256 x 64] -> LayerNorm(64) + ReLU ->
+// F2 = F1 . param2[64 x 256] -> LayerNorm(256) + ReLU -> out[49 x 256].  The per-box parameters arrive as P1T[64][256] | P2T[256][64]
+// ([N][K] rows, the row order csrc/model.hip gives dynamic_layer), so both MFMA operands are K-contiguous rows read straight from
+// global as float4 fragments; F1 / F2 cross LDS for the row statistics.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int DC_P1 = 68, DC_P2 = 260;
+__global__ __launch_bounds__(256) void f32_dynconv_kernel(const float* __restrict__ roi, const float* __restrict__ params,
+                                                           const float* __restrict__ g1, const float* __restrict__ b1,
+                                                           const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ out,
+                                                           int nbox) {
+#pragma clang fp contract(off)
+    __shared__ float F1[64 * DC_P1];
+    __shared__ float F2[49 * DC_P2];
+    const int box = igemm_xcd_remap((int)blockIdx.x, nbox);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = (lane >> 5) * 4;
+    const float* x = roi + (long)box * 49 * 256;
+    const float* p1 = params + (long)box * 32768;
+    const float* p2 = p1 + 64 * 256;
+
+    // the second product's parameter fragments are requested first: they land under the first product
+    float4v w2[2][8];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w2[nb][j] = *reinterpret_cast<const float4v*>(p2 + (long)((wave * 2 + nb) * 32 + fr) * 64 + j * 8 + fk);
+
+    // ---- product 1: wave = (row block mb, column block nb) of the 64 x 64 result, K = 256 in four chunks of 64
+    {
+        const int mb = wave >> 1, nb = wave & 1;
+        const int prow = mb * 32 + fr;
+        const bool pok = prow < 49;
+        const float* ap = x + (long)(pok ? prow : 0) * 256 + fk;
+        const float* bp = p1 + (long)(nb * 32 + fr) * 256 + fk;
+        float16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float4v a[2][8], b[2][8];
+        auto fetch = [&](int c, int buf) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a[buf][j] = pok ? *reinterpret_cast<const float4v*>(ap + c * 64 + j * 8) : (float4v){0.f, 0.f, 0.f, 0.f};
+                b[buf][j] = *reinterpret_cast<const float4v*>(bp + c * 64 + j * 8);
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c + 1 < 4) fetch(c + 1, (c + 1) & 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma_f32(a[c & 1][j][e], b[c & 1][j][e], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) F1[(mb * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3)) * DC_P1 + nb * 32 + fr] = acc[r];
+    }
+    __syncthreads();
+    // ---- LayerNorm(64) + ReLU on rows 0..48: four lanes per row, 16 values each
+    if (tid < 49 * 4) {
+        const int row = tid >> 2, part = tid & 3;
+        float* rp = &F1[row * DC_P1 + part * 16];
+        float vals[16], sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            vals[e] = rp[e];
+            sum += vals[e];
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        const float mean = sum / 64.f;
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float t = vals[e] - mean;
+            sq += t * t;
+        }
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        const float rstd = rsqrtf(sq / 64.f + 1e-5f);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rp[e] = fmaxf((vals[e] - mean) * rstd * g1[part * 16 + e] + b1[part * 16 + e], 0.f);
+    }
+    __syncthreads();
+    // ---- product 2: wave w owns columns [64 w, 64 w + 64) of the 64 x 256 result, K = 64
+    {
+        float16v acc[2][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4v a[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const float4v*>(&F1[(mb * 32 + fr) * DC_P1 + j * 8 + fk]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma_f32(a[mb][e], w2[nb][j][e], acc[mb][nb]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mb * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                    if (row < 49) F2[row * DC_P2 + (wave * 2 + nb) * 32 + fr] = acc[mb][nb][r];
+                }
+    }
+    __syncthreads();
+    // ---- LayerNorm(256) + ReLU, one wave per row, 4 values per lane; rows go straight to global
+    const float4v gg = *reinterpret_cast<const float4v*>(g2 + lane * 4);
+    const float4v bb = *reinterpret_cast<const float4v*>(b2 + lane * 4);
+    for (int row = wave; row < 49; row += 4) {
+        const float4v t = *reinterpret_cast<const float4v*>(&F2[row * DC_P2 + lane * 4]);
+        const float mean = wave_sum(t[0] + t[1] + t[2] + t[3]) / 256.f;
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = t[e] - mean;
+            sq += u * u;
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / 256.f + 1e-5f);
+        float4v o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf((t[e] - mean) * rstd * gg[e] + bb[e], 0.f);
+        *reinterpret_cast<float4v*>(out + ((long)box * 49 + row) * 256 + lane * 4) = o;
+    }
+}
+
+}  // namespace
+
+// =================================================================================================================================
+int dvid_f32_igemm_launch(const F32GemmParams& p0, hipStream_t s) {
+    F32GemmParams p = p0;
+    if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
+    if (p.Cin % 4 || p.Kpad % F32_BK || p.K > p.Kpad || p.ldc < p.Cout) return DVID_ERR_ARG;
+    if (p.res_mode == 2 && ((p.Ho | p.Wo) & 1)) return DVID_ERR_ARG;
+    p.tiles_m = ceil_div(p.M, F32_BM);
+    if (p.Cout <= 64) {
+        p.tiles_n = ceil_div(p.Cout, 64);
+        hipLaunchKernelGGL(f32_igemm_kernel<64>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+    } else {
+        p.tiles_n = ceil_div(p.Cout, 128);
+        hipLaunchKernelGGL(f32_igemm_kernel<128>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+    }
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_f32_prep_images_launch(const float* const* frames, float* nhwc4, int n, int h, int w, const float* mean, const float* std_,
+                                hipStream_t s) {
+    const long hw = (long)h * w;
+    for (int f0 = 0; f0 < n; f0 += FrameTable::kMax) {
+        const int nf = n - f0 < FrameTable::kMax ? n - f0 : FrameTable::kMax;
+        FrameTable tab;
+        for (int i = 0; i < FrameTable::kMax; ++i) tab.p[i] = frames[f0 + (i < nf ? i : 0)];
+        const long npix = hw * nf;
+        hipLaunchKernelGGL(f32_prep_images_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, tab, nhwc4 + (long)f0 * hw * 4, npix, hw,
+                           mean[0], mean[1], mean[2], std_[0], std_[1], std_[2]);
+        LAUNCH_CHECK();
+    }
+    return DVID_OK;
+}
+
+int dvid_f32_maxpool3x3s2_launch(const float* in, float* out, int n, int h, int w, int c, hipStream_t s) {
+    if (c % 4) return DVID_ERR_ARG;
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long total = (long)n * ho * wo * (c / 4);
+    hipLaunchKernelGGL(f32_maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, n, h, w, c, ho, wo);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_f32_silu_launch(const float* x, float* y, long n, hipStream_t s) {
+    if (n % 4) return DVID_ERR_ARG;
+    hipLaunchKernelGGL(f32_silu_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, y, n / 4);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_f32_modulate_launch(const float* x, const float* scale, int scale_ld, const float* shift, int shift_per_row, int shift_ld, float* y,
+                             int rows, int rows_per_frame, int d, hipStream_t s) {
+    if (d % 4) return DVID_ERR_ARG;
+    const long n4 = (long)rows * d / 4;
+    hipLaunchKernelGGL(f32_modulate_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, scale, scale_ld, shift, shift_per_row, shift_ld,
+                       y, n4, rows_per_frame, d);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_f32_roialign_launch(const RoiLevels32& lv, int channels, const float* boxes, int n_img, int boxes_per_img, float* roi_out,
+                             float* mean_out, hipStream_t s) {
+    if (channels != 256) return DVID_ERR_UNSUPPORTED;
+    const int nbox = n_img * boxes_per_img;
+    if (nbox == 0) return DVID_OK;
+    hipLaunchKernelGGL(f32_roialign_kernel, dim3(nbox), dim3(256), 0, s, lv, boxes, boxes_per_img, roi_out, mean_out, nbox);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_f32_mha_launch(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int q_ld, int kv_ld,
+                        int out_ld, long q_bs, long kv_bs, long out_bs, hipStream_t s) {
+    if (batch <= 0 || lq <= 0) return DVID_OK;
+    if (lk <= 0 || nheads <= 0 || (q_ld | kv_ld | out_ld) % 4) return DVID_ERR_ARG;
+    hipLaunchKernelGGL(f32_mha_kernel, dim3(ceil_div(lq, 64), nheads, batch), dim3(64), 0, s, q, k, v, out, lq, lk, q_ld, kv_ld, out_ld, q_bs, kv_bs,
+                       out_bs, 0.17677669529663688110f);          // 1 / sqrt(32)
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_f32_dynconv_launch(const float* roi, const float* params, const float* g1, const float* b1, const float* g2, const float* b2,
+                            float* out, int rows, hipStream_t s) {
+    if (rows <= 0) return DVID_OK;
+    hipLaunchKernelGGL(f32_dynconv_kernel, dim3(rows), dim3(256), 0, s, roi, params, g1, b1, g2, b2, out, rows);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}

@@ -194,8 +194,7 @@ int dvid_fps_launch(const float* dist, int n, int m, int bs_emul, int* idx, hipS
     int bits = 0;
     while ((1 << bits) < bs) ++bits;
     if ((1 << bits) != bs) return DVID_ERR_ARG;
-    static const bool lds_form = getenv("DVID_FPS_LDS") && atoi(getenv("DVID_FPS_LDS")) != 0;          // A/B: the round-1 kernel
-    if (!lds_form && n <= 256 * 16) {
+    if (n <= 256 * 16) {          // the register kernel; larger inputs take the LDS form below
         const int ept = (n + 255) / 256;
         if (ept <= 4) hipLaunchKernelGGL(fps_reg_kernel<4>, dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);
         else if (ept <= 8) hipLaunchKernelGGL(fps_reg_kernel<8>, dim3(1), dim3(256), 0, s, dist, n, m, bs, bits, idx);

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "igemm_epilogue.h"
 #include "kernels.h"
+#include "options.h"
 
 namespace {
 
@@ -509,10 +510,9 @@ int launch2(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.Cout, BN);
-    // DVID_IGEMM_GENERIC=1 (read per launch): always the general addressing + general epilogue -- the parity tests
-    // compare the specialised paths against it bit for bit
-    const char* g = getenv("DVID_IGEMM_GENERIC");
-    const bool generic = g && g[0] == '1';
+    // option igemm_generic = 1: always the general addressing + general epilogue -- the parity tests compare the specialised
+    // paths against it bit for bit
+    const bool generic = g_opt.igemm_generic != 0;
     const int epi = generic ? 0 : epilogue_kind(p);
     if constexpr (SMALLC) {
         return epi == 1 ? launch2k<BM, BN, BKT, NSTAGE, WN, 1, 1>(p, s) : launch2k<BM, BN, BKT, NSTAGE, WN, 1, 0>(p, s);
@@ -564,8 +564,6 @@ const TileCfg kStemCfgs[] = {   // Cin == 8 stem (one filter tap per 16-byte chu
 };
 
 bool cfg_valid(const TileCfg& c, const IgemmParams& p) {
-    static const int no_stage = getenv("DVID_IGEMM_NO_NSTAGE") ? atoi(getenv("DVID_IGEMM_NO_NSTAGE")) : -1;   // A/B measurements
-    if (c.nstage == no_stage) return false;
     if (p.splitk > 1 && (p.Kpad / c.bkt) % p.splitk) return false;
     if (c.bm > 128 && p.M < 2 * c.bm) return false;
     if (c.bn > 64 && p.Cout <= c.bn / 2) return false;          // more than half of the tile would be padding
@@ -605,7 +603,6 @@ struct ShapeHash {
     }
 };
 std::mutex g_tune_mu;
-int g_forced_cfg = -2;          // -2: follow DVID_IGEMM_CFG; -1: tuner; >= 0: forced table index
 std::unordered_map<ShapeKey, int, ShapeHash> g_tuned;
 
 // DVID_IGEMM_TUNE_CACHE=<file>: winners are appended as they are found and read back at the first launch of the next
@@ -664,7 +661,7 @@ int tune_shape(const IgemmParams& p, hipStream_t s, const TileCfg* cfgs, int ncf
     }
     IgemmParams q = p;
     q.out = g_tune_scratch;
-    static const bool log = getenv("DVID_IGEMM_TUNE_LOG") != nullptr;
+    constexpr bool log = false;          // (set to true to print every timing of the tuner)
     int best = fallback;
     float best_ms = 1e30f;
     for (int c = 0; c < ncfg; ++c) {
@@ -740,39 +737,35 @@ int nearest_bucket_cfg(const ShapeKey& k, const TileCfg* cfgs) {
     return best;
 }
 
-int g_tune_mode = -1;            // -1: follow DVID_IGEMM_TUNE (default on); 0: never time on the serving path; 1: time new shape buckets
-
 }  // namespace
 
 int dvid_igemm_num_configs(void) { return kNumCfg; }
 
 int dvid_igemm_set_config(int cfg) {
     if (cfg < -1 || cfg >= kNumCfg) return DVID_ERR_ARG;
-    g_forced_cfg = cfg;
+    g_opt.igemm_cfg = cfg;
     return DVID_OK;
 }
 
 int dvid_igemm_set_tuning(int mode) {
     if (mode < -1 || mode > 1) return DVID_ERR_ARG;
-    g_tune_mode = mode;
+    g_opt.igemm_tune = mode;
     return DVID_OK;
 }
 
-// 3x3 / stride-1 layers on the halo-staged kernel (conv3x3.hip): -1 = DVID_CONV3X3_HALO or on, 0 = off, 1 = on where the shape
-// rule prefers it, 2 = on wherever the layer type fits (tests)
-static int g_halo_mode = -1;
+// 3x3 / stride-1 layers on the halo-staged kernel (conv3x3.hip): 0 = off, 1 = on where the shape rule prefers it, 2 = on wherever the
+// layer type fits (tests), -1 = the default (1)
 int dvid_igemm_set_conv3x3(int mode) {
     if (mode < -1 || mode > 2) return DVID_ERR_ARG;
-    g_halo_mode = mode;
+    g_opt.conv3x3 = mode < 0 ? DvidOptions().conv3x3 : mode;
     return DVID_OK;
 }
 
-// short-K / wide-N 1x1 layers on the weight-stationary kernel (wstat.hip): -1 = DVID_WSTAT or on, 0 = off, 1 = on where the shape rule
-// prefers it, 2 = on wherever the layer type fits (tests).  Bit-identical to igemm2, so the rule may look at the row count.
-static int g_wstat_mode = -1;
+// short-K / wide-N 1x1 layers on the weight-stationary kernel (wstat.hip): 0 = off, 1 = on where the shape rule prefers it, 2 = on
+// wherever the layer type fits (tests), -1 = the default (1).  Bit-identical to igemm2, so the rule may look at the row count.
 int dvid_igemm_set_wstat(int mode) {
     if (mode < -1 || mode > 2) return DVID_ERR_ARG;
-    g_wstat_mode = mode;
+    g_opt.wstat = mode < 0 ? DvidOptions().wstat : mode;
     return DVID_OK;
 }
 
@@ -780,10 +773,8 @@ int dvid_igemm_launch(const IgemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
     if (p.Kpad % 64 != 0 || p.Kpad < 64) return DVID_ERR_ARG;
     {
-        static const int ws_env = getenv("DVID_WSTAT") ? atoi(getenv("DVID_WSTAT")) : 1;
-        static const int cfg_forced_env0 = getenv("DVID_IGEMM_CFG") ? atoi(getenv("DVID_IGEMM_CFG")) : -1;
-        const bool forced = g_forced_cfg >= 0 || (g_forced_cfg < -1 && cfg_forced_env0 >= 0);
-        const int ws = g_wstat_mode >= 0 ? g_wstat_mode : ws_env;
+        const bool forced = g_opt.igemm_cfg >= 0;
+        const int ws = g_opt.wstat;
         if (ws && !forced && (ws >= 2 ? dvid_wstat_supported(p) : dvid_wstat_preferred(p))) return dvid_wstat_launch(p, s);
     }
     return dvid_igemm2_launch(p, s);
@@ -795,10 +786,8 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
     {
         // a function of the shape only -- never of a timing: the two kernels sum the same products in different orders.  A forced
         // tile configuration (the bit-identity tests, experiments) means the igemm2 kernel.
-        static const int halo_env = getenv("DVID_CONV3X3_HALO") ? atoi(getenv("DVID_CONV3X3_HALO")) : 1;
-        static const int cfg_forced_env = getenv("DVID_IGEMM_CFG") ? atoi(getenv("DVID_IGEMM_CFG")) : -1;
-        const bool forced = g_forced_cfg >= 0 || (g_forced_cfg < -1 && cfg_forced_env >= 0);
-        const int halo = g_halo_mode >= 0 ? g_halo_mode : halo_env;
+        const bool forced = g_opt.igemm_cfg >= 0;
+        const int halo = g_opt.conv3x3;
         if (halo && !forced && (halo >= 2 ? dvid_conv3x3_halo_supported(p) : dvid_conv3x3_halo_preferred(p))) return dvid_conv3x3_halo_launch(p, s);
     }
     const bool smallc = ((p.Cin == 8 || p.Cin == 16) && p.KH * p.KW > 1);
@@ -807,10 +796,10 @@ int dvid_igemm2_launch(const IgemmParams& p, hipStream_t s) {
     if (p.splitk > 1 && (!p.out_f32 || p.bias || p.relu || p.res_mode || smallc || (p.Kpad / 64) % p.splitk)) return DVID_ERR_ARG;
     const TileCfg* cfgs = smallc ? kStemCfgs : kCfgs;
     const int ncfg = smallc ? 2 : kNumCfg;
-    // DVID_IGEMM_CFG=<index into the table> / dvid_igemm_set_config() force one configuration for every layer it is
-    // valid for (parity tests compare configurations bit for bit; experiments)
-    static const int cfg_env0 = getenv("DVID_IGEMM_CFG") ? atoi(getenv("DVID_IGEMM_CFG")) : -1;
-    const int cfg_env = g_forced_cfg >= -1 ? g_forced_cfg : cfg_env0;
+    // dvid_igemm_set_config() forces one configuration for every layer it is valid for (parity tests compare configurations bit
+    // for bit; experiments)
+    const int cfg_env = g_opt.igemm_cfg;
+    const int g_tune_mode = g_opt.igemm_tune;
     static const bool tune_env = !(getenv("DVID_IGEMM_TUNE") && atoi(getenv("DVID_IGEMM_TUNE")) == 0);
     const bool tune = g_tune_mode < 0 ? tune_env : true;         // mode 0 still uses cached / preloaded winners
     int fallback = smallc ? (p.Kpad >= 512 ? 1 : 0) : heuristic_cfg(p);

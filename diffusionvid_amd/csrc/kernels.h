@@ -156,3 +156,35 @@ int dvid_nms_frames_launch(const float* cand_boxes, const float* cand_scores, co
 int dvid_cdist_launch(const float* x, int n, int d, float* dist, hipStream_t s);
 int dvid_fps_launch(const float* dist, int n, int m, int bs_emul, int* idx, hipStream_t s);
 int dvid_gather_rows_launch(const float* x, const int* idx, float* y, int m, int d, hipStream_t s);
+
+// f32.hip: the DTYPE float32 path (fp32 storage, v_mfma_f32_32x32x2_f32 products)
+struct F32GemmParams {
+    const float* in;     // NHWC fp32 [N,H,W,Cin], Cin % 4 == 0  (Linear: [M,K] as N = M, H = W = 1, Cin = K)
+    const float* w;      // [Cout][Kpad], k = (ky*KW + kx)*Cin + c, zero beyond K; Kpad % 16 == 0
+    const float* bias;   // [Cout] or nullptr
+    const float* res;    // fp32 residual, see res_mode
+    float* out;          // [M][ldc]
+    int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int M, K, Kpad, ldc;
+    int relu, res_mode;  // relu: 0 none, 1 ReLU, 2 exact GELU; res_mode: 0 none, 1 same shape, 2 nearest-x2 upsample
+    int tiles_m, tiles_n;   // filled by the launcher
+};
+int dvid_f32_igemm_launch(const F32GemmParams& p, hipStream_t s);
+struct RoiLevels32 {
+    const float* feat[3];
+    int h[3], w[3];
+    float scale[3];
+};
+int dvid_f32_prep_images_launch(const float* const* frames, float* nhwc4, int n, int h, int w, const float* mean, const float* std_, hipStream_t s);
+int dvid_f32_maxpool3x3s2_launch(const float* in, float* out, int n, int h, int w, int c, hipStream_t s);
+int dvid_f32_silu_launch(const float* x, float* y, long n, hipStream_t s);
+int dvid_f32_modulate_launch(const float* x, const float* scale, int scale_ld, const float* shift, int shift_per_row, int shift_ld, float* y,
+                             int rows, int rows_per_frame, int d, hipStream_t s);
+int dvid_f32_roialign_launch(const RoiLevels32& lv, int channels, const float* boxes, int n_img, int boxes_per_img, float* roi_out,
+                             float* mean_out, hipStream_t s);
+// q / k / v fp32 with head h at columns [32 h, 32 h + 32) of a row (head dim 32)
+int dvid_f32_mha_launch(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int q_ld, int kv_ld,
+                        int out_ld, long q_bs, long kv_bs, long out_bs, hipStream_t s);
+// roi [R][49][256], params [R][32768] as P1T[64][256] | P2T[256][64], out [R][49][256]
+int dvid_f32_dynconv_launch(const float* roi, const float* params, const float* g1, const float* b1, const float* g2, const float* b2,
+                            float* out, int rows, hipStream_t s);

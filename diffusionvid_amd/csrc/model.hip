@@ -13,6 +13,9 @@
 #include "../../include/dvid_hip.h"
 #include "common.h"
 #include "kernels.h"
+#include "options.h"
+
+DvidOptions g_opt;          // csrc/options.h: the library-wide option table (defaults = the benchmarked configuration)
 
 namespace {
 
@@ -146,8 +149,6 @@ int bneck128_tail(const half_t* t1, const half_t* w2, const float* b2, const hal
     return rc;
 }
 
-int g_stem_pool_mode = -1;          // dvid_set_stem_pool: -1 follow DVID_STEM_POOL (default 1), 0 two launches, 1 one launch
-
 // A launch outside the implicit-GEMM family (RoIAlign, DynamicConv, attention, the head tail, max pool) as a record of the per-kernel
 // table: `rows` units, algorithmic FLOP and bytes of the whole launch.  Not part of the family's sums unless `family`.
 template <typename F>
@@ -221,6 +222,9 @@ struct ConvW {   // conv or linear weights in MFMA-operand layout
     int cin_real = 0;  // un-padded input channels (algorithmic FLOP count)
     bool same_size = false;    // output spatial size = input size whatever (kh, pad) say (the space-to-depth stem: pad 2 before, 1 after)
     int alg_k = 0;             // algorithmic K for the FLOP count when the packed layout carries structural zeros (0: kh*kw*cin_real)
+    // DTYPE float32 (csrc/f32.hip): the same rows un-rounded, [cout][kpad32] fp32 with k = (ky*kw + kx)*cin32 + c, cin32 = cin rounded up to 4
+    float* w32 = nullptr;
+    int cin32 = 0, kpad32 = 0;
 };
 // fragment-order copies of the head-tail weights (csrc/headtail.hip)
 struct HeadFrags {
@@ -271,12 +275,13 @@ struct dvid_model {
     dvid_config cfg;
     std::map<std::string, HostTensor> raw;
     bool finalized = false;
+    int precision = 0;         // 0: fp16 storage / fp16 MFMA (DTYPE float16), 1: fp32 storage / fp32 MFMA (DTYPE float32); dvid_model_set_precision
     std::vector<void*> owned;  // device allocations of weights
 
     // backbone
     bool has_backbone = false;
     ConvW stem, stem_s2d;      // NHWC8 7x7/2 form and the 2x2 space-to-depth 4x4/1 form of the same layer
-    bool use_s2d = true;       // DVID_STEM_S2D=0: the NHWC8 form
+    bool use_s2d = true;       // dvid_set_stem_layout(m, 0): the NHWC8 form
     std::vector<Block> blocks[4];
     ConvW lateral[3], output[3];  // index 0 -> level 3
     // Swin backbone (backbone_type 1)
@@ -362,6 +367,21 @@ int make_conv(dvid_model* m, const HostTensor& w, const std::vector<float>& scal
                 }
     }
     TRY(m->upload(packed.data(), packed.size() * sizeof(half_t), reinterpret_cast<void**>(&out->w)));
+    if (m->precision == 1) {          // the un-rounded rows for the fp32 kernels
+        const int c4 = (cin + 3) / 4 * 4, k32 = (kh * kw * c4 + 15) / 16 * 16;
+        std::vector<float> p32((size_t)cout * k32, 0.f);
+        for (int o = 0; o < cout; ++o) {
+            const int so = row_perm ? (*row_perm)[o] : o;
+            const float sc = scale.empty() ? 1.f : scale[so];
+            for (int c = 0; c < cin; ++c)
+                for (int y = 0; y < kh; ++y)
+                    for (int x = 0; x < kw; ++x)
+                        p32[(size_t)o * k32 + (size_t)(y * kw + x) * c4 + c] = w.v[(((size_t)so * cin + c) * kh + y) * kw + x] * sc;
+        }
+        TRY(upload_f32(m, p32, &out->w32));
+        out->cin32 = c4;
+        out->kpad32 = k32;
+    }
     out->bias = nullptr;
     if (!bias.empty()) {
         std::vector<float> b(cout);
@@ -633,6 +653,45 @@ int linear_run(const ConvW& w, const half_t* in, int rows, void* out, int relu, 
     return conv_run(w, in, rows, 1, 1, out, relu, out_f32, nullptr, 0, 0, s);
 }
 
+// ---- DTYPE float32: the same layers on csrc/f32.hip (fp32 NHWC activations, un-rounded weights) ---------------------------------
+int conv_run32(const ConvW& w, const float* in, int n, int h, int wd, float* out, int relu, const float* res, int res_mode, hipStream_t s,
+               int* ho_out = nullptr, int* wo_out = nullptr, int ldc = 0) {
+    if (!w.w32) return DVID_ERR_STATE;
+    F32GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = in;
+    p.w = w.w32;
+    p.bias = w.bias;
+    p.res = res;
+    p.out = out;
+    p.H = h;
+    p.W = wd;
+    p.Cin = w.cin32;
+    p.KH = w.kh;
+    p.KW = w.kw;
+    p.stride = w.stride;
+    p.pad = w.pad;
+    p.Ho = (h + 2 * w.pad - w.kh) / w.stride + 1;
+    p.Wo = (wd + 2 * w.pad - w.kw) / w.stride + 1;
+    p.Cout = w.cout;
+    p.M = n * p.Ho * p.Wo;
+    p.K = w.kh * w.kw * w.cin32;
+    p.Kpad = w.kpad32;
+    p.ldc = ldc ? ldc : w.cout;
+    p.relu = relu;
+    p.res_mode = res_mode;
+    if (ho_out) *ho_out = p.Ho;
+    if (wo_out) *wo_out = p.Wo;
+    const double alg_k = (double)w.kh * w.kw * (w.cin_real ? w.cin_real : w.cin32);
+    const double in_px = (double)p.M * (w.kh * w.kw > 1 ? w.stride * w.stride : 1);
+    const double bytes = 4.0 * (in_px * p.Cin + (double)p.Cout * p.Kpad + (double)p.M * p.Cout * (res_mode == 1 ? 2.0 : res_mode == 2 ? 1.25 : 1.0));
+    return prof_other("igemm_f32", p.M, p.Cout, p.Kpad, 2.0 * p.M * (double)p.Cout * alg_k, bytes, s, [&] { return dvid_f32_igemm_launch(p, s); },
+                      /*family=*/true);
+}
+int linear_run32(const ConvW& w, const float* in, int rows, float* out, int relu, hipStream_t s, int ldc = 0) {
+    return conv_run32(w, in, rows, 1, 1, out, relu, nullptr, 0, s, nullptr, nullptr, ldc);
+}
+
 // detectron2 FPN.forward over three levels (strides 8/16/32): lateral 1x1 (+ nearest-x2 top-down sum fused in the
 // epilogue), 3x3 output conv.  Inputs: m->c3/c4/c5 fp16 NHWC; sh/sw = their heights/widths.
 int run_fpn(dvid_model* m, int n, const int* sh, const int* sw, void* p3, void* p4, void* p5, hipStream_t s) {
@@ -728,9 +787,8 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
     float* obj = f32d;
     TRY(dvid_add_layernorm_launch(x1, f32b, hw.norm2.g, hw.norm2.b, obj, h16a, R, d, 0, s));
     // --- FFN + norm3 + modulation + towers + class_logits + bboxes_delta + apply_deltas: one row-tile kernel (csrc/headtail.hip);
-    // DVID_HEAD_TAIL=0 (A/B measurements) or an unsupported shape takes the layer-by-layer launches below
-    static const bool tail_env = !(getenv("DVID_HEAD_TAIL") && atoi(getenv("DVID_HEAD_TAIL")) == 0);
-    if (tail_env && hw.frag.ok) {
+    // option head_tail = 0 (the fused-vs-layerwise parity test) or an unsupported shape takes the layer-by-layer launches below
+    if (g_opt.head_tail && hw.frag.ok) {
         HeadTailParams q;
         memset(&q, 0, sizeof(q));
         q.x16 = h16a;
@@ -816,6 +874,153 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
     return DVID_OK;
 }
 
+// The same pass with DTYPE float32 (csrc/f32.hip): fp32 RoI tiles, q / k / v, dynamic parameters, hidden layers; layer by layer.
+int rcnn_head_chain_f32(dvid_model* m, const HeadW& hw, int is_cond, const void* p3, const void* p4, const void* p5, int f0, int nf,
+                        int height, int width, int M, const float* boxes_all, const float* pro_all, const float* cond_all,
+                        float* logits_all, float* boxes_out_all, float* obj_all, int* bad_box_flag, const float* ss_all, int ss_stride,
+                        size_t wrow, hipStream_t s) {
+    const int d = m->cfg.hidden_dim, R = nf * M, dd = m->cfg.dim_dynamic, dff = m->cfg.dim_feedforward;
+    const size_t r0 = (size_t)f0 * M;
+    const float* boxes = boxes_all + r0 * 4;
+    const float* pro_features = pro_all ? pro_all + r0 * d : nullptr;
+    const float* cond = cond_all ? cond_all + r0 * d : nullptr;
+    float* logits = logits_all + r0 * m->cfg.num_classes;
+    float* boxes_out = boxes_out_all + r0 * 4;
+    float* obj_features = obj_all + r0 * d;
+    const float* ss_dev = ss_all + (size_t)f0 * ss_stride;
+    float* roi = m->roi.as<float>() + wrow * 49 * d;
+    float* dyn = m->dyn.as<float>() + wrow * 49 * d;
+    float* params = m->params.as<float>() + wrow * 2 * d * dd;
+    float* qkv = m->qkv.as<float>() + wrow * 3 * d;
+    float* attn = m->attn16.as<float>() + wrow * d;
+    float* f32a = m->f32a.as<float>() + wrow * d;
+    float* f32b = m->f32b.as<float>() + wrow * d;
+    float* f32c = m->f32c.as<float>() + wrow * d;
+    float* f32d = m->f32d.as<float>() + wrow * d;
+    float* ha = m->h16a.as<float>() + wrow * d;
+    float* hb = m->h16b.as<float>() + wrow * d;
+    float* hid = m->hid16.as<float>() + wrow * dff;
+    float* deltas = m->deltas.as<float>() + wrow * 4;
+
+    RoiLevels32 lv;
+    const void* pl[3] = {p3, p4, p5};
+    double map_px = 0;
+    for (int l = 0; l < 3; ++l) {
+        lv.h[l] = height >> (3 + l);
+        lv.w[l] = width >> (3 + l);
+        lv.feat[l] = reinterpret_cast<const float*>(pl[l]) + (size_t)f0 * lv.h[l] * lv.w[l] * d;
+        lv.scale[l] = 1.f / (float)(8 << l);
+        map_px += (double)lv.h[l] * lv.w[l];
+    }
+    float* pro32 = f32a;
+    TRY(prof_other("roialign_f32", R, d, 49, 0.0, (double)nf * map_px * d * 4.0 + (double)R * 49 * d * 4.0, s,
+                   [&] { return dvid_f32_roialign_launch(lv, d, boxes, nf, M, roi, pro_features ? nullptr : pro32, s); }));
+    const float* pro = pro_features ? pro_features : pro32;
+    // --- self attention + norm1 (box_head.py:512-517)
+    TRY(linear_run32(hw.in_proj, pro, R, qkv, 0, s));
+    TRY(prof_other("mha_f32", R, d, M, 4.0 * R * (double)M * d, (double)R * d * 4.0 * 4.0, s, [&] {
+        return dvid_f32_mha_launch(qkv, qkv + d, qkv + 2 * d, attn, nf, M, M, m->cfg.nheads, 3 * d, 3 * d, d, (long)M * 3 * d, (long)M * 3 * d,
+                                   (long)M * d, s);
+    }));
+    TRY(linear_run32(hw.out_proj, attn, R, f32b, 0, s));
+    float* x1 = f32c;
+    TRY(dvid_add_layernorm_launch(pro, f32b, hw.norm1.g, hw.norm1.b, x1, nullptr, R, d, 0, s));
+    // --- DynamicConv (box_head.py:687-711)
+    TRY(linear_run32(hw.dynamic_layer, x1, R, params, 0, s));
+    TRY(prof_other("dynconv_f32", R, d, dd, 2.0 * R * 49.0 * d * dd * 2.0, (double)R * (2.0 * 49 * d * 4.0 + 2.0 * d * dd * 4.0), s,
+                   [&] { return dvid_f32_dynconv_launch(roi, params, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn, R, s); }));
+    TRY(linear_run32(hw.out_layer, dyn, R, f32b, 0, s));
+    TRY(dvid_add_layernorm_launch(f32b, nullptr, hw.dc_norm3.g, hw.dc_norm3.b, f32b, nullptr, R, d, 1, s));
+    float* obj = f32d;
+    TRY(dvid_add_layernorm_launch(x1, f32b, hw.norm2.g, hw.norm2.b, obj, nullptr, R, d, 0, s));
+    // --- FFN + norm3
+    TRY(linear_run32(hw.linear1, obj, R, hid, 1, s));
+    TRY(linear_run32(hw.linear2, hid, R, f32b, 0, s));
+    TRY(dvid_add_layernorm_launch(obj, f32b, hw.norm3.g, hw.norm3.b, obj_features, nullptr, R, d, 0, s));
+    // --- time / cond modulation
+    float* fc = ha;
+    if (!is_cond) {
+        TRY(dvid_f32_modulate_launch(obj_features, ss_dev, ss_stride, ss_dev + d, 0, ss_stride, fc, R, M, d, s));
+    } else {
+        TRY(dvid_f32_silu_launch(cond, hb, (long)R * d, s));
+        TRY(linear_run32(hw.c_mlp, hb, R, f32b, 0, s));
+        TRY(dvid_f32_modulate_launch(obj_features, ss_dev, ss_stride, f32b, 1, d, fc, R, M, d, s));
+    }
+    // --- cls tower
+    const float* cur = fc;
+    for (size_t i = 0; i < hw.cls.size(); ++i) {
+        TRY(linear_run32(hw.cls[i], cur, R, f32b, 0, s));
+        TRY(dvid_add_layernorm_launch(f32b, nullptr, hw.cls_ln[i].g, hw.cls_ln[i].b, hb, nullptr, R, d, 1, s));
+        cur = hb;
+    }
+    TRY(linear_run32(hw.class_logits, cur, R, logits, 0, s, m->cfg.num_classes));
+    // --- reg tower
+    cur = fc;
+    float* regbuf[2] = {hb, attn};
+    for (size_t i = 0; i < hw.reg.size(); ++i) {
+        TRY(linear_run32(hw.reg[i], cur, R, f32b, 0, s));
+        TRY(dvid_add_layernorm_launch(f32b, nullptr, hw.reg_ln[i].g, hw.reg_ln[i].b, regbuf[i & 1], nullptr, R, d, 1, s));
+        cur = regbuf[i & 1];
+    }
+    TRY(linear_run32(hw.bboxes_delta, cur, R, deltas, 0, s, 4));
+    TRY(dvid_apply_deltas_launch(deltas, 4, boxes, boxes_out, R, 2.f, 2.f, 1.f, 1.f, logf(100000.f / 16.f), bad_box_flag, s));
+    return DVID_OK;
+}
+
+// detectron2 build_resnet_fpn_backbone with DTYPE float32: normaliser -> NHWC4, BasicStem (7x7 / 2 + FrozenBN folded + ReLU + max pool),
+// the bottleneck stages layer by layer, FPN; every tensor fp32 (csrc/f32.hip)
+int backbone_resnet_f32(dvid_model* m, const float* const* frames, int n, int height, int width, float* p3, float* p4, float* p5, hipStream_t s) {
+    float mean[3], stdv[3];
+    for (int i = 0; i < 3; ++i) {
+        mean[i] = m->cfg.pixel_mean[i] / 255.f;
+        stdv[i] = m->cfg.pixel_std[i] / 255.f;
+    }
+    float* img = m->img8.as<float>();
+    float* bx = m->bufX.as<float>();
+    float* by = m->bufY.as<float>();
+    float* t1 = m->bufT1.as<float>();
+    float* t2 = m->bufT2.as<float>();
+    float* sc = m->bufSC.as<float>();
+    float* stage_out[4] = {nullptr, m->c3.as<float>(), m->c4.as<float>(), m->c5.as<float>()};
+    TRY(dvid_f32_prep_images_launch(frames, img, n, height, width, mean, stdv, s));
+    int h = height, w = width;
+    TRY(conv_run32(m->stem, img, n, h, w, t1, 1, nullptr, 0, s, &h, &w));
+    TRY(prof_other("maxpool_f32", (long)n * h * w, 64, 9, 0.0, (double)n * h * w * 64 * 4.0 * 1.25, s,
+                   [&] { return dvid_f32_maxpool3x3s2_launch(t1, bx, n, h, w, 64, s); }));
+    h = (h + 2 - 3) / 2 + 1;
+    w = (w + 2 - 3) / 2 + 1;
+    float* cur = bx;
+    int sh[4], sw[4];
+    for (int st = 0; st < 4; ++st) {
+        const int nb = (int)m->blocks[st].size();
+        for (int b = 0; b < nb; ++b) {
+            const Block& blk = m->blocks[st][b];
+            int h2 = h, w2 = w;
+            TRY(conv_run32(blk.c1, cur, n, h, w, t1, 1, nullptr, 0, s));
+            TRY(conv_run32(blk.c2, t1, n, h, w, t2, 1, nullptr, 0, s, &h2, &w2));
+            const float* res = cur;
+            if (blk.has_sc) {
+                TRY(conv_run32(blk.sc, cur, n, h, w, sc, 0, nullptr, 0, s));
+                res = sc;
+            }
+            float* dst = (b == nb - 1 && stage_out[st]) ? stage_out[st] : (cur == bx ? by : bx);
+            TRY(conv_run32(blk.c3, t2, n, h2, w2, dst, 1, res, 1, s));
+            h = h2;
+            w = w2;
+            cur = dst;
+        }
+        sh[st] = h;
+        sw[st] = w;
+    }
+    float* pout[3] = {p3, p4, p5};
+    for (int l = 2; l >= 0; --l) {
+        const float* res = (l < 2) ? m->lat[l + 1].as<float>() : nullptr;
+        TRY(conv_run32(m->lateral[l], stage_out[l + 1], n, sh[l + 1], sw[l + 1], m->lat[l].as<float>(), 0, res, res ? 2 : 0, s));
+        TRY(conv_run32(m->output[l], m->lat[l].as<float>(), n, sh[l + 1], sw[l + 1], pout[l], 0, nullptr, 0, s));
+    }
+    return DVID_OK;
+}
+
 float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // box_head.py:218-223 + :734-741 on the host (a handful of distinct t values per config)
@@ -865,7 +1070,6 @@ int dvid_model_create(const dvid_config* cfg, dvid_model** out) {
     dvid_model* m = new dvid_model();
     m->cfg = *cfg;
     if (const char* e = getenv("DVID_CHAINS")) m->nchain = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
-    if (const char* e = getenv("DVID_STEM_S2D")) m->use_s2d = atoi(e) != 0;
     *out = m;
     return DVID_OK;
 }
@@ -899,6 +1103,8 @@ int dvid_model_finalize(dvid_model* m) {
     if (m->finalized) return DVID_OK;
     const dvid_config& c = m->cfg;
     m->has_backbone = c.backbone_type == 1 ? c.swin_depths[0] > 0 : c.res_blocks[0] > 0;
+    if (m->precision == 1 && m->has_backbone && c.backbone_type == 1)
+        FAIL(DVID_ERR_UNSUPPORTED, "DTYPE float32 is built for the ResNet-FPN backbone only (the Swin backbone runs DTYPE float16)");
     if (m->has_backbone && c.backbone_type == 0) {
         const std::string bu = "backbone.bottom_up.";
         TRY(make_conv_bn(m, bu + "stem.conv1", 2, 3, 8, &m->stem));
@@ -1008,9 +1214,76 @@ int dvid_model_finalize(dvid_model* m) {
     return DVID_OK;
 }
 
+int dvid_model_set_precision(dvid_model* m, int precision) {
+    g_err[0] = 0;
+    if (!m || (precision != 0 && precision != 1)) FAIL(DVID_ERR_ARG, "precision must be 0 (float16) or 1 (float32)");
+    if (m->finalized) FAIL(DVID_ERR_STATE, "dvid_model_set_precision must precede dvid_model_finalize (the weights are packed for one precision)");
+    m->precision = precision;
+    return DVID_OK;
+}
+
+namespace {
+struct OptEntry {
+    const char* name;
+    int DvidOptions::*field;
+    int lo, hi;
+};
+const OptEntry kOptions[] = {
+    {"conv3x3", &DvidOptions::conv3x3, 0, 2},       {"wstat", &DvidOptions::wstat, 0, 2},           {"bneck_fuse", &DvidOptions::bneck_fuse, 0, 2},
+    {"stem_pool", &DvidOptions::stem_pool, 0, 1},   {"head_tail", &DvidOptions::head_tail, 0, 1},   {"ln_rows", &DvidOptions::ln_rows, 0, 1},
+    {"igemm_cfg", &DvidOptions::igemm_cfg, -1, 255}, {"igemm_tune", &DvidOptions::igemm_tune, -1, 1}, {"igemm_generic", &DvidOptions::igemm_generic, 0, 1},
+    {"bneck_lds", &DvidOptions::bneck_lds, 0, 160 * 1024},
+};
+}  // namespace
+
+int dvid_set_option(const char* name, int value) {
+    g_err[0] = 0;
+    if (!name) FAIL(DVID_ERR_ARG, "null option name");
+    for (const OptEntry& e : kOptions)
+        if (!strcmp(e.name, name)) {
+            if (value < e.lo || value > e.hi) FAIL(DVID_ERR_ARG, "option %s: %d outside [%d, %d]", name, value, e.lo, e.hi);
+            if (e.field == &DvidOptions::igemm_cfg && value >= dvid_igemm_num_configs()) FAIL(DVID_ERR_ARG, "igemm_cfg %d: the table has %d entries", value, dvid_igemm_num_configs());
+            g_opt.*(e.field) = value;
+            return DVID_OK;
+        }
+    FAIL(DVID_ERR_ARG, "unknown option '%s'", name);
+}
+
+int dvid_get_option(const char* name, int* value) {
+    g_err[0] = 0;
+    if (!name || !value) FAIL(DVID_ERR_ARG, "null argument");
+    for (const OptEntry& e : kOptions)
+        if (!strcmp(e.name, name)) {
+            *value = g_opt.*(e.field);
+            return DVID_OK;
+        }
+    FAIL(DVID_ERR_ARG, "unknown option '%s'", name);
+}
+
+int dvid_reset_options(void) {
+    g_opt = DvidOptions();
+    return DVID_OK;
+}
+
+// "name=value ..." of every option, then the environment switches the library still reads, as they are set
+int dvid_effective_config(char* buf, int cap) {
+    g_err[0] = 0;
+    if (!buf || cap <= 0) FAIL(DVID_ERR_ARG, "no buffer");
+    std::string out;
+    for (const OptEntry& e : kOptions) out += std::string(e.name) + "=" + std::to_string(g_opt.*(e.field)) + " ";
+    for (const char* env : {"DVID_IGEMM_TUNE", "DVID_IGEMM_TUNE_CACHE", "DVID_CHAINS", "DVID_POISON_WORKSPACE"}) {
+        const char* v = getenv(env);
+        out += std::string(env) + "=" + (v ? v : "") + " ";
+    }
+    if (!out.empty()) out.pop_back();
+    if ((int)out.size() + 1 > cap) FAIL(DVID_ERR_ARG, "buffer of %d bytes, need %d", cap, (int)out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return DVID_OK;
+}
+
 int dvid_set_stem_pool(int mode) {
     if (mode < -1 || mode > 1) return DVID_ERR_ARG;
-    g_stem_pool_mode = mode;
+    g_opt.stem_pool = mode < 0 ? DvidOptions().stem_pool : mode;
     return DVID_OK;
 }
 
@@ -1036,6 +1309,7 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
     if (height % 32 || width % 32) FAIL(DVID_ERR_ARG, "height/width must be multiples of 32 (got %dx%d)", height, width);
     const size_t n = ((size_t)max_frames + 3) / 4 * 4;      // room for up to 4 equal sub-batch chains
     const size_t px4 = (size_t)(height / 4) * (width / 4);
+    const size_t es = m->precision == 1 ? 2 : 1;            // DTYPE float32: every fp16 buffer below holds fp32 values instead
     if (m->has_backbone && m->cfg.backbone_type == 1) {
         const size_t C0 = m->cfg.swin_embed_dim, M0 = n * px4;      // stage-0 tokens; M*C halves per stage
         TRY(m->img8.ensure(n * height * width * 8 * 2));
@@ -1051,32 +1325,32 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
         for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2));
     }
     if (m->has_backbone && m->cfg.backbone_type == 0) {
-        TRY(m->img8.ensure(n * height * width * 8 * 2));
-        const size_t big = n * px4 * 256 * 2;  // largest activation: res2 output (also >= stem output)
+        TRY(m->img8.ensure(n * height * width * 8 * 2));          // (fp32: NHWC4 = the same bytes)
+        const size_t big = n * px4 * 256 * 2 * es;  // largest activation: res2 output (also >= stem output)
         TRY(m->bufX.ensure(big));
         TRY(m->bufY.ensure(big));
         TRY(m->bufT1.ensure(big));
         TRY(m->bufT2.ensure(big));
         TRY(m->bufSC.ensure(big));
-        TRY(m->c3.ensure(n * (px4 / 4) * 512 * 2));
-        TRY(m->c4.ensure(n * (px4 / 16) * 1024 * 2));
-        TRY(m->c5.ensure(n * (px4 / 64) * 2048 * 2));
-        for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2));
+        TRY(m->c3.ensure(n * (px4 / 4) * 512 * 2 * es));
+        TRY(m->c4.ensure(n * (px4 / 16) * 1024 * 2 * es));
+        TRY(m->c5.ensure(n * (px4 / 64) * 2048 * 2 * es));
+        for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2 * es));
     }
     const size_t R = n * boxes_per_frame;
     const int d = m->cfg.hidden_dim;
-    TRY(m->roi.ensure(R * 49 * d * 2));
-    TRY(m->dyn.ensure(R * 49 * d * 2));
-    TRY(m->params.ensure(R * 2 * d * m->cfg.dim_dynamic * 2));
+    TRY(m->roi.ensure(R * 49 * d * 2 * es));
+    TRY(m->dyn.ensure(R * 49 * d * 2 * es));
+    TRY(m->params.ensure(R * 2 * d * m->cfg.dim_dynamic * 2 * es));
     TRY(m->qkv.ensure(R * 3 * d * 4));
-    TRY(m->attn16.ensure(R * d * 2));
+    TRY(m->attn16.ensure(R * d * 2 * es));
     TRY(m->f32a.ensure(R * d * 4));
     TRY(m->f32b.ensure(R * d * 4));
     TRY(m->f32c.ensure(R * d * 4));
     TRY(m->f32d.ensure(R * d * 4));
-    TRY(m->h16a.ensure(R * d * 2));
-    TRY(m->h16b.ensure(R * d * 2));
-    TRY(m->hid16.ensure(R * m->cfg.dim_feedforward * 2));
+    TRY(m->h16a.ensure(R * d * 2 * es));
+    TRY(m->h16b.ensure(R * d * 2 * es));
+    TRY(m->hid16.ensure(R * m->cfg.dim_feedforward * 2 * es));
     TRY(m->ss.ensure((size_t)(m->cfg.num_heads + m->cfg.num_heads_cond) * n * 2 * d * 4));
     TRY(m->deltas.ensure(R * 4 * 4));
     TRY(m->splitk.ensure(R * d * 4 * 8));
@@ -1110,6 +1384,8 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
         FAIL(DVID_ERR_STATE, "workspace reserved for %d frames of up to %dx%d, got %d of %dx%d", m->ws_frames, m->ws_h, m->ws_w, n,
              height, width);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (m->precision == 1)          // DTYPE float32: p3 / p4 / p5 are fp32 NHWC
+        return backbone_resnet_f32(m, frames, n, height, width, reinterpret_cast<float*>(p3), reinterpret_cast<float*>(p4), reinterpret_cast<float*>(p5), s);
     float mean[3], inv_std[3];
     for (int i = 0; i < 3; ++i) {
         mean[i] = m->cfg.pixel_mean[i] / 255.f;
@@ -1157,8 +1433,7 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
             // normalise + 2x2 space-to-depth (16 halves per block: the same bytes per frame as half an NHWC8 image), then the stem
             // as a 4x4 / stride-1 convolution on the half-resolution grid
             TRY(dvid_prep_images_s2d_launch(frames + f0, img8, nf, height, width, mean, inv_std, cs));
-            static const int sp_env = getenv("DVID_STEM_POOL") ? atoi(getenv("DVID_STEM_POOL")) : 1;
-            if (g_stem_pool_mode >= 0 ? g_stem_pool_mode : sp_env) {
+            if (g_opt.stem_pool) {
                 // stem + ReLU + max pool as one launch (csrc/conv3x3.hip: stem_pool_kernel): the half-resolution 64-channel map never exists
                 TRY(conv_run(m->stem_s2d, img8, nf, h / 2, w / 2, bx, 1, 0, nullptr, 0, 0, cs, &h, &w, 0, 1, /*pooled=*/true));
                 pooled = true;
@@ -1415,31 +1690,13 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
         ss_stride = hw.bt_out;
     }
 
-    // Frames are independent inside a head (self-attention is per frame): run them as sub-batch chains on separate
-    // streams so that the many small GEMM / row kernels of the two chains fill each other's idle CUs.
-    // (measured: 0.49 ms per pass sequential vs 0.53 ms with two chains -- the head is launch-latency bound, so the
-    //  chains stay off here unless DVID_HEAD_CHAINS=1; tools/bench_head.py)
-    static const bool head_chains = getenv("DVID_HEAD_CHAINS") != nullptr;
-    const int nchain = (head_chains && m->nchain > 1 && n_frames >= 2 * m->nchain) ? 2 : 1;
-    if (nchain > 1) {
-        TRY(m->ensure_streams());
-        HIP_TRY(hipEventRecord(m->ev_fork, s));
-        for (int c = 0; c < nchain; ++c) HIP_TRY(hipStreamWaitEvent(m->cs[c], m->ev_fork, 0));
-    }
-    const int per = (n_frames + nchain - 1) / nchain;
-    const size_t lk_pad = ((size_t)M + 31) / 32 * 32 + 32;
-    for (int c = 0; c < nchain; ++c) {
-        const int f0 = c * per, nf = (f0 + per <= n_frames) ? per : n_frames - f0;
-        if (nf <= 0) continue;
-        TRY(rcnn_head_chain(m, hw, is_cond, p3, p4, p5, f0, nf, height, width, M, boxes, pro_features, cond, logits, boxes_out,
-                            obj_features, bad_box_flag, ss_dev, ss_stride, (size_t)f0 * M, (size_t)f0 * m->cfg.nheads * 32 * lk_pad,
-                            nchain > 1 ? m->cs[c] : s));
-        if (nchain > 1) {
-            HIP_TRY(hipEventRecord(m->ev_join[c], m->cs[c]));
-            HIP_TRY(hipStreamWaitEvent(s, m->ev_join[c], 0));
-        }
-    }
-    return DVID_OK;
+    // One launch sequence on the caller's stream.  (Frames are independent inside a head, but two sub-batch chains on two streams
+    // measured slower -- 0.53 against 0.49 ms per pass, tools/bench_head.py -- the switch that kept that path is gone.)
+    if (m->precision == 1)
+        return rcnn_head_chain_f32(m, hw, is_cond, p3, p4, p5, 0, n_frames, height, width, M, boxes, pro_features, cond, logits, boxes_out, obj_features,
+                                   bad_box_flag, ss_dev, ss_stride, 0, s);
+    return rcnn_head_chain(m, hw, is_cond, p3, p4, p5, 0, n_frames, height, width, M, boxes, pro_features, cond, logits, boxes_out, obj_features,
+                           bad_box_flag, ss_dev, ss_stride, 0, 0, s);
 }
 
 // K/V projections of the global memory (box_head.py:366-380 recomputes them on every call; they depend on the per-video
@@ -1452,6 +1709,11 @@ int dvid_global_memory_project(dvid_model* m, const float* memory, int lk, void*
     const int d = m->cfg.hidden_dim;
     m->mem_lk = 0;
     TRY(m->kvproj.ensure((size_t)lk * 2 * d * 4));
+    if (m->precision == 1) {          // fp32 K | V rows
+        TRY(linear_run32(m->gkv, memory, lk, m->kvproj.as<float>(), 0, s));
+        m->mem_lk = lk;
+        return DVID_OK;
+    }
     TRY(m->mem16.ensure((size_t)lk * d * 2));
     TRY(dvid_f32_to_f16_launch(memory, m->mem16.as<half_t>(), (long)lk * d, s));
     TRY(linear_run(m->gkv, m->mem16.as<half_t>(), lk, m->kvproj.p, 0, 0, s));
@@ -1471,6 +1733,15 @@ int dvid_global_xattn(dvid_model* m, const float* query, int rows, const float* 
         FAIL(DVID_ERR_STATE, "no projected global memory of %d rows (call dvid_global_memory_project)", lk);
     }
     lk = m->mem_lk;
+    if (m->precision == 1) {
+        float* qp = m->h16a.as<float>();
+        float* at = m->attn16.as<float>();
+        const float* kv32 = m->kvproj.as<float>();
+        TRY(linear_run32(m->gq, query, rows, qp, 0, s));
+        TRY(dvid_f32_mha_launch(qp, kv32, kv32 + d, at, 1, rows, lk, m->cfg.nheads, d, 2 * d, d, 0, 0, 0, s));
+        TRY(linear_run32(m->gout, at, rows, out, 0, s));
+        return DVID_OK;
+    }
     TRY(dvid_f32_to_f16_launch(query, m->h16a.as<half_t>(), (long)rows * d, s));
     TRY(linear_run(m->gq, m->h16a.as<half_t>(), rows, m->h16b.p, 0, 0, s));
     const half_t* kv = m->kvproj.as<half_t>();
@@ -1496,6 +1767,56 @@ int dvid_roialign_v2_multilevel(const void* p3, const void* p4, const void* p5, 
     }
     TRY(dvid_roialign_launch(lv, channels, boxes, n_frames, boxes_per_frame, reinterpret_cast<half_t*>(roi_out), mean_out,
                              reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_roialign_v2_multilevel_f32(const float* p3, const float* p4, const float* p5, int n_frames, int height, int width, int channels,
+                                    const float* boxes, int boxes_per_frame, float* roi_out, float* mean_out, void* stream) {
+    g_err[0] = 0;
+    if (height % 32 || width % 32) FAIL(DVID_ERR_ARG, "height/width must be multiples of 32");
+    RoiLevels32 lv;
+    const float* pl[3] = {p3, p4, p5};
+    for (int l = 0; l < 3; ++l) {
+        lv.feat[l] = pl[l];
+        lv.h[l] = height >> (3 + l);
+        lv.w[l] = width >> (3 + l);
+        lv.scale[l] = 1.f / (float)(8 << l);
+    }
+    TRY(dvid_f32_roialign_launch(lv, channels, boxes, n_frames, boxes_per_frame, roi_out, mean_out, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* residual, float* out, int n, int h, int wd, int cin,
+                         int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int residual_mode, void* stream) {
+    g_err[0] = 0;
+    if (cin % 4 || kpad % 16 || kpad < kh * kw * cin || pad < 0) FAIL(DVID_ERR_ARG, "fp32 conv: cin %% 4 == 0, kpad %% 16 == 0, kpad >= kh*kw*cin, pad >= 0");
+    ConvW cw;
+    cw.w32 = const_cast<float*>(w);
+    cw.bias = const_cast<float*>(bias);
+    cw.cin32 = cin;
+    cw.cin_real = cin;
+    cw.cout = cout;
+    cw.kh = kh;
+    cw.kw = kw;
+    cw.stride = stride;
+    cw.pad = pad;
+    cw.kpad32 = kpad;
+    TRY(conv_run32(cw, in, n, h, wd, out, relu, residual, residual_mode, reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_mha_f32(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int q_ld, int kv_ld, int out_ld,
+                 int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_f32_mha_launch(q, k, v, out, batch, lq, lk, nheads, q_ld, kv_ld, out_ld, (long)q_bs, (long)kv_bs, (long)out_bs,
+                            reinterpret_cast<hipStream_t>(stream)));
+    return DVID_OK;
+}
+
+int dvid_dynconv_f32(const float* roi, const float* params, const float* g1, const float* b1, const float* g2, const float* b2, float* out,
+                     int rows, void* stream) {
+    g_err[0] = 0;
+    TRY(dvid_f32_dynconv_launch(roi, params, g1, b1, g2, b2, out, rows, reinterpret_cast<hipStream_t>(stream)));
     return DVID_OK;
 }
 

@@ -299,11 +299,10 @@ int dvid_topk_candidates_launch(const float* logits, const float* boxes, int n_i
                                 float* cand_scores, int* cand_labels, hipStream_t s) {
     if (n_img == 0) return DVID_OK;
     {
-        // radix select + sort of the M selected keys (topk_select_kernel); DVID_TOPK_FULL_SORT=1 keeps the full sort (A/B, tests)
-        static const bool full_sort = getenv("DVID_TOPK_FULL_SORT") && atoi(getenv("DVID_TOPK_FULL_SORT")) != 0;
+        // radix select + sort of the M selected keys (topk_select_kernel); shapes whose keys do not fit its LDS take the full sort below
         const int mpad = next_pow2(m);
         const size_t smem2 = (size_t)mpad * 8 + (size_t)m * c * 4 + 2048 * 4;
-        if (!full_sort && m * c > m && smem2 <= 150 * 1024) {
+        if (m * c > m && smem2 <= 150 * 1024) {
             static std::atomic<unsigned long long> attr2{0};          // one bit per device: the attribute belongs to (function, device)
             if (first_on_device(attr2)) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -153,8 +153,7 @@ int dvid_roialign_launch(const RoiLevels& lv, int channels, const float* boxes, 
     if (channels != 256) return DVID_ERR_UNSUPPORTED;
     const int nbox = n_img * boxes_per_img;
     if (nbox == 0) return DVID_OK;
-    static const int xcd_major = getenv("DVID_ROI_XCD") ? atoi(getenv("DVID_ROI_XCD")) : 1;      // 0: A/B measurements
-    hipLaunchKernelGGL(roialign_kernel, dim3(nbox), dim3(256), 0, s, lv, boxes, boxes_per_img, roi_out, mean_out, nbox, xcd_major);
+    hipLaunchKernelGGL(roialign_kernel, dim3(nbox), dim3(256), 0, s, lv, boxes, boxes_per_img, roi_out, mean_out, nbox, /*xcd_major=*/1);
     LAUNCH_CHECK();
     return DVID_OK;
 }

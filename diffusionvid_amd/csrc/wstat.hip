@@ -517,18 +517,16 @@ bool dvid_wstat_supported(const IgemmParams& p) {
     if (p.out_f32 || p.splitk > 1 || p.relu > 2 || (p.ldc & 7)) return false;
     if (p.res_mode > 1 || (p.res_mode == 1 && p.res_f32)) return false;
     if (p.relu == 2 && p.res_mode) return false;          // exact GELU: Swin's fc1, no residual
-    static const bool gelu_ok = !(getenv("DVID_WSTAT_GELU") && atoi(getenv("DVID_WSTAT_GELU")) == 0);          // A/B switch
-    if (p.relu == 2 && !gelu_ok) return false;
     return true;
 }
 
 // ... and the launch is large enough for the persistent workgroups: each streams at least kMinBlocks row blocks per weight load.
 // (24 until round 3; the 8-frame launches of a one-batch call -- res4 conv3: 9 blocks per workgroup, dynamic_layer: 9 -- run faster
 // here than on igemm2's small tiles: 1311 vs 1264 frames/s with every supported launch forced onto this kernel,
-// profiles/r03_lookahead1_ab.txt.  DVID_WSTAT_MIN overrides.)
+// profiles/r03_lookahead1_ab.txt.)
 bool dvid_wstat_preferred(const IgemmParams& p) {
     if (!dvid_wstat_supported(p)) return false;
-    static const int kMinBlocks = getenv("DVID_WSTAT_MIN") ? atoi(getenv("DVID_WSTAT_MIN")) : 8;
+    constexpr int kMinBlocks = 8;
     const int ns = p.Cout / 256;
     const long blocks_per_xcd = ((long)p.M + 31) / 32 / 8;
     const long per_wg = ns <= 32 ? blocks_per_xcd / (32 / ns) : blocks_per_xcd;
@@ -562,12 +560,9 @@ static int wstat_launch_rows32(const IgemmParams& p, hipStream_t s) {
     // layers with a residual: the row-coalesced variant (res3 conv3 0.460 vs 0.497 ms, res4 conv3 0.291 vs 0.300 at 104 frames); without
     // one (dynamic_layer, linear1) the accumulator-layout stores are as fast or faster (0.780 vs 0.791), and 64 channels per wave
     // (512-channel slabs: every A fragment read and every DMA piece serves two MFMA chains) where the slab count allows it.
-    // DVID_WSTAT_V2=0 / 1 forces one, DVID_WSTAT_TN=1 the 32-channel form.
-    static const int v2 = getenv("DVID_WSTAT_V2") ? atoi(getenv("DVID_WSTAT_V2")) : -1;
-    static const int tn_env = getenv("DVID_WSTAT_TN") ? atoi(getenv("DVID_WSTAT_TN")) : 2;
-    if (p.Kpad != 512 && (v2 > 0 || (v2 < 0 && p.res_mode == 1))) return p.Kpad == 128 ? ws2_launch_v<128, 4>(p, s) : ws2_launch_v<256, 3>(p, s);
+    if (p.Kpad != 512 && p.res_mode == 1) return p.Kpad == 128 ? ws2_launch_v<128, 4>(p, s) : ws2_launch_v<256, 3>(p, s);
     const int ns2 = p.Cout / 512;
-    const bool wide = tn_env == 2 && p.res_mode == 0 && p.Cout % 512 == 0 && ns2 >= 32 && ns2 % 32 == 0;      // dynamic_layer: 0.749 vs 0.775 ms; linear1 (4 slabs) is slower that way
+    const bool wide = p.res_mode == 0 && p.Cout % 512 == 0 && ns2 >= 32 && ns2 % 32 == 0;      // dynamic_layer: 0.749 vs 0.775 ms; linear1 (4 slabs) is slower that way
     if (p.Kpad == 512) return ws_launch_v<512, 4, 1>(p, s);          // 128 registers of weights per wave, four 32-KB A tiles
     if (p.Kpad == 128) return wide ? ws_launch_v<128, 6, 2>(p, s) : ws_launch_v<128, 6, 1>(p, s);
     return wide ? ws_launch_v<256, 4, 2>(p, s) : ws_launch_v<256, 4, 1>(p, s);

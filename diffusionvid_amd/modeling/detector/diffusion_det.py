@@ -100,6 +100,13 @@ class DiffusionDet(nn.Module):
         self.infer_batch = cfg.INPUT.INFER_BATCH
         self.lookahead = max(1, int(getattr(cfg.INPUT, "LOOKAHEAD_BATCHES", 1)))
         self.size_divisibility = 32
+        # The reference's global precision switch (mega_core/config/defaults.py:582: "float32" unless the command line says
+        # `DTYPE float16`, README.md:86-96; tools/test_net.py:97-98 turns apex amp on for float16 only).  float16 = fp16 storage /
+        # fp16 MFMA (the headline path), float32 = fp32 storage / fp32 MFMA (csrc/f32.hip).  Anything else is refused: no value of
+        # this key silently selects another precision.
+        self.dtype = str(cfg.DTYPE)
+        if self.dtype not in ops.PRECISIONS:
+            raise NotImplementedError("DTYPE %r: the MI355X path builds float16 and float32" % (self.dtype,))
         if self.lookahead > 1:
             # The look-ahead schedule finishes later batches inside the group's call: that equals the reference only when
             # a batch is exactly one full local queue starting at its key frame, and the global memory is final after the
@@ -215,7 +222,7 @@ class DiffusionDet(nn.Module):
                 num_classes=d.NUM_CLASSES, num_cls=d.NUM_CLS, num_reg=d.NUM_REG, num_heads=d.NUM_HEADS,
                 num_heads_cond=d.NUM_HEADS_LOCAL, pooler_resolution=self.cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION,
                 sampling_ratio=self.cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO, res_blocks=tuple(self.res_blocks),
-                pixel_mean=tuple(self.cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(self.cfg.MODEL.PIXEL_STD),
+                pixel_mean=tuple(self.cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(self.cfg.MODEL.PIXEL_STD), precision=self.dtype,
                 **({} if self.swin is None else dict(backbone="swin", swin_embed_dim=self.swin["embed_dim"],
                                                       swin_depths=tuple(self.swin["depths"]), swin_heads=tuple(self.swin["heads"]),
                                                       swin_window=self.swin["window"])))
@@ -550,9 +557,11 @@ class DiffusionDet(nn.Module):
             self._graphs, self._graph_seen, self._graph_generation = {}, {}, gen
         # ... and it bakes in every switch the eager path reads per call
         gframes = [im.tensors for im in ref_g] if ref_g else []
+        # (the engine may not exist yet: a rank that adopted its video's memory -- adopt_video_memory -- reaches its first full batch
+        # without having run anything, and a device move drops the engine; _get_engine builds it)
+        eng = self._get_engine()
         key = (tuple(frames[0].shape), len(frames), self.sampling_timesteps, int(mem[0].shape[0]), int(mem[1].shape[0]) if mem[1] is not None else 0,
-               id(self._engine), (float(w), float(h)), bool(self.skip_unobservable), bool(self.use_nms), self._engine.chains,
-               os.environ.get("DVID_HEAD_CHAINS", ""), len(gframes))
+               id(eng), (float(w), float(h)), bool(self.skip_unobservable), bool(self.use_nms), eng.chains, eng.precision, len(gframes))
         M = self.num_proposals
         g = self._graphs.get(key)
         if g is None:

@@ -52,11 +52,18 @@ class DynamicHead(nn.Module):
         return self._engine_provider()
 
     @staticmethod
-    def _as_nhwc(features):
+    def _as_nhwc(features, eng):
+        """The engine's layout: NHWC in its feature dtype (fp16, or fp32 with DTYPE float32).  The detector hands its own backbone
+        outputs over in that layout; a caller with the reference's NCHW maps (box_head.py:273: list[Tensor NCHW]) gets them converted."""
         feats = []
         for f in features:
-            if f.dtype == torch.float16 and f.dim() == 4 and f.shape[-1] == 256:
-                feats.append(f)                       # already the engine's NHWC fp16 layout
+            c = eng.hidden_dim
+            if f.dtype == eng.feat_dtype and f.dim() == 4 and f.shape[-1] == c and (f.dtype == torch.float16 or f.shape[1] != c):
+                feats.append(f)                       # already the engine's layout
+            elif eng.feat_dtype == torch.float32:
+                if f.dim() != 4 or f.shape[1] != c:
+                    raise ops._lib.DvidError("DynamicHead: feature maps must be NCHW with %d channels (or the engine's NHWC tensors)" % c)
+                feats.append(f.float().permute(0, 2, 3, 1).contiguous())
             else:
                 feats.append(ops.nhwc_from_nchw(f.float()))   # reference layout: NCHW
         return feats
@@ -67,7 +74,7 @@ class DynamicHead(nn.Module):
         if init_features is not None:
             raise NotImplementedError("init_features is unused by DiffusionVID inference (always None, diffusion_det.py:662-664)")
         eng = self._engine()
-        feats = self._as_nhwc(features)
+        feats = self._as_nhwc(features, eng)
         bs, num_boxes = init_bboxes.shape[:2]
         height, width = feats[0].shape[1] * 8, feats[0].shape[2] * 8
         eng.reserve(max(bs, self.infer_batch), height, width, num_boxes)

@@ -28,7 +28,9 @@ def nhwc_from_nchw(x):
 
 
 def nchw_from_nhwc(x):
-    """fp16 NHWC -> fp32 NCHW."""
+    """fp16 NHWC -> fp32 NCHW (an fp32 NHWC map, DTYPE float32, is a pure permutation: a strided copy)."""
+    if x.dtype == torch.float32:
+        return _cuda(x).permute(0, 3, 1, 2).contiguous()
     x = _cuda(x, torch.float16)
     n, h, w, c = x.shape
     out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
@@ -65,6 +67,69 @@ def conv2d_nhwc(x, w_packed, kpad, bias, cout, kh, kw, stride, pad, relu=False, 
     out = torch.empty((n, ho, wo, cout), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
     call("dvid_conv2d_nhwc_f16", ptr(x), ptr(w_packed), ptr(bias), ptr(residual), ptr(out), n, h, wd, cin, cout, kh, kw,
          stride, pad, kpad, int(relu), int(out_f32), residual_mode, stream_ptr())
+    return out
+
+
+# ---- DTYPE float32 forms (csrc/f32.hip): fp32 NHWC activations, un-rounded weights, fp32 MFMA --------------------------------------
+def pack_conv_weight_f32(w):
+    """OIHW fp32 (or [out, in]) -> fp32 [cout, kpad], k = (ky*kw+kx)*cin4 + c with cin4 = cin rounded up to 4, kpad to 16 (zeros)."""
+    w = w.detach().float().cpu()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    cout, cin, kh, kw = w.shape
+    c4 = (cin + 3) // 4 * 4
+    kpad = (kh * kw * c4 + 15) // 16 * 16
+    packed = torch.zeros((cout, kh * kw, c4), dtype=torch.float32)
+    packed[:, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    out = torch.zeros((cout, kpad), dtype=torch.float32)
+    out[:, :kh * kw * c4] = packed.reshape(cout, -1)
+    return out, kpad
+
+
+def conv2d_nhwc_f32(x, w_packed, kpad, bias, cout, kh, kw, stride, pad, relu=0, residual=None, residual_mode=0):
+    """x fp32 NHWC (channels a multiple of 4); returns fp32 NHWC.  relu: 0 none, 1 ReLU, 2 exact GELU."""
+    x = _cuda(x, torch.float32)
+    n, h, wd, cin = x.shape
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (wd + 2 * pad - kw) // stride + 1
+    out = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    call("dvid_conv2d_nhwc_f32", ptr(x), ptr(w_packed), ptr(bias), ptr(residual), ptr(out), n, h, wd, cin, cout, kh, kw, stride, pad, kpad,
+         int(relu), residual_mode, stream_ptr())
+    return out
+
+
+def linear_f32(x, w_packed, kpad, bias, relu=0):
+    rows, k = x.shape
+    return conv2d_nhwc_f32(x.view(rows, 1, 1, k), w_packed, kpad, bias, w_packed.shape[0], 1, 1, 1, 0, relu=relu).view(rows, -1)
+
+
+def roialign_f32(feats_nhwc, boxes, height, width, want_mean=False):
+    """feats_nhwc: [p3, p4, p5] fp32 NHWC; boxes fp32 [n, M, 4] -> roi fp32 [n*M, 49, C] (+ mean fp32 [n*M, C])."""
+    p3, p4, p5 = (_cuda(f, torch.float32) for f in feats_nhwc)
+    boxes = _cuda(boxes, torch.float32)
+    n, M = boxes.shape[:2]
+    c = p3.shape[-1]
+    roi = torch.empty((n * M, 49, c), dtype=torch.float32, device=boxes.device)
+    mean = torch.empty((n * M, c), dtype=torch.float32, device=boxes.device) if want_mean else None
+    call("dvid_roialign_v2_multilevel_f32", ptr(p3), ptr(p4), ptr(p5), n, height, width, c, ptr(boxes), M, ptr(roi), ptr(mean), stream_ptr())
+    return (roi, mean) if want_mean else roi
+
+
+def mha_f32(q, k, v, nheads):
+    """fp32 attention: q [B, Lq, d], k / v [B, Lk, d] -> fp32 [B, Lq, d] (head dim 32)."""
+    q, k, v = _cuda(q, torch.float32), _cuda(k, torch.float32), _cuda(v, torch.float32)
+    B, lq, d = q.shape
+    lk = k.shape[1]
+    out = torch.empty_like(q)
+    call("dvid_mha_f32", ptr(q), ptr(k), ptr(v), ptr(out), B, lq, lk, nheads, d, d, d, lq * d, lk * d, lq * d, stream_ptr())
+    return out
+
+
+def dynconv_f32(roi, params, g1, b1, g2, b2):
+    """roi fp32 [R, 49, 256], params fp32 [R, 32768] as P1T[64][256] | P2T[256][64] -> fp32 [R, 49, 256]"""
+    roi, params = _cuda(roi, torch.float32), _cuda(params, torch.float32)
+    out = torch.empty_like(roi)
+    call("dvid_dynconv_f32", ptr(roi), ptr(params), ptr(g1), ptr(b1), ptr(g2), ptr(b2), ptr(out), roi.shape[0], stream_ptr())
     return out
 
 
@@ -271,13 +336,21 @@ def workspace_generation():
     return int(_lib.load().dvid_workspace_generation())
 
 
+PRECISIONS = {"float16": 0, "float32": 1}          # the reference's DTYPE values (mega_core/config/defaults.py:582) -> dvid_model_set_precision
+
+
 class Model:
     """Owns a dvid_model handle: repacked weights + activation workspace on the current device."""
 
     def __init__(self, state_dict, *, hidden_dim=256, nheads=8, dim_feedforward=2048, dim_dynamic=64, num_classes=30,
                  num_cls=1, num_reg=3, num_heads=3, num_heads_cond=1, pooler_resolution=7, sampling_ratio=2,
                  res_blocks=(3, 4, 23, 3), pixel_mean=(123.675, 116.280, 103.530), pixel_std=(58.395, 57.120, 57.375),
-                 backbone="resnet", swin_embed_dim=128, swin_depths=(2, 2, 18, 2), swin_heads=(4, 8, 16, 32), swin_window=7):
+                 backbone="resnet", swin_embed_dim=128, swin_depths=(2, 2, 18, 2), swin_heads=(4, 8, 16, 32), swin_window=7,
+                 precision="float16"):
+        """precision: the reference's DTYPE key -- "float16" (fp16 storage, fp16 MFMA, fp32 accumulation) or "float32" (fp32 storage,
+        fp32 MFMA; csrc/f32.hip, ResNet-FPN only).  Feature maps are fp16 / fp32 NHWC tensors accordingly."""
+        if precision not in PRECISIONS:
+            raise _lib.DvidError(f"precision must be one of {sorted(PRECISIONS)} (the reference's DTYPE), got {precision!r}")
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.DvidError("no HIP device visible: the DiffusionVID hot path runs only on the GPU (no CPU fallback)")
@@ -288,9 +361,12 @@ class Model:
                               (C.c_int * 4)(*swin_heads), swin_window)
         self.backbone_kind = backbone
         self.cfg = cfg
+        self.precision = precision
+        self.feat_dtype = torch.float32 if precision == "float32" else torch.float16
         h = C.c_void_p()
         _lib.check(lib.dvid_model_create(C.byref(cfg), C.byref(h)), "dvid_model_create")
         self.handle = h
+        _lib.check(lib.dvid_model_set_precision(h, PRECISIONS[precision]), "dvid_model_set_precision")
         self.hidden_dim, self.num_classes, self.nheads = hidden_dim, num_classes, nheads
         self.has_backbone = (swin_depths[0] > 0) if backbone == "swin" else (res_blocks[0] > 0)
         wanted = ("head.", "backbone.") if self.has_backbone else ("head.",)
@@ -324,12 +400,12 @@ class Model:
             self._ws = key
 
     def backbone(self, images, frames_per_launch=None):
-        """images fp32 NCHW [n,3,H,W] in [0,1] -> (p3, p4, p5) fp16 NHWC.  frames_per_launch: run the n frames as
+        """images fp32 NCHW [n,3,H,W] in [0,1] -> (p3, p4, p5) fp16 (precision float32: fp32) NHWC.  frames_per_launch: run the n frames as
         consecutive launch sequences of at most that many frames (same results; smaller activation working set)."""
         images = _cuda(images, torch.float32)
         n, _, h, w = images.shape
         dev = images.device
-        outs = [torch.empty((n, h >> s, w >> s, self.hidden_dim), dtype=torch.float16, device=dev) for s in (3, 4, 5)]
+        outs = [torch.empty((n, h >> s, w >> s, self.hidden_dim), dtype=self.feat_dtype, device=dev) for s in (3, 4, 5)]
         fn = "dvid_backbone_swin_fpn" if self.backbone_kind == "swin" else "dvid_backbone_resnet_fpn"
         step = n if not frames_per_launch else max(1, min(n, int(frames_per_launch)))
         for a in range(0, n, step):
@@ -350,7 +426,7 @@ class Model:
             keep.append(f if f.is_contiguous() else f.contiguous())
         n = len(keep)
         dev = first.device
-        outs = [torch.empty((n, h >> s, w >> s, self.hidden_dim), dtype=torch.float16, device=dev) for s in (3, 4, 5)]
+        outs = [torch.empty((n, h >> s, w >> s, self.hidden_dim), dtype=self.feat_dtype, device=dev) for s in (3, 4, 5)]
         table = (C.c_void_p * n)(*[f.data_ptr() for f in keep])
         fn = "dvid_backbone_swin_fpn_frames" if self.backbone_kind == "swin" else "dvid_backbone_resnet_fpn_frames"
         call(fn, self.handle, table, n, h, w, ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream_ptr())
@@ -362,6 +438,9 @@ class Model:
         n, M = boxes.shape[:2]
         dev = boxes.device
         d = self.hidden_dim
+        for f in feats_nhwc:          # the library reads them as the model's precision says: a mismatch would be silent garbage
+            if f.dtype != self.feat_dtype or not f.is_contiguous():
+                raise _lib.DvidError(f"rcnn_head: feature maps must be contiguous {self.feat_dtype} NHWC tensors for precision {self.precision}")
         logits = torch.empty((n, M, self.num_classes), dtype=torch.float32, device=dev)
         boxes_out = torch.empty((n, M, 4), dtype=torch.float32, device=dev)
         obj = torch.empty((n * M, d), dtype=torch.float32, device=dev)

@@ -27,7 +27,8 @@
  *   dvid_model_set_tensor      DetectronCheckpointer.load name contract, mega_core/utils/model_serialization.py:12-73
  *
  * Layouts: images fp32 NCHW in [0,1] (what the reference model receives); feature maps fp16 NHWC
- * (channels fastest); boxes fp32 xyxy absolute pixels; object features fp32 [rows, hidden].
+ * (channels fastest; fp32 NHWC with DTYPE float32, dvid_model_set_precision); boxes fp32 xyxy absolute pixels; object features
+ * fp32 [rows, hidden].
  */
 #ifndef DVID_HIP_H
 #define DVID_HIP_H
@@ -77,6 +78,12 @@ int dvid_model_destroy(dvid_model* m);
 /* state_dict entry, reference parameter names ("backbone.bottom_up.res2.0.conv1.weight",
  * "head.head_series.0.inst_interact.dynamic_layer.weight", ...); data is copied. */
 int dvid_model_set_tensor(dvid_model* m, const char* name, const float* data, const int64_t* shape, int ndim);
+/* The reference's global DTYPE switch (mega_core/config/defaults.py:582, default "float32"; tools/test_net.py:97-98 turns apex amp on for
+ * "float16" only): precision 0 = DTYPE float16 -- fp16 weights / stored activations, fp16 MFMA, fp32 accumulation (the apex O1 policy);
+ * precision 1 = DTYPE float32 -- every weight and activation fp32, products on the fp32 MFMA (csrc/f32.hip; ResNet-FPN backbone only:
+ * finalize fails for Swin).  Feature maps handed to / taken from the stage functions below are fp16 NHWC in mode 0 and fp32 NHWC in
+ * mode 1.  Must be called before dvid_model_finalize (the weights are packed for one precision); the default is 0. */
+int dvid_model_set_precision(dvid_model* m, int precision);
 /* fold FrozenBN, repack to MFMA operand layouts, upload.  Fails (DVID_ERR_STATE) naming the first
  * missing tensor. */
 int dvid_model_finalize(dvid_model* m);
@@ -136,6 +143,17 @@ int dvid_global_memory_project(dvid_model* m, const float* memory, int lk, void*
 int dvid_roialign_v2_multilevel(const void* p3, const void* p4, const void* p5, int n_frames, int height, int width,
                                 int channels, const float* boxes, int boxes_per_frame, void* roi_out /* fp16 [R,49,C] */,
                                 float* mean_out /* [R,C] or NULL */, void* stream);
+/* The DTYPE float32 forms of the stand-alone ops (csrc/f32.hip): fp32 NHWC pyramids -> fp32 [R,49,C] tiles; fp32 conv / linear with
+ * w [cout][kpad] fp32, k = (ky*kw+kx)*cin + c, cin % 4 == 0, kpad = round_up(kh*kw*cin, 16) zero-padded; fp32 attention (head dim 32,
+ * head h at columns [32h, 32h+32)); fp32 DynamicConv (params [R][32768] = P1T[64][256] | P2T[256][64]). */
+int dvid_roialign_v2_multilevel_f32(const float* p3, const float* p4, const float* p5, int n_frames, int height, int width, int channels,
+                                    const float* boxes, int boxes_per_frame, float* roi_out, float* mean_out, void* stream);
+int dvid_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* residual, float* out, int n, int h, int wd, int cin,
+                         int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int residual_mode, void* stream);
+int dvid_mha_f32(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int q_ld, int kv_ld, int out_ld,
+                 int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream);
+int dvid_dynconv_f32(const float* roi, const float* params, const float* g1, const float* b1, const float* g2, const float* b2, float* out,
+                     int rows, void* stream);
 int dvid_select_topk_features(const float* logits, int n_frames, int m, int num_classes, int k1, int k2, const float* feats,
                               int hidden, float* out_k1, float* out_k2, void* stream);
 /* N(0, 1) draws as a pure function of (key, element index): out[i][e], i < n_images, e < per_image, = element e of the stream

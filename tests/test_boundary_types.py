@@ -128,7 +128,7 @@ def test_collator_padding_matches_reference_and_foreign_image_lists_are_accepted
 def _small_detector():
     from diffusionvid_amd.config import get_cfg
     from diffusionvid_amd.modeling.detector import build_detection_model
-    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), None, os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16"], os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
     cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
     cfg.freeze()
     return build_detection_model(cfg).eval()
@@ -216,7 +216,7 @@ def test_annotations_and_do_vid_evaluation_match_reference(tmp_path):
     assert os.path.exists(cache)
     again = VIDAnnotations(VIDFrameList(index), None, cache)          # the cache alone is enough the second time
     assert torch.equal(again.get_groundtruth(n - 1).bbox, an.get_groundtruth(n - 1).bbox)
-    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), None, os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16"], os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
     ds = VIDMEGATestDataset(cfg, os.path.join(str(tmp_path), "Data", "VID"), index, anno_path=anno_dir)
     assert ds.map_class_id_to_class_name(1) == "airplane"
     with pytest.raises(RuntimeError):
@@ -307,7 +307,7 @@ def test_one_call_from_foreign_typed_dict_on_gpu():
     from diffusionvid_amd.structures.bounding_box import BoxList
     from diffusionvid_amd.utils import synthetic
     FImageList, FBoxList = _foreign_package()
-    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), None, os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16"], os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
     cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = (1, 1, 1, 1)
     cfg.freeze()
     model = build_detection_model(cfg)

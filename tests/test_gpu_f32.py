@@ -1,0 +1,217 @@
+"""DTYPE float32 (the reference's default precision, mega_core/config/defaults.py:582): per-kernel and per-stage parity of csrc/f32.hip
+against the fp32 CPU oracle / plain torch fp32 on identical un-rounded inputs, through the C ABI.
+
+Tolerances.  Both sides are fp32 fmaf chains that differ in summation order only (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 is
+bit-for-bit a k-ordered fmaf chain): per layer ~1e-6 of the output's RMS, a few 1e-6 through a chain of layers.  Bounds below are
+2e-5 of RMS + 2e-5 relative for single kernels and 2e-4 for the ~15-layer head / ~20-layer backbone chains -- two orders of
+magnitude inside what the fp16 path is allowed (tests/test_gpu_kernels.py).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import backbone_r101, head as ohead, roi_align as oroi, schedule as osch  # noqa: E402
+from test_gpu_kernels import _boxes, check  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dv():
+    from diffusionvid_amd import ops
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return ops
+
+
+def nhwc(x, pad_to=None):
+    x = x.permute(0, 2, 3, 1).contiguous()
+    if pad_to and x.shape[-1] < pad_to:
+        x = F.pad(x, (0, pad_to - x.shape[-1]))
+    return x.cuda()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=2, h=20, w=28, cin=64, cout=128, k=3, stride=1, pad=1, relu=1, res=1),
+    dict(n=2, h=21, w=27, cin=128, cout=64, k=3, stride=2, pad=1, relu=0, res=0),          # ragged M, BN 64 tiles
+    dict(n=3, h=16, w=24, cin=256, cout=256, k=1, stride=1, pad=0, relu=1, res=1),
+    dict(n=1, h=16, w=24, cin=128, cout=512, k=1, stride=2, pad=0, relu=0, res=0),          # strided 1x1 (shortcut)
+    dict(n=1, h=12, w=16, cin=512, cout=256, k=1, stride=1, pad=0, relu=0, res=2),          # FPN lateral + nearest-x2 top-down sum
+    dict(n=2, h=64, w=96, cin=3, cout=64, k=7, stride=2, pad=3, relu=1, res=0),             # the stem: 3 channels padded to 4, K 196 -> 208
+    dict(n=1, h=9, w=11, cin=256, cout=30, k=1, stride=1, pad=0, relu=0, res=0),            # N tail (class_logits)
+    dict(n=1, h=5, w=7, cin=64, cout=130, k=3, stride=1, pad=1, relu=2, res=0),             # exact GELU, N tail across two tiles
+])
+def test_f32_conv(dv, cfg):
+    g = torch.Generator().manual_seed(1)
+    n, h, w, cin, cout, k = cfg["n"], cfg["h"], cfg["w"], cfg["cin"], cfg["cout"], cfg["k"]
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), stride=cfg["stride"], padding=cfg["pad"])
+    res = None
+    if cfg["res"] == 1:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res.double()
+    elif cfg["res"] == 2:
+        res = torch.randn(n, cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g)
+        ref = ref + F.interpolate(res.double(), scale_factor=2.0, mode="nearest")
+    if cfg["relu"] == 1:
+        ref = F.relu(ref)
+    elif cfg["relu"] == 2:
+        ref = F.gelu(ref)
+    wp, kpad = dv.pack_conv_weight_f32(wt)
+    out = dv.conv2d_nhwc_f32(nhwc(x, (cin + 3) // 4 * 4), wp.cuda(), kpad, bias.cuda(), cout, k, k, cfg["stride"], cfg["pad"], relu=cfg["relu"],
+                             residual=nhwc(res) if res is not None else None, residual_mode=cfg["res"])
+    check(f"f32_conv{cfg}", out.permute(0, 3, 1, 2), ref.float(), 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("rows,k,nout", [(600, 256, 768), (300, 256, 4), (257, 12544, 256), (600, 256, 32768), (1, 1024, 256)])
+def test_f32_linear(dv, rows, k, nout):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(rows, k, generator=g)
+    wt = torch.randn(nout, k, generator=g) / math.sqrt(k)
+    bias = torch.randn(nout, generator=g)
+    ref = F.linear(x.double(), wt.double(), bias.double()).float()
+    wp, kpad = dv.pack_conv_weight_f32(wt)
+    out = dv.linear_f32(x.cuda(), wp.cuda(), kpad, bias.cuda())
+    check(f"f32_linear[{rows}x{k}->{nout}]", out, ref, 2e-5, 2e-5)
+
+
+def test_f32_roialign(dv):
+    """zero-area, oversize and edge boxes, all three levels; against oracle/roi_align.py on the same fp32 maps"""
+    g = torch.Generator().manual_seed(4)
+    n, M, H, W = 2, 300, 160, 256
+    feats = [torch.randn(n, 256, H // s, W // s, generator=g) for s in (8, 16, 32)]
+    boxes = _boxes(g, n, M, H, W)
+    ref = oroi.roi_pooler(feats, boxes, 7, (1 / 8., 1 / 16., 1 / 32.), 2)          # [n*M, 256, 7, 7]
+    roi, mean = dv.roialign_f32([nhwc(f) for f in feats], boxes.cuda(), H, W, want_mean=True)
+    check("f32_roialign.tiles", roi.view(n * M, 49, 256).permute(0, 2, 1), ref.reshape(n * M, 256, 49), 1e-5, 1e-5)
+    check("f32_roialign.mean", mean, ref.reshape(n * M, 256, 49).mean(-1), 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("B,lq,lk", [(2, 300, 300), (1, 777, 900), (1, 64, 37), (3, 17, 1)])
+def test_f32_mha(dv, B, lq, lk):
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(B, L, 256, generator=g) for L in (lq, lk, lk))
+    qh, kh, vh = (t.double().view(B, -1, 8, 32).transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(32.0), dim=-1)
+    ref = (p @ vh).transpose(1, 2).reshape(B, lq, 256).float()
+    out = dv.mha_f32(q.cuda(), k.cuda(), v.cuda(), 8)
+    check(f"f32_mha[{B},{lq},{lk}]", out, ref, 2e-5, 2e-5)
+
+
+def _head_state(seed=0):
+    from diffusionvid_amd.utils import synthetic
+    sd = synthetic.make_head_state_dict(seed)
+    return sd, {k: v.float() for k, v in sd.items()}
+
+
+def test_f32_dynconv(dv):
+    """box_head.py:687-711 up to (not including) out_layer, on un-rounded parameters"""
+    sd, _ = _head_state()
+    g = torch.Generator().manual_seed(6)
+    R, d, dd = 77, 256, 64
+    roi = torch.randn(R, 49, d, generator=g)
+    params = torch.randn(R, 2 * d * dd, generator=g) / 8.0
+    pfx = "head.head_series.0.inst_interact"
+    p1 = params[:, :d * dd].view(R, d, dd)
+    p2 = params[:, d * dd:].view(R, dd, d)
+    f = torch.bmm(roi.double(), p1.double())
+    f = F.relu(F.layer_norm(f, (dd,), sd[pfx + ".norm1.weight"].double(), sd[pfx + ".norm1.bias"].double()))
+    f = torch.bmm(f, p2.double())
+    ref = F.relu(F.layer_norm(f, (d,), sd[pfx + ".norm2.weight"].double(), sd[pfx + ".norm2.bias"].double())).float()
+    packed = torch.cat([p1.transpose(1, 2).reshape(R, -1), p2.transpose(1, 2).reshape(R, -1)], dim=1).contiguous()      # P1T | P2T (model.hip: make_head)
+    out = dv.dynconv_f32(roi.cuda(), packed.cuda(), *(sd[pfx + k].cuda() for k in (".norm1.weight", ".norm1.bias", ".norm2.weight", ".norm2.bias")))
+    check("f32_dynconv", out, ref, 3e-5, 3e-5)
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_f32_rcnn_head(dv, cond):
+    """One RCNNHead / RCNNHead_cond pass (box_head.py:495-548, :605-664) with DTYPE float32 against the fp32 oracle: the same test as
+    test_gpu_kernels.py::test_rcnn_head with bounds 100 x tighter (2e-4 against 2e-2)."""
+    sd, sdo = _head_state()
+    g = torch.Generator().manual_seed(7)
+    n, M, H, W = 2, 300, 160, 256
+    feats = [torch.randn(n, 256, H // s, W // s, generator=g) * 0.5 for s in (8, 16, 32)]
+    boxes = _boxes(g, n, M, H, W)
+    boxes[0, 0] = torch.tensor([10.0, 10.0, 14.0, 13.0])
+    cfg = ohead.HeadCfg()
+    t = torch.tensor([999, 499], dtype=torch.long)
+    time = osch.time_mlp(sdo, "head.", t, 256)
+    pfx = "head.head_series_cond.0" if cond else "head.head_series.1"
+    pro = torch.randn(1, n * M, 256, generator=g)
+    cnd = torch.randn(n * M, 256, generator=g) if cond else None
+    cl, bx, of = ohead.rcnn_head(sdo, pfx, feats, boxes, pro, time, cfg, cond=cnd)
+    model = dv.Model(sd, res_blocks=(0, 0, 0, 0), precision="float32")
+    model.reserve(n, H, W, M)
+    fd = [nhwc(f) for f in feats]
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gl, gb, go = model.rcnn_head(0 if cond else 1, fd, H, W, boxes.cuda(), pro[0].cuda(), t, cond=None if cnd is None else cnd.cuda(), bad_flag=flag)
+    tag = "cond" if cond else "plain"
+    check(f"f32_rcnn_head[{tag}].obj_features", go, of[0], 2e-4, 2e-4)
+    check(f"f32_rcnn_head[{tag}].logits", gl, cl, 2e-4, 2e-4)
+    bw = (boxes[..., 2:] - boxes[..., :2]).clamp(min=1.0).max(-1).values
+    err = ((gb.cpu() - bx).abs().max(-1).values / bw).max().item()
+    print(f"f32_rcnn_head[{tag}].boxes rel-to-size err max={err:.3e}")
+    assert err < 3e-4
+    assert int(flag.item()) == 0
+    # first head: pro_features None -> mean of the RoI tiles
+    cl0, bx0, of0 = ohead.rcnn_head(sdo, "head.head_series.0", feats, boxes, None, time, cfg)
+    gl0, gb0, go0 = model.rcnn_head(0, fd, H, W, boxes.cuda(), None, t)
+    check(f"f32_rcnn_head[{tag}].first.obj_features", go0, of0[0], 2e-4, 2e-4)
+    check(f"f32_rcnn_head[{tag}].first.logits", gl0, cl0, 2e-4, 2e-4)
+    # an fp16 map handed to an fp32 model is refused, not reinterpreted
+    from diffusionvid_amd._lib import DvidError
+    with pytest.raises(DvidError):
+        model.rcnn_head(0, [f.half() for f in fd], H, W, boxes.cuda(), None, t)
+    model.close()
+
+
+def test_f32_global_xattn(dv):
+    sd, sdo = _head_state()
+    g = torch.Generator().manual_seed(8)
+    rows, lk = 600, 900
+    q = torch.randn(1, rows, 256, generator=g)
+    mem = torch.randn(lk, 256, generator=g)
+    ref = ohead.global_attention(sdo, "head.", q, [mem, None], ohead.HeadCfg())
+    model = dv.Model(sd, res_blocks=(0, 0, 0, 0), precision="float32")
+    model.reserve(2, 64, 64, 300)
+    memd = mem.cuda()
+    out = model.global_xattn(q[0].cuda(), memd)
+    check("f32_global_xattn", out, ref, 1e-4, 1e-4)
+    model.close()
+
+
+def test_f32_backbone_small(dv):
+    """Reduced-depth ResNet-FPN on 2 frames of 128 x 192 with DTYPE float32 against the fp32 oracle (the fp16 path's bound here is 3e-2)."""
+    from diffusionvid_amd.utils import synthetic
+    blocks = (1, 2, 2, 1)
+    sd = synthetic.make_state_dict(0, blocks=blocks)
+    g = torch.Generator().manual_seed(14)
+    imgs = torch.rand(2, 3, 128, 192, generator=g)
+    cfg_mean, cfg_std = (123.675, 116.280, 103.530), (58.395, 57.120, 57.375)
+    ref = backbone_r101.backbone_r101_fpn(backbone_r101.normalizer(imgs, cfg_mean, cfg_std), sd, "backbone.", blocks)
+    model = dv.Model(sd, res_blocks=blocks, precision="float32")
+    model.reserve(2, 128, 192, 300)
+    p3, p4, p5 = model.backbone(imgs.cuda())
+    assert p3.dtype == torch.float32
+    for name, got in (("p3", p3), ("p4", p4), ("p5", p5)):
+        check(f"f32_backbone_small.{name}", dv.nchw_from_nhwc(got), ref[name], 2e-4, 2e-4)
+    # the pointer-table entry point gives the same maps
+    q3, _, _ = model.backbone_frames([imgs[i:i + 1].cuda() for i in range(2)])
+    assert torch.equal(q3, p3)
+    model.close()
+
+
+def test_f32_swin_is_refused_not_run_in_fp16(dv):
+    from diffusionvid_amd._lib import DvidError
+    from diffusionvid_amd.utils import synthetic
+    sw = dict(embed_dim=64, depths=(2, 2, 2, 1), heads=(2, 4, 8, 16), window=7)
+    sd = synthetic.make_state_dict(0, blocks=(0, 0, 0, 0), swin=sw)
+    with pytest.raises(DvidError, match="float32"):
+        dv.Model(sd, res_blocks=(0, 0, 0, 0), backbone="swin", swin_embed_dim=64, swin_depths=sw["depths"], swin_heads=sw["heads"], precision="float32")
+    with pytest.raises(DvidError, match="precision"):
+        dv.Model(sd, res_blocks=(0, 0, 0, 0), precision="bfloat16")

@@ -18,7 +18,7 @@ def run(la, frames=120):
     from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
     from diffusionvid_amd.modeling.detector import build_detection_model
     from diffusionvid_amd.utils import synthetic
-    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["INPUT.LOOKAHEAD_BATCHES", la, "MODEL.DiffusionDet.SAMPLE_STEP", 1], "configs/BASE_RCNN_1gpu.yaml")
+    cfg = get_cfg("configs/vid_R_101_DiffusionVID.yaml", ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", la, "MODEL.DiffusionDet.SAMPLE_STEP", 1], "configs/BASE_RCNN_1gpu.yaml")
     cfg.freeze()
     model = build_detection_model(cfg)
     model.load_state_dict(synthetic.tame_box_deltas(model.state_dict(), 0.1))

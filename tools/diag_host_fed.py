@@ -10,7 +10,7 @@ from diffusionvid_amd.engine import inference as engine
 from diffusionvid_amd.modeling.detector import build_detection_model
 from diffusionvid_amd.utils import synthetic
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["INPUT.LOOKAHEAD_BATCHES", 13], os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", 13], os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
 dev = torch.device("cuda")
 model = build_detection_model(cfg).to(dev).eval()
 model.noise_fn = synthetic.noise_fn

@@ -38,7 +38,7 @@ def main():
     from diffusionvid_amd.utils import synthetic
     from oracle import backbone_r101, detector as odet, precision
     blocks = tuple(int(b) for b in args.blocks.split(","))
-    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["MODEL.VID.MEGA.GLOBAL.SIZE", args.global_frames],
+    cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16", "MODEL.VID.MEGA.GLOBAL.SIZE", args.global_frames],
                   os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
     cfg.MODEL.RESNETS.BLOCKS_OVERRIDE = None if blocks == (3, 4, 23, 3) else blocks
     cfg.freeze()

@@ -17,7 +17,7 @@ from diffusionvid_amd.utils import synthetic  # noqa: E402
 
 la = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 ss = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["INPUT.LOOKAHEAD_BATCHES", la, "MODEL.DiffusionDet.SAMPLE_STEP", ss], os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
+cfg = get_cfg(os.path.join(ROOT, "configs/vid_R_101_DiffusionVID.yaml"), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", la, "MODEL.DiffusionDet.SAMPLE_STEP", ss], os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
 cfg.freeze()
 model = build_detection_model(cfg).to("cuda").eval()
 model.noise_fn = synthetic.noise_fn
