@@ -44,7 +44,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from diffusionvid_amd import _lib  # noqa: E402
+from diffusionvid_amd import _lib, ops  # noqa: E402
 from diffusionvid_amd.config import get_cfg  # noqa: E402
 from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset  # noqa: E402
 from diffusionvid_amd.engine import inference as engine  # noqa: E402
@@ -70,12 +70,16 @@ def _md5(path):
 # traffic comes from another build says so
 LIB_MD5 = _md5(os.path.join(ROOT, "diffusionvid_amd", "libdvid_hip.so"))
 PEAK_FP16_TFLOPS = 2500.0
+PEAK_FP32_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md): the DTYPE float32 path's roof
+# the library's option table at its defaults (csrc/options.h): the configuration every number of this file is quoted on unless --option says otherwise;
+# tests/test_host_logic.py::test_default_library_configuration_is_the_benchmarked_one holds the library to this string
+DEFAULT_LIBRARY_CONFIG = "conv3x3=1 wstat=1 bneck_fuse=1 stem_pool=1 head_tail=1 ln_rows=1 igemm_cfg=-1 igemm_tune=-1 igemm_generic=0 bneck_lds=0"
 PEAK_HBM_GBS = 8000.0
 # algorithmic work per output frame: backbone + heads + global attention, faithful pass counts
 ALG_GFLOP_PER_FRAME = {("r101", 1): 249.3, ("r101", 4): 385.0, ("swinb", 1): 459.6}
 
 
-def top_kernels(csv_path, n=5):
+def top_kernels(csv_path, n=5, mfma_peak=PEAK_FP16_TFLOPS):
     """The per-launch table of the library (dvid_profile_dump: HIP events around every launch of the instrumented pass, chains off) grouped
     by (kernel, shape); the `n` heaviest groups, each against its own roof: algorithmic intensity below the ridge of the part (2500 TFLOP/s /
     8 TB/s = 312 FLOP/B) -> HBM bound, achieved = algorithmic bytes / time; else MFMA bound, achieved = algorithmic FLOP / time."""
@@ -94,13 +98,13 @@ def top_kernels(csv_path, n=5):
     out = []
     for key, (calls, ms, flop, nbytes) in sorted(groups.items(), key=lambda kv: -kv[1][1])[:n]:
         kernel, M, N, K, taps, stride, res = key
-        hbm = nbytes > 0 and flop / nbytes < PEAK_FP16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        hbm = nbytes > 0 and flop / nbytes < mfma_peak * 1e12 / (PEAK_HBM_GBS * 1e9)
         ach = nbytes / (ms * 1e-3) / 1e9 if hbm else flop / (ms * 1e-3) / 1e12
         out.append({"name": "%s [M %d, N %d, K %d%s%s%s]" % (kernel, M, N, K, ", %d taps" % taps if taps > 1 else "", ", stride %d" % stride if stride > 1 else "",
                                                              {0: "", 1: ", + residual", 2: ", + upsampled residual", 3: ", fused block tail", 4: ", fused block tail + shortcut"}.get(res, "")),
                     "launches": calls, "ms": round(ms, 3), "share": round(ms / total, 4) if total else None, "bound": "hbm" if hbm else "mfma",
-                    "achieved": round(ach, 1), "unit": "GB/s" if hbm else "TFLOP/s", "peak": PEAK_HBM_GBS if hbm else PEAK_FP16_TFLOPS,
-                    "frac": round(ach / (PEAK_HBM_GBS if hbm else PEAK_FP16_TFLOPS), 4)})
+                    "achieved": round(ach, 1), "unit": "GB/s" if hbm else "TFLOP/s", "peak": PEAK_HBM_GBS if hbm else mfma_peak,
+                    "frac": round(ach / (PEAK_HBM_GBS if hbm else mfma_peak), 4)})
     return {"recorded_ms": round(total, 2), "what": "share = of the recorded kernel time of one step (implicit-GEMM family + RoIAlign, DynamicConv, attention, head tail, max pool; chains off)",
             "kernels": out}
 
@@ -371,6 +375,33 @@ def dry_run(args, rank, world):
         comm.init_dist("gloo")
         assert dist.get_world_size() == args.gpus
     L = args.frames
+    if args.workload == "vidval":
+        # BASELINE.json configs[4] without a GPU: the 555-video / 176126-frame VID-val-shaped set sharded over the ranks by whole videos
+        # (data/samplers.balanced_video_partition -- what `--workload vidval` runs), each rank's load gathered to rank 0, and the host-thread
+        # cap every rank would run with under the container's CPU quota (--assume-cpu-quota N injects one: the GPU boxes grant 16 of 256 CPUs)
+        from diffusionvid_amd.data.samplers import balanced_video_partition, vid_val_shaped_lengths
+        lens = vid_val_shaped_lengths()
+        mine = balanced_video_partition(lens, world)[rank]
+        quota = args.assume_cpu_quota if args.assume_cpu_quota > 0 else comm.cpu_quota()
+        share = comm.rank_cpu_share(rank, world, allowed=range(args.assume_cpus if args.assume_cpus > 0 else (os.cpu_count() or 1)))
+        rec = {"rank": rank, "videos": len(mine), "frames": int(sum(lens[v] for v in mine)), "cpus": len(share),
+               "threads": comm.rank_thread_cap(len(share), world, quota)}
+        recs = [None] * world
+        if world > 1:
+            dist.all_gather_object(recs, rec)
+        else:
+            recs = [rec]
+        if rank == 0:
+            loads = [r["frames"] for r in recs]
+            print(json.dumps({"metric": "dry run (vidval partition + host-thread caps)", "n_gpus": world, "videos": sum(r["videos"] for r in recs),
+                              "frames": sum(loads), "heaviest_over_mean": round(max(loads) / (sum(loads) / world), 5), "cpu_quota_cpus": quota,
+                              "threads_per_rank": [r["threads"] for r in recs], "cpus_per_rank": [r["cpus"] for r in recs],
+                              "note": "config #5 on real JPEGs is decode-bound at a 16-CPU quota: ~310 decoded frames/s per granted CPU "
+                                      "(profiles/r05m_feed_groups.txt) against ~2300 frames/s per rank"}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
     res = {}
     for f in range(L):
         k = (f * 7 + rank) % 5
@@ -404,6 +435,11 @@ def main():
     ap.add_argument("--skip-unobservable", action="store_true",
                     help="MODEL.DiffusionDet.SKIP_UNOBSERVABLE for the main measurement (x4 only; SURVEY.md Appendix B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="set a library option (csrc/options.h; A/B runs -- tools/ab_bench.sh): the line's build.library_config echoes the table, "
+                         "and a run with any non-default option says so in build.default_configuration")
+    ap.add_argument("--dtype", choices=("float16", "float32"), default="float16",
+                    help="the reference's DTYPE key for the HEADLINE configuration (BASELINE.json configs[1] is fp16; float32 = csrc/f32.hip)")
     ap.add_argument("--smooth-frames", action="store_true", help="low-frequency synthetic frames (the parity tests' content) instead of white noise: the chip runs at its "
                     "1.4 kW power limit on this workload, so its clock -- and the frame rate -- depends on how much the data toggles (A/B only; the default stays white noise)")
     ap.add_argument("--host-noise", action="store_true", help="draw the DDIM noise with the host generator and upload it (rounds 1-3) instead of on the device")
@@ -418,6 +454,8 @@ def main():
                          "BASELINE.json configs[4] -- a 555-video / 176126-frame VID-val-shaped set (data/samplers.vid_val_shaped_lengths) "
                          "sharded over the ranks by balanced_video_partition, strong scaling; one step = the whole set (or --videos K of it)")
     ap.add_argument("--videos", type=int, default=0, help="vidval: use only the first K videos of the set (0 = all 555)")
+    ap.add_argument("--assume-cpu-quota", type=float, default=0, help="--dry --workload vidval: the container CPU quota to plan host threads for (0 = read cgroup cpu.max)")
+    ap.add_argument("--assume-cpus", type=int, default=0, help="--dry --workload vidval: the host's CPU count to plan for (0 = os.cpu_count())")
     ap.add_argument("--force-dist", action="store_true",
                     help="build the process group even for one rank (env:// rendezvous on 127.0.0.1) so that a single GPU runs the RCCL "
                          "gather / all-reduce path of the N-rank job (tests/test_gpu_dist.py)")
@@ -476,7 +514,10 @@ def main():
         comm.init_dist("nccl", force=True, timeout_s=900)
         assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
 
-    headline = args.arch == "r101" and args.sample_step == 1
+    for kv in args.option:
+        name, _, val = kv.partition("=")
+        ops.set_option(name, int(val))
+    headline = args.arch == "r101" and args.sample_step == 1 and args.dtype == "float16"
     if args.lookahead <= 0:
         args.lookahead = 38 if args.arch == "r101" else 76          # one launch group per 304-frame video (~60 GB of workspace on a 288 GB part)
     H, W, L = 600, 1000, args.frames
@@ -487,9 +528,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def build(arch, sample_step, lookahead, skip_unobservable=False, extra=()):
+    def build(arch, sample_step, lookahead, skip_unobservable=False, extra=(), dtype="float16"):
         yaml = "configs/vid_R_101_DiffusionVID.yaml" if arch == "r101" else "configs/vid_Swin_B_DiffusionVID.yaml"
-        cfg = get_cfg(os.path.join(ROOT, yaml), ["DTYPE", "float16", "INPUT.LOOKAHEAD_BATCHES", lookahead,
+        cfg = get_cfg(os.path.join(ROOT, yaml), ["DTYPE", dtype, "INPUT.LOOKAHEAD_BATCHES", lookahead,
                                                  "MODEL.DiffusionDet.SAMPLE_STEP", sample_step,
                                                  "MODEL.DiffusionDet.SKIP_UNOBSERVABLE", bool(skip_unobservable)] + list(extra),
                       os.path.join(ROOT, "configs/BASE_RCNN_1gpu.yaml"))
@@ -553,7 +594,7 @@ def main():
 
     if args.workload == "vidval":
         return vidval(args, build, timed, barrier, device, rank, world, H, W)
-    cfg, model = build(args.arch, args.sample_step, args.lookahead, args.skip_unobservable)
+    cfg, model = build(args.arch, args.sample_step, args.lookahead, args.skip_unobservable, dtype=args.dtype)
     ds = SyntheticVIDDataset([L], cfg, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False, smooth=args.smooth_frames)
     ds.preload()
     if shared_tune and rank != 0:
@@ -593,6 +634,7 @@ def main():
     lib = _lib.load()
 
     def measure_roofline(model, ds, arch, sample_step, fps, frames_per_step, lookahead):
+        f32 = model.dtype == "float32"
         """per-launch HIP events on the library's stream; sub-batch chains are switched off for this pass so that launches do
         not overlap and each event pair times one kernel alone (the same condition the rocprofv3 summaries in profiles/ are
         taken under: DVID_CHAINS=1)"""
@@ -620,17 +662,19 @@ def main():
         top = None
         if rank == 0:
             import tempfile
-            cfg_tag = "%s_x%d%s" % (arch, sample_step, "" if lookahead > 1 else "_lookahead1")
+            cfg_tag = "%s_x%d%s%s" % (arch, sample_step, "" if lookahead > 1 else "_lookahead1", "_float32" if f32 else "")
             keep = os.environ.get("DVID_PROFILE_DUMP")
             if keep and "{cfg}" in keep:
                 path = keep.replace("{cfg}", cfg_tag)
-            elif keep and arch == args.arch and sample_step == args.sample_step and lookahead == args.lookahead:
+            elif keep and arch == args.arch and sample_step == args.sample_step and lookahead == args.lookahead and model.dtype == args.dtype:
                 path = keep
             else:
-                keep, path = None, tempfile.mkstemp(suffix=".csv")[1]
+                fd, path = tempfile.mkstemp(suffix=".csv")
+                os.close(fd)
+                keep = None
             try:
                 _lib.check(lib.dvid_profile_dump(path.encode()), "dvid_profile_dump")
-                top = top_kernels(path)
+                top = top_kernels(path, mfma_peak=PEAK_FP32_TFLOPS if f32 else PEAK_FP16_TFLOPS)
             finally:
                 if not keep:
                     os.unlink(path)
@@ -641,9 +685,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", traffic_file)
         if traffic_file and os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS configuration (cannot be collected in-process)
             pmc = json.load(open(tpath))
-            traffic = round(pmc["hbm_bytes_per_launch"])
-            mfma_busy = pmc.get("mfma_busy_fraction")
             stamp = pmc.get("library_md5")
+            if stamp == LIB_MD5 and not f32:          # a profile of ANOTHER build (or another precision) is refused, not reported with a warning
+                traffic = round(pmc["hbm_bytes_per_launch"])
+                mfma_busy = pmc.get("mfma_busy_fraction")
         if ms.value <= 0:
             return None
         sec = ms.value * 1e-3
@@ -654,16 +699,20 @@ def main():
         # kFLOP/B); `achieved` = algorithmic FLOP of the launches / their summed durations.  The layer-by-layer byte model
         # (every layer's input + weights + output + residual once) and the measured traffic are printed next to it: their
         # ratio to the ideal-fusion figure is the activation round-trip traffic that fusion has yet to remove.
-        r = {"bound": "mfma", "kernel": "implicit-GEMM conv/linear kernels, fp16 MFMA (igemm2_kernel; conv3x3_* for the 3x3 / stride-1 layers; wstat_kernel for the short-K / wide-N 1x1 layers; bneck64 / bneck128_tail_kernel = a res2 / res3 block behind its conv1 as one launch)",
-             "achieved": round(tflops, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP16_TFLOPS, 4),
+        peak = PEAK_FP32_TFLOPS if f32 else PEAK_FP16_TFLOPS
+        r = {"bound": "mfma", "kernel": ("implicit-GEMM conv/linear kernel of the DTYPE float32 path, fp32 MFMA v_mfma_f32_32x32x2_f32 (f32_igemm_kernel, csrc/f32.hip)" if f32 else
+                                         "implicit-GEMM conv/linear kernels, fp16 MFMA (igemm2_kernel; conv3x3_* for the 3x3 / stride-1 layers; wstat_kernel for the short-K / wide-N 1x1 layers; bneck64 / bneck128_tail_kernel = a res2 / res3 block behind its conv1 as one launch)"),
+             "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
              "traffic": traffic,
              "traffic_source": ("profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh on this "
-                                "configuration's workload, bytes per launch; not collected in this run%s)"
-                                % (traffic_file, "" if stamp in (None, LIB_MD5) else "; COLLECTED ON ANOTHER BUILD of the library (md5 %s, this run %s)" % (stamp, LIB_MD5))) if traffic is not None
+                                "configuration's workload and THIS build of the library, md5 %s; bytes per launch; not collected in this run)"
+                                % (traffic_file, stamp)) if traffic is not None
+                               else ("refused: profiles/%s was collected on another build of the library (md5 %s, this run %s) -- re-run tools/profile_round.sh"
+                                     % (traffic_file, stamp, LIB_MD5)) if (stamp is not None and not f32)
                                else "no PMC profile of this configuration is committed (tools/profile_round.sh <tag> --arch ... --sample-step ...)",
              "mfma_busy_pmc": None if mfma_busy is None else round(mfma_busy, 4),
              "end_to_end_tflops": round(fps / max(world, 1) * gflop_frame / 1e3, 1),
-             "end_to_end_frac": round(fps / max(world, 1) * gflop_frame / 1e3 / PEAK_FP16_TFLOPS, 4),
+             "end_to_end_frac": round(fps / max(world, 1) * gflop_frame / 1e3 / peak, 4),
              "layerwise_alg_gbs": round(gbs, 1), "layerwise_alg_hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
              "layerwise_alg_mbytes_per_launch": round(ab.value / max(1, nl.value) / 1e6, 2),
              "ideal_fusion_mbytes_per_frame": "60-90 (SURVEY.md 8d)",
@@ -685,16 +734,16 @@ def main():
     del model
     others = {}
 
-    def side(name, arch, sample_step, lookahead, steps, skip_unobservable=False, extra=(), note=None, with_roofline=False):
+    def side(name, arch, sample_step, lookahead, steps, skip_unobservable=False, extra=(), note=None, with_roofline=False, dtype="float16"):
         try:
-            c2, m2 = build(arch, sample_step, lookahead, skip_unobservable, extra)
+            c2, m2 = build(arch, sample_step, lookahead, skip_unobservable, extra, dtype=dtype)
             d2 = SyntheticVIDDataset([L], c2, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
             d2._cache = ds._cache                  # same frames, already resident
             with torch.no_grad():
                 run_video(m2, d2, device)
             t2, f2 = timed(m2, d2, steps, 1)
             others[name] = {"value": round(f2 / t2, 2), "unit": "frames/sec", "ms_per_step": round(t2 / steps * 1e3, 2),
-                            "lookahead_batches": lookahead, "infer_batch": c2.INPUT.INFER_BATCH, "sample_step": sample_step, "steps": steps,
+                            "lookahead_batches": lookahead, "infer_batch": c2.INPUT.INFER_BATCH, "sample_step": sample_step, "steps": steps, "DTYPE": dtype,
                             "host_blocked_on_gpu_frac": timed.last["host_blocked_on_gpu_frac_min_over_ranks"]}
             if lookahead == 1:
                 others[name]["call_graph_replays"] = m2.graph_replays          # calls served by one hipGraph launch each (0: kernel by kernel)
@@ -714,6 +763,12 @@ def main():
             # 12 observable head passes per frame instead of the faithful 19 (same detections)
             side("r101_x4_observable_passes_only", "r101", 4, 38, 5, skip_unobservable=True)
             side("swinb_x1", "swinb", 1, 76, 5, with_roofline=True)
+            # `DTYPE float32` (the reference's default precision; round 6): fp32 storage + fp32 MFMA end to end (csrc/f32.hip) -- the mode in
+            # which the path meets SURVEY.md 8(d)'s tolerances against the fp32 oracle (tests/test_gpu_e2e.py); 1/16 of the fp16 MFMA rate
+            f32_note = ("DTYPE float32: every weight and activation fp32, products on v_mfma_f32_32x32x2_f32 (157 TFLOP/s dense peak); groups of 13 "
+                        "batches (104 frames)")
+            side("r101_x1_float32", "r101", 1, 13, 2, with_roofline=True, dtype="float32", note=f32_note)
+            side("r101_x4_float32", "r101", 4, 13, 2, dtype="float32", note=f32_note)
             # the latency-oriented variant of demo/demo.py:60-68 -- one frame per call, one new global frame per
             # call merged into the memory and pruned back (vid_mega.py:213-215)
             side("r101_x1_streaming", "r101", 1, 1, 3,
@@ -750,11 +805,11 @@ def main():
             "metric": "frames/sec (1000x600) DiffusionVID-%s x%d" % ("R101" if args.arch == "r101" else "SwinB", args.sample_step),
             "value": round(total_frames / dt, 2), "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "%s DiffusionVID x%d fp16, 300 boxes, %d DDIM step(s); one step = one synthetic "
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "float32" else "f16", "data": "synthetic",
+            "config": {"workload": "%s DiffusionVID x%d %s, 300 boxes, %d DDIM step(s); one step = one synthetic "
                                    "%d-frame 1000x600 video per GPU (24 global + %d local frames, %d batches of %d)"
-                                   % ("ResNet-101" if args.arch == "r101" else "Swin-Base", args.sample_step, args.sample_step, L, L,
-                                      -(-L // infer_batch), infer_batch),
+                                   % ("ResNet-101" if args.arch == "r101" else "Swin-Base", args.sample_step, "fp32" if args.dtype == "float32" else "fp16",
+                                      args.sample_step, L, L, -(-L // infer_batch), infer_batch),
                        "frames_per_step_per_gpu": L, "infer_batch": infer_batch, "lookahead_batches": args.lookahead,
                        "lookahead_note": "the dataset emits the reference's unchanged item dict (vid_mega.py:236-248); the engine loop reads the "
                                          "group's later items ahead and hands their frames to the detector with the group's first call "
@@ -769,6 +824,10 @@ def main():
                       # every DVID_* variable the library or the host side reads decides which kernel / schedule ran: the ones set in
                       # this process's environment are listed; anything not listed ran on its default
                       "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DVID_")},
+                      # the library's option table as it stood during the timed region (csrc/options.h; dvid_effective_config) and whether
+                      # it is the default one -- tests/test_host_logic.py pins the default string
+                      "tuner_timing_passes": int(_lib.load().dvid_igemm_tuning_passes()),          # shape buckets timed in this process (set-up + side configurations)
+                      "library_config": ops.effective_config(), "default_configuration": ops.effective_config().split(" DVID_")[0] == DEFAULT_LIBRARY_CONFIG,
                       "noise": "host generator + upload" if args.host_noise else "device (dvid_counter_normal)",
                       "shared_tuner_cache": shared_tune, "rank0_cpus": None if cpus is None else "%d CPUs: %d..%d" % (len(cpus), cpus[0], cpus[-1])},
             "host_view": host_view,

@@ -37,7 +37,7 @@ SIGNATURES = {
     "dvid_set_chains": (c_int, [c_void_p, c_int]),
     "dvid_set_stem_layout": (c_int, [c_void_p, c_int]),
     "dvid_workspace_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
-    "dvid_workspace_generation": (C.c_ulonglong, []),
+    "dvid_workspace_generation": (C.c_ulonglong, [c_void_p]),
     "dvid_backbone_resnet_fpn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvid_backbone_swin_fpn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvid_backbone_resnet_fpn_frames": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -77,10 +77,15 @@ SIGNATURES = {
     "dvid_igemm_num_configs": (c_int, []),
     "dvid_igemm_set_config": (c_int, [c_int]),
     "dvid_igemm_set_tuning": (c_int, [c_int]),
+    "dvid_igemm_tuning_passes": (C.c_longlong, []),
     "dvid_igemm_set_conv3x3": (c_int, [c_int]),
     "dvid_igemm_set_wstat": (c_int, [c_int]),
     "dvid_igemm_set_bottleneck_fusion": (c_int, [c_int]),
     "dvid_set_stem_pool": (c_int, [c_int]),
+    "dvid_set_option": (c_int, [C.c_char_p, c_int]),
+    "dvid_get_option": (c_int, [C.c_char_p, C.POINTER(c_int)]),
+    "dvid_reset_options": (c_int, []),
+    "dvid_effective_config": (c_int, [C.c_char_p, c_int]),
     "dvid_profile_enable": (c_int, [c_int]),
     "dvid_profile_reset": (c_int, []),
     "dvid_profile_dump": (c_int, [C.c_char_p]),

@@ -643,7 +643,10 @@ void tune_cache_append(const ShapeKey& k, int cfg, int n) {
 void* g_tune_scratch = nullptr;
 size_t g_tune_scratch_bytes = 0;
 
+std::atomic<long long> g_tune_passes{0};          // shape buckets timed on the calling path so far (dvid_igemm_tuning_passes; bench.py reports it)
+
 int tune_shape(const IgemmParams& p, hipStream_t s, const TileCfg* cfgs, int ncfg, int fallback, int* best_out) {
+    g_tune_passes.fetch_add(1, std::memory_order_relaxed);
     const size_t out_bytes = (size_t)p.M * p.ldc * (p.out_f32 ? 4 : 2) * (p.splitk > 1 ? p.splitk : 1);
     HIP_TRY(hipStreamSynchronize(s));           // a quiet stream for the timings; other streams keep running
     if (out_bytes > g_tune_scratch_bytes) {
@@ -740,6 +743,7 @@ int nearest_bucket_cfg(const ShapeKey& k, const TileCfg* cfgs) {
 }  // namespace
 
 int dvid_igemm_num_configs(void) { return kNumCfg; }
+long long dvid_igemm_tuning_passes(void) { return g_tune_passes.load(std::memory_order_relaxed); }
 
 int dvid_igemm_set_config(int cfg) {
     if (cfg < -1 || cfg >= kNumCfg) return DVID_ERR_ARG;

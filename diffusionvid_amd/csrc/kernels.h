@@ -35,8 +35,7 @@ int dvid_wstat_launch(const IgemmParams& p, hipStream_t s);
 // bneck.hip: the tail of a res2 bottleneck block (conv2 3x3 64 -> 64, conv3 64 -> 256 + residual or shortcut convolution, ReLU and the
 // next block's conv1 256 -> 64) as one launch; bit-identical to the layer-by-layer launches.  ws == null: the residual is `res`
 // [rows][W][256]; else `res` is the 64-channel block input and the residual is its shortcut convolution.  w1n == null: no next conv1.
-bool dvid_bneck64_tail_preferred(int H, int W);
-bool dvid_bneck_stage_enabled(int stage);          // DVID_BNECK_STAGES bit mask (diagnostics): 0 = res2, 1 = res3     // the shape rule (a function of the map size only), for either width
+bool dvid_bneck64_tail_preferred(int H, int W);          // the shape rule (a function of the map size only), for either width
 // 128-wide blocks (res3: 128 -> 128 -> 512; weights streamed through an LDS ring).  w2 == null: `t1` is the conv2 output (res3's first
 // block, whose 3x3 / stride-2 conv2 runs as its own launch); w1n == null: no next conv1.  Bit-identical to the layer-by-layer launches
 // on igemm2 (the chunked 3x3 patch kernel sums in another order).

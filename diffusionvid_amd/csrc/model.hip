@@ -184,17 +184,16 @@ struct HostTensor {
     }
 };
 
-// Bumped whenever a workspace buffer moves (DevBuf::ensure re-allocating).  A captured launch sequence holds raw pointers into the
-// workspace: the detector compares this counter with the value it saw at capture time and drops its graphs when it differs
-// (dvid_workspace_generation).
-static std::atomic<unsigned long long> g_workspace_generation{0};
-
+// A captured launch sequence holds raw pointers into the workspace: every model counts the moves of ITS buffers (`gen`, bumped when a
+// buffer that already existed is re-allocated -- a first allocation cannot have been captured), the detector compares the counter with the
+// value it saw at capture time and drops its graphs when it differs (dvid_workspace_generation).  Per model: another model's growth, or
+// this model's first allocations, no longer throw this model's graphs away.
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
-    int ensure(size_t n) {
+    int ensure(size_t n, std::atomic<unsigned long long>* gen = nullptr) {
         if (n <= bytes) return DVID_OK;
-        g_workspace_generation.fetch_add(1, std::memory_order_relaxed);
+        if (gen && p) gen->fetch_add(1, std::memory_order_relaxed);
         if (p) HIP_TRY(hipFree(p));
         p = nullptr;
         bytes = 0;
@@ -275,6 +274,7 @@ struct dvid_model {
     dvid_config cfg;
     std::map<std::string, HostTensor> raw;
     bool finalized = false;
+    std::atomic<unsigned long long> ws_gen{0};          // moves of this model's workspace buffers (DevBuf::ensure)
     int precision = 0;         // 0: fp16 storage / fp16 MFMA (DTYPE float16), 1: fp32 storage / fp32 MFMA (DTYPE float32); dvid_model_set_precision
     std::vector<void*> owned;  // device allocations of weights
 
@@ -1287,7 +1287,7 @@ int dvid_set_stem_pool(int mode) {
     return DVID_OK;
 }
 
-unsigned long long dvid_workspace_generation(void) { return g_workspace_generation.load(std::memory_order_relaxed); }
+unsigned long long dvid_workspace_generation(const dvid_model* m) { return m ? m->ws_gen.load(std::memory_order_relaxed) : 0ull; }
 
 int dvid_set_chains(dvid_model* m, int nchain) {
     g_err[0] = 0;
@@ -1312,49 +1312,49 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
     const size_t es = m->precision == 1 ? 2 : 1;            // DTYPE float32: every fp16 buffer below holds fp32 values instead
     if (m->has_backbone && m->cfg.backbone_type == 1) {
         const size_t C0 = m->cfg.swin_embed_dim, M0 = n * px4;      // stage-0 tokens; M*C halves per stage
-        TRY(m->img8.ensure(n * height * width * 8 * 2));
-        TRY(m->sw_x.ensure(M0 * C0 * 4));
-        TRY(m->sw_x2.ensure(M0 * C0 * 4 / 2));
-        TRY(m->sw_ln16.ensure(M0 * C0 * 2));
-        TRY(m->sw_qkv16.ensure(M0 * C0 * 3 * 2));
-        TRY(m->sw_attn16.ensure(M0 * C0 * 2));
-        TRY(m->sw_h16.ensure(M0 * C0 * 4 * 2));
-        TRY(m->c3.ensure(n * (px4 / 4) * (C0 * 2) * 2));
-        TRY(m->c4.ensure(n * (px4 / 16) * (C0 * 4) * 2));
-        TRY(m->c5.ensure(n * (px4 / 64) * (C0 * 8) * 2));
-        for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2));
+        TRY(m->img8.ensure(n * height * width * 8 * 2, &m->ws_gen));
+        TRY(m->sw_x.ensure(M0 * C0 * 4, &m->ws_gen));
+        TRY(m->sw_x2.ensure(M0 * C0 * 4 / 2, &m->ws_gen));
+        TRY(m->sw_ln16.ensure(M0 * C0 * 2, &m->ws_gen));
+        TRY(m->sw_qkv16.ensure(M0 * C0 * 3 * 2, &m->ws_gen));
+        TRY(m->sw_attn16.ensure(M0 * C0 * 2, &m->ws_gen));
+        TRY(m->sw_h16.ensure(M0 * C0 * 4 * 2, &m->ws_gen));
+        TRY(m->c3.ensure(n * (px4 / 4) * (C0 * 2) * 2, &m->ws_gen));
+        TRY(m->c4.ensure(n * (px4 / 16) * (C0 * 4) * 2, &m->ws_gen));
+        TRY(m->c5.ensure(n * (px4 / 64) * (C0 * 8) * 2, &m->ws_gen));
+        for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2, &m->ws_gen));
     }
     if (m->has_backbone && m->cfg.backbone_type == 0) {
-        TRY(m->img8.ensure(n * height * width * 8 * 2));          // (fp32: NHWC4 = the same bytes)
+        TRY(m->img8.ensure(n * height * width * 8 * 2, &m->ws_gen));          // (fp32: NHWC4 = the same bytes)
         const size_t big = n * px4 * 256 * 2 * es;  // largest activation: res2 output (also >= stem output)
-        TRY(m->bufX.ensure(big));
-        TRY(m->bufY.ensure(big));
-        TRY(m->bufT1.ensure(big));
-        TRY(m->bufT2.ensure(big));
-        TRY(m->bufSC.ensure(big));
-        TRY(m->c3.ensure(n * (px4 / 4) * 512 * 2 * es));
-        TRY(m->c4.ensure(n * (px4 / 16) * 1024 * 2 * es));
-        TRY(m->c5.ensure(n * (px4 / 64) * 2048 * 2 * es));
-        for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2 * es));
+        TRY(m->bufX.ensure(big, &m->ws_gen));
+        TRY(m->bufY.ensure(big, &m->ws_gen));
+        TRY(m->bufT1.ensure(big, &m->ws_gen));
+        TRY(m->bufT2.ensure(big, &m->ws_gen));
+        TRY(m->bufSC.ensure(big, &m->ws_gen));
+        TRY(m->c3.ensure(n * (px4 / 4) * 512 * 2 * es, &m->ws_gen));
+        TRY(m->c4.ensure(n * (px4 / 16) * 1024 * 2 * es, &m->ws_gen));
+        TRY(m->c5.ensure(n * (px4 / 64) * 2048 * 2 * es, &m->ws_gen));
+        for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2 * es, &m->ws_gen));
     }
     const size_t R = n * boxes_per_frame;
     const int d = m->cfg.hidden_dim;
-    TRY(m->roi.ensure(R * 49 * d * 2 * es));
-    TRY(m->dyn.ensure(R * 49 * d * 2 * es));
-    TRY(m->params.ensure(R * 2 * d * m->cfg.dim_dynamic * 2 * es));
-    TRY(m->qkv.ensure(R * 3 * d * 4));
-    TRY(m->attn16.ensure(R * d * 2 * es));
-    TRY(m->f32a.ensure(R * d * 4));
-    TRY(m->f32b.ensure(R * d * 4));
-    TRY(m->f32c.ensure(R * d * 4));
-    TRY(m->f32d.ensure(R * d * 4));
-    TRY(m->h16a.ensure(R * d * 2 * es));
-    TRY(m->h16b.ensure(R * d * 2 * es));
-    TRY(m->hid16.ensure(R * m->cfg.dim_feedforward * 2 * es));
-    TRY(m->ss.ensure((size_t)(m->cfg.num_heads + m->cfg.num_heads_cond) * n * 2 * d * 4));
-    TRY(m->deltas.ensure(R * 4 * 4));
-    TRY(m->splitk.ensure(R * d * 4 * 8));
-    TRY(m->vt.ensure((size_t)n * m->cfg.nheads * 32 * (((size_t)boxes_per_frame + 31) / 32 * 32 + 32) * 2));          // up to 8 split-K slabs of an [R, d] fp32 output
+    TRY(m->roi.ensure(R * 49 * d * 2 * es, &m->ws_gen));
+    TRY(m->dyn.ensure(R * 49 * d * 2 * es, &m->ws_gen));
+    TRY(m->params.ensure(R * 2 * d * m->cfg.dim_dynamic * 2 * es, &m->ws_gen));
+    TRY(m->qkv.ensure(R * 3 * d * 4, &m->ws_gen));
+    TRY(m->attn16.ensure(R * d * 2 * es, &m->ws_gen));
+    TRY(m->f32a.ensure(R * d * 4, &m->ws_gen));
+    TRY(m->f32b.ensure(R * d * 4, &m->ws_gen));
+    TRY(m->f32c.ensure(R * d * 4, &m->ws_gen));
+    TRY(m->f32d.ensure(R * d * 4, &m->ws_gen));
+    TRY(m->h16a.ensure(R * d * 2 * es, &m->ws_gen));
+    TRY(m->h16b.ensure(R * d * 2 * es, &m->ws_gen));
+    TRY(m->hid16.ensure(R * m->cfg.dim_feedforward * 2 * es, &m->ws_gen));
+    TRY(m->ss.ensure((size_t)(m->cfg.num_heads + m->cfg.num_heads_cond) * n * 2 * d * 4, &m->ws_gen));
+    TRY(m->deltas.ensure(R * 4 * 4, &m->ws_gen));
+    TRY(m->splitk.ensure(R * d * 4 * 8, &m->ws_gen));
+    TRY(m->vt.ensure((size_t)n * m->cfg.nheads * 32 * (((size_t)boxes_per_frame + 31) / 32 * 32 + 32) * 2, &m->ws_gen));          // up to 8 split-K slabs of an [R, d] fp32 output
     m->ws_frames = max_frames;
     m->ws_h = height;
     m->ws_w = width;
@@ -1433,7 +1433,9 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
             // normalise + 2x2 space-to-depth (16 halves per block: the same bytes per frame as half an NHWC8 image), then the stem
             // as a 4x4 / stride-1 convolution on the half-resolution grid
             TRY(dvid_prep_images_s2d_launch(frames + f0, img8, nf, height, width, mean, inv_std, cs));
-            if (g_opt.stem_pool) {
+            // (only while the patch kernels are on and no tile configuration is forced: "all layers on igemm2" runs -- conv3x3 = 0,
+            // dvid_igemm_set_config -- then include the stem, whose fused kernel sums in the patch kernels' order)
+            if (g_opt.stem_pool && g_opt.conv3x3 && g_opt.igemm_cfg < 0) {
                 // stem + ReLU + max pool as one launch (csrc/conv3x3.hip: stem_pool_kernel): the half-resolution 64-channel map never exists
                 TRY(conv_run(m->stem_s2d, img8, nf, h / 2, w / 2, bx, 1, 0, nullptr, 0, 0, cs, &h, &w, 0, 1, /*pooled=*/true));
                 pooled = true;
@@ -1454,14 +1456,14 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
             const int nb = (int)m->blocks[st].size();
             // res2 (64-wide bottlenecks, 256 out): one launch per block for everything behind conv1 -- conv2, conv3 + shortcut / residual
             // + ReLU and the next block's conv1 (csrc/bneck.hip; bit-identical to the launches below)
-            if (st == 0 && dvid_bneck_stage_enabled(0) && bneck64_stage(m->blocks[0]) && dvid_bneck64_tail_preferred(h, w)) {
+            if (st == 0 && bneck64_stage(m->blocks[0]) && dvid_bneck64_tail_preferred(h, w)) {
                 half_t* ta = t1;
                 half_t* tb = t2;
                 TRY(conv_run(m->blocks[0][0].c1, cur, nf, h, w, ta, 1, 0, nullptr, 0, 0, cs));
                 // the last block's launch also computes res3's first conv1 (1x1 / stride 1 over this stage's output, 256 -> 128) when
                 // res3 takes the fused path too: that layer alone re-read the 512 B per pixel this launch has in registers
                 const Block* r3 = nullptr;
-                if (nb > 1 && dvid_bneck_stage_enabled(1) && bneck128_stage(m->blocks[1])) {
+                if (nb > 1 && bneck128_stage(m->blocks[1])) {
                     const Block& b0 = m->blocks[1][0];
                     auto osz = [](const ConvW& c, int v) { return (v + 2 * c.pad - c.kh) / c.stride + 1; };
                     if (b0.c1.kh == 1 && b0.c1.stride == 1 && b0.c1.pad == 0 && b0.c1.cin == 256 && b0.c1.cout == 128 && b0.c1.kpad == 256 &&
@@ -1485,7 +1487,7 @@ int dvid_backbone_resnet_fpn_frames(dvid_model* m, const float* const* frames, i
             }
             // res3 (128-wide): the first block's conv1 / strided conv2 / shortcut as their own launches, then one launch per block for
             // conv3 + residual + ReLU + the next block's conv1 (+ the next block's conv2 in front of them)
-            if (st == 1 && dvid_bneck_stage_enabled(1) && bneck128_stage(m->blocks[1])) {
+            if (st == 1 && bneck128_stage(m->blocks[1])) {
                 const Block& b0 = m->blocks[1][0];
                 auto osz = [](const ConvW& c, int v) { return (v + 2 * c.pad - c.kh) / c.stride + 1; };
                 if (dvid_bneck64_tail_preferred(osz(b0.c2, osz(b0.c1, h)), osz(b0.c2, osz(b0.c1, w)))) {
@@ -1661,7 +1663,7 @@ int dvid_rcnn_head(dvid_model* m, int head_index, int is_cond, const void* p3, c
             if ((size_t)hw.bt_out > kSsRowFloats) return DVID_ERR_UNSUPPORTED;
             if (m->ss_slabs.empty() || m->ss_slab_used == kSsSlabRows) {
                 m->ss_slabs.emplace_back();
-                TRY(m->ss_slabs.back().ensure(kSsSlabRows * kSsRowFloats * sizeof(float)));
+                TRY(m->ss_slabs.back().ensure(kSsSlabRows * kSsRowFloats * sizeof(float), &m->ws_gen));
                 m->ss_slab_used = 0;
             }
             float* dst = m->ss_slabs.back().as<float>() + (m->ss_slab_used++) * kSsRowFloats;
@@ -1708,13 +1710,13 @@ int dvid_global_memory_project(dvid_model* m, const float* memory, int lk, void*
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int d = m->cfg.hidden_dim;
     m->mem_lk = 0;
-    TRY(m->kvproj.ensure((size_t)lk * 2 * d * 4));
+    TRY(m->kvproj.ensure((size_t)lk * 2 * d * 4, &m->ws_gen));
     if (m->precision == 1) {          // fp32 K | V rows
         TRY(linear_run32(m->gkv, memory, lk, m->kvproj.as<float>(), 0, s));
         m->mem_lk = lk;
         return DVID_OK;
     }
-    TRY(m->mem16.ensure((size_t)lk * d * 2));
+    TRY(m->mem16.ensure((size_t)lk * d * 2, &m->ws_gen));
     TRY(dvid_f32_to_f16_launch(memory, m->mem16.as<half_t>(), (long)lk * d, s));
     TRY(linear_run(m->gkv, m->mem16.as<half_t>(), lk, m->kvproj.p, 0, 0, s));
     m->mem_lk = lk;
@@ -1745,7 +1747,7 @@ int dvid_global_xattn(dvid_model* m, const float* query, int rows, const float* 
     TRY(dvid_f32_to_f16_launch(query, m->h16a.as<half_t>(), (long)rows * d, s));
     TRY(linear_run(m->gq, m->h16a.as<half_t>(), rows, m->h16b.p, 0, 0, s));
     const half_t* kv = m->kvproj.as<half_t>();
-    TRY(m->vt.ensure((size_t)m->cfg.nheads * 32 * (((size_t)lk + 31) / 32 * 32 + 32) * 2));
+    TRY(m->vt.ensure((size_t)m->cfg.nheads * 32 * (((size_t)lk + 31) / 32 * 32 + 32) * 2, &m->ws_gen));
     TRY(dvid_mha_mfma_launch(m->h16b.as<half_t>(), kv, kv + d, m->attn16.as<half_t>(), m->vt.as<half_t>(), 1, rows, lk, m->cfg.nheads,
                              d, 2 * d, d, 0, 0, 0, s));
     TRY(linear_run(m->gout, m->attn16.as<half_t>(), rows, out, 0, 1, s));

@@ -186,7 +186,7 @@ class DiffusionDet(nn.Module):
         self._srm1_host = torch.sqrt(1.0 / alphas_cumprod - 1)
         self.noise_fn = None
         self.after_first_launch = None      # optional callable, run once the first backbone launch of a call is queued
-        self.memory_on_side_stream = os.environ.get("DVID_MEMORY_SIDE_STREAM", "1") != "0"
+        self.memory_on_side_stream = True          # (attribute, not an environment switch: tests compare both settings)
         self._mem_stream = None
         self._mem_stream2 = None
         self._mem_side_pending = False
@@ -205,8 +205,8 @@ class DiffusionDet(nn.Module):
         self._graphs, self._graph_seen, self._graph_generation = {}, {}, -1
         # the streaming mode's steady call as a graph (_stream_graph_applies): built, bit-identical, and NOT faster -- 247 against 252 frames/s
         # (profiles/r05n_streaming_graph_ab.txt): that call is 4 ms of kernels (two-frame launches, two dependent farthest-point sweeps), the
-        # host's launching hides behind them.  Off unless asked for (DVID_STREAM_GRAPH=1, tests).
-        self.use_stream_graph = os.environ.get("DVID_STREAM_GRAPH", "0") == "1"
+        # host's launching hides behind them.  Off unless a caller sets the attribute (tests do).
+        self.use_stream_graph = False
         self.graph_replays = 0
         self.host_wait_s = 0.0      # seconds this process spent blocked in the per-batch device->host result copy
         self.video_index = 0
@@ -552,14 +552,12 @@ class DiffusionDet(nn.Module):
         mem = self.head.proposal_feats_global
         # A captured launch holds raw addresses inside the engine's workspace, and the workspace moves when it grows (a video of a larger
         # frame size, a memory with more rows): every graph captured before such a move is dropped, never replayed into freed memory.
-        gen = ops.workspace_generation()
+        eng = self._get_engine()          # (may not exist yet: a rank that adopted its video's memory reaches its first full batch without
+        gen = eng.workspace_generation()  #  having run anything, and a device move drops the engine; _get_engine builds it)
         if gen != self._graph_generation:
             self._graphs, self._graph_seen, self._graph_generation = {}, {}, gen
         # ... and it bakes in every switch the eager path reads per call
         gframes = [im.tensors for im in ref_g] if ref_g else []
-        # (the engine may not exist yet: a rank that adopted its video's memory -- adopt_video_memory -- reaches its first full batch
-        # without having run anything, and a device move drops the engine; _get_engine builds it)
-        eng = self._get_engine()
         key = (tuple(frames[0].shape), len(frames), self.sampling_timesteps, int(mem[0].shape[0]), int(mem[1].shape[0]) if mem[1] is not None else 0,
                id(eng), (float(w), float(h)), bool(self.skip_unobservable), bool(self.use_nms), eng.chains, eng.precision, len(gframes))
         M = self.num_proposals
@@ -680,9 +678,9 @@ class DiffusionDet(nn.Module):
             self.after_first_launch = hook
             self.memory_on_side_stream = side_mem
         static["graph"], static["out"] = graph, out
-        if ops.workspace_generation() != self._graph_generation:          # the capture's own warm-up run may have grown the workspace:
+        if self._get_engine().workspace_generation() != self._graph_generation:          # the capture's own warm-up run may have grown the workspace:
             self._graphs, self._graph_seen = {}, {}                        # older graphs go; this one was captured after the move
-            self._graph_generation = ops.workspace_generation()
+            self._graph_generation = self._get_engine().workspace_generation()
         self._graphs[key] = static
         return static
 
@@ -708,7 +706,7 @@ class DiffusionDet(nn.Module):
         # Frames stay where they are: the backbone reads each through a pointer table (ops.Model.backbone_frames).  Only frames
         # that are not fp32 device tensors of one size (host tensors of a plain DataLoader, other dtypes) are concatenated and
         # moved as the reference does (diffusion_det.py:418-421).
-        as_list = os.environ.get("DVID_FRAME_LIST", "1") != "0" and all(f.is_cuda and f.device == self.device and f.dtype == torch.float32 and f.shape[0] == 1 and f.shape == frames[0].shape
+        as_list = all(f.is_cuda and f.device == self.device and f.dtype == torch.float32 and f.shape[0] == 1 and f.shape == frames[0].shape
                       for f in frames)
         total = None if as_list else torch.cat(frames).to(self.device, torch.float32)
         n_total = len(frames) if as_list else total.shape[0]

@@ -330,10 +330,28 @@ def update_erase_memory(feats_new, feats_mem, target_size):
     return gather_rows(merged, idx), idx
 
 
-def workspace_generation():
-    """re-allocations of workspace buffers in this process so far (include/dvid_hip.h: dvid_workspace_generation); a captured launch
-    sequence is valid only while this stays what it was at capture time"""
-    return int(_lib.load().dvid_workspace_generation())
+def set_option(name, value):
+    """one entry of the library's option table (include/dvid_hip.h: dvid_set_option; csrc/options.h lists names and defaults)"""
+    call("dvid_set_option", name.encode(), int(value))
+
+
+def get_option(name):
+    v = C.c_int()
+    call("dvid_get_option", name.encode(), C.byref(v))
+    return v.value
+
+
+def reset_options():
+    call("dvid_reset_options")
+
+
+def effective_config():
+    """"name=value ..." of every library option + the environment variables the library still reads (dvid_effective_config)"""
+    buf = C.create_string_buffer(1024)
+    call("dvid_effective_config", buf, 1024)
+    return buf.value.decode()
+
+
 
 
 PRECISIONS = {"float16": 0, "float32": 1}          # the reference's DTYPE values (mega_core/config/defaults.py:582) -> dvid_model_set_precision
@@ -380,6 +398,11 @@ class Model:
         self._ws = None
         self.chains = -1                 # the library's default until set_chains
         self._kv_src = None
+
+    def workspace_generation(self):
+        """moves of this model's workspace buffers so far (include/dvid_hip.h: dvid_workspace_generation); a captured launch sequence is
+        valid only while this stays what it was at capture time"""
+        return int(_lib.load().dvid_workspace_generation(self.handle))
 
     def set_chains(self, n):
         """concurrent sub-batch chains inside the library (1 = sequential kernels, for per-kernel profiling)"""

@@ -116,9 +116,21 @@ def gpu_numa_topology(n_gpus):
         return None, None
 
 
+def rank_thread_cap(n_cpus, local_world, quota=None, ceiling=32):
+    """Host threads (torch intra-op pool, decode pool) one rank should run: its CPU share, at most `ceiling`, and -- when the container
+    has a CPU-time quota (cpu_quota(): the GPU boxes of this pool show 256 CPUs and grant 16) -- at most its share of the quota: eight
+    ranks with 32 threads each on 16 CPUs' worth of run time spend their time in the scheduler (profiles/r05m_feed_groups.txt).
+    Pure function (tests inject the numbers)."""
+    cap = max(1, min(int(n_cpus), int(ceiling)))
+    if quota is not None and quota > 0:
+        cap = max(1, min(cap, int(quota // max(1, local_world))))
+    return cap
+
+
 def bind_rank_to_cpus(local_rank, local_world):
-    """Pin this process (and the threads it starts later) to its share of the host's CPUs; returns the CPU list (for the
-    bench line) or None when affinity cannot be set here.  No-op for a single rank."""
+    """Pin this process (and the threads it starts later) to its share of the host's CPUs and cap its thread pool by its share of
+    the CPU quota (rank_thread_cap); returns the CPU list (for the bench line) or None when affinity cannot be set here.  No-op for
+    a single rank."""
     if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
     try:
@@ -126,7 +138,7 @@ def bind_rank_to_cpus(local_rank, local_world):
         nodes, node_cpus = gpu_numa_topology(local_world) if torch.cuda.is_available() else (None, None)
         cpus = rank_cpu_share(local_rank, local_world, nodes, node_cpus, allowed)
         os.sched_setaffinity(0, cpus)
-        torch.set_num_threads(max(1, min(len(cpus), 32)))
+        torch.set_num_threads(rank_thread_cap(len(cpus), local_world, cpu_quota()))
         return cpus
     except (OSError, ValueError):
         return None

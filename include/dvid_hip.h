@@ -90,11 +90,12 @@ int dvid_model_finalize(dvid_model* m);
 /* (re)allocate the activation workspace for batches of up to max_frames frames of height x width
  * (multiples of 32) and boxes_per_frame boxes. */
 int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width, int boxes_per_frame);
-/* Counts the re-allocations of workspace buffers in this process (any model: dvid_workspace_reserve growing the arena,
- * dvid_global_memory_project / dvid_global_xattn growing the memory's projection buffers).  A caller that captured launches into a
- * hipGraph holds addresses inside the workspace; when the counter differs from its value at capture time the graph must be dropped.
+/* Counts the MOVES of this model's workspace buffers (dvid_workspace_reserve growing the arena, dvid_global_memory_project /
+ * dvid_global_xattn growing the memory's projection buffers; a buffer's first allocation does not count: nothing can hold its address yet).
+ * A caller that captured launches into a hipGraph holds addresses inside the workspace; when the counter differs from its value at
+ * capture time the graph must be dropped.  Per model: another model's growth leaves this one's graphs alone.
  * (The reference has no counterpart: its workspace is torch's caching allocator, mega_core/modeling/detector/diffusion_det.py:418-476.) */
-unsigned long long dvid_workspace_generation(void);
+unsigned long long dvid_workspace_generation(const dvid_model* m);
 
 /* Number of concurrent sub-batch chains (separate HIP streams inside the library, joined back to the caller's
  * stream before returning) used by the backbone and the heads; 1 = strictly sequential kernels (profiling). */
@@ -220,6 +221,19 @@ int dvid_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
 int dvid_resize_u8_to_f32(const void* src_hwc, int h, int w, void* tmp, float* out_chw, int oh, int ow, int ph, int pw,
                           const int* xbounds, const int* xk, int xksize, const int* ybounds, const int* yk, int yksize, void* stream);
 
+/* ---- options ------------------------------------------------------------------------------
+ * The library's behaviour switches are ONE table set through this ABI, never through the environment (csrc/options.h; the defaults
+ * are the benchmarked configuration).  Names: conv3x3, wstat, bneck_fuse (0 off / 1 by the layer's shape rule / 2 wherever the layer
+ * type fits), stem_pool, head_tail, ln_rows (0 / 1), igemm_cfg (-1 = tuner, >= 0 forced tile configuration), igemm_tune (-1 / 0 / 1, see
+ * dvid_igemm_set_tuning), igemm_generic (0 / 1), bneck_lds (diagnostics).  Every choice gives the same values up to fp32 summation
+ * order (most are bit-identical; the tests say which).  dvid_effective_config writes "name=value ..." of all options followed by the
+ * environment variables the library still reads (DVID_IGEMM_TUNE, DVID_IGEMM_TUNE_CACHE, DVID_CHAINS, DVID_POISON_WORKSPACE) as they
+ * are set; bench.py echoes it.  The dvid_igemm_set_* / dvid_set_stem_pool entry points below write the same table (-1 = the default). */
+int dvid_set_option(const char* name, int value);
+int dvid_get_option(const char* name, int* value);
+int dvid_reset_options(void);
+int dvid_effective_config(char* buf, int cap);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Tile configurations of the implicit-GEMM kernel (all bit-identical in their results): the per-shape tuner picks one;
  * dvid_igemm_set_config(k) forces table entry k wherever it is valid (k = -1: back to the tuner). */
@@ -231,28 +245,32 @@ int dvid_igemm_set_config(int cfg);
  * launches) or the hand rule; -1 = follow the environment: DVID_IGEMM_TUNE if set, else 0 when DVID_IGEMM_TUNE_CACHE names a
  * non-empty winners file (a deployment that ships one is in serving mode by default), else 1. */
 int dvid_igemm_set_tuning(int mode);
+/* Shape buckets timed on the calling path in this process so far (each = one stream synchronisation + 4 .. ~40 launches per valid
+ * configuration): a serving process wants this to stop growing after warm-up -- ragged video tails whose launches are under two rounds of
+ * the CUs inherit a tuned bucket only within a quarter octave and may add passes mid-stream (bench.py reports the count per run). */
+long long dvid_igemm_tuning_passes(void);
 /* 3x3 / stride-1 / pad-1 convolutions with Cin % 32 == 0 and Cout % 128 == 0 (the bottleneck conv2 layers of res3-res5, the FPN
  * output convolutions) on the halo-staged kernel (csrc/conv3x3.hip: the 8 x 32 output patch's input pixels are staged once per
  * 32-channel chunk and serve all nine taps): 1 = on where the shape rule prefers it (W within 1/8 of a multiple of 32, maps of at least
- * 512 pixels -- a function of the layer and the image size, not of the number of frames in the launch), 2 = on wherever the layer type fits (tests), 0 = off (the igemm2 kernel), -1 = follow DVID_CONV3X3_HALO
- * (default 1).  The choice depends on the layer's shape only; the two kernels differ in fp32 summation order. */
+ * 512 pixels -- a function of the layer and the image size, not of the number of frames in the launch), 2 = on wherever the layer type fits (tests), 0 = off (the igemm2 kernel), -1 = the default
+ * (1).  The choice depends on the layer's shape only; the two kernels differ in fp32 summation order. */
 int dvid_igemm_set_conv3x3(int mode);
 /* 1x1 convolutions / linear layers with K in {128, 256} (512 without a residual) and N a multiple of 256 (bottleneck conv3 + residual, the decoder's
  * dynamic_layer and linear1) on the weight-stationary kernel (csrc/wstat.hip: a workgroup keeps the weights of 256 output channels in
  * registers and streams its rows through a DMA ring; epilogue straight from the accumulator layout): 1 = on for launches large
- * enough for 256 persistent workgroups, 2 = wherever the layer type fits (tests), 0 = off (igemm2), -1 = follow DVID_WSTAT (default 1).
+ * enough for 256 persistent workgroups, 2 = wherever the layer type fits (tests), 0 = off (igemm2), -1 = the default (1).
  * Bit-identical to igemm2. */
 int dvid_igemm_set_wstat(int mode);
 
 /* res2 / res3 bottleneck blocks behind their conv1 as one launch each (csrc/bneck.hip: dvid_bottleneck64_tail_f16 /
  * dvid_bottleneck128_tail_f16 inside the ResNet backbone): 1 = where the shape rule of the 3x3 patch kernels holds for the stage's map
  * (a function of the image size only), 2 = whenever the stage is made of such bottlenecks (tests), 0 = off (layer-by-layer launches),
- * -1 = follow DVID_BNECK_FUSE (default 1).  res2: bit-identical to the layer-by-layer launches; res3: to those on igemm2 (see above). */
+ * -1 = the default (1).  res2: bit-identical to the layer-by-layer launches; res3: to those on igemm2 (see above). */
 int dvid_igemm_set_bottleneck_fusion(int mode);
 
 /* The ResNet stem (7x7 / stride 2 as a 4x4 convolution over the space-to-depth image, + FrozenBN + ReLU) and the 3x3 / stride-2 max pool
  * behind it (detectron2 BasicStem, reached from mega_core/modeling/detector/diffusion_det.py:427) as ONE launch: 1 = on, 0 = two launches,
- * -1 = follow DVID_STEM_POOL (default 1).  Bit-identical either way (csrc/conv3x3.hip: stem_pool_kernel). */
+ * -1 = the default (1).  Bit-identical either way (csrc/conv3x3.hip: stem_pool_kernel). */
 int dvid_set_stem_pool(int mode);
 
 /* When enabled, every igemm launch is bracketed by HIP events on its stream; dvid_profile_read

@@ -85,6 +85,30 @@ def test_bench_launcher_starts_n_ranks():
     assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
 
 
+def test_eight_rank_dry_run_vidval_partition_and_thread_caps():
+    """No 8-GPU node has been available to any round, so the N = 8 launch is kept honest without one: `bench.py --gpus 8 --dry --workload
+    vidval` becomes 8 gloo ranks, each takes its share of the 555-video / 176126-frame VID-val-shaped set (the partition `--workload vidval`
+    runs: whole videos, greedy by frame count), the loads meet on rank 0 -- heaviest / mean <= 1.001 -- and every rank plans its host
+    threads for its share of a 16-CPU quota on a 256-CPU host (what the GPU boxes of this pool grant): 2 threads, not 32."""
+    import json
+    import subprocess
+    import sys
+    from diffusionvid_amd.utils import comm
+    assert comm.rank_thread_cap(32, 8, quota=16) == 2 and comm.rank_thread_cap(32, 8, quota=None) == 32 and comm.rank_thread_cap(256, 1, quota=16) == 16
+    assert comm.rank_thread_cap(4, 8, quota=2) == 1 and comm.rank_thread_cap(2, 2, quota=64) == 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry", "--workload", "vidval", "--assume-cpu-quota", "16",
+                          "--assume-cpus", "256"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["videos"] == 555 and line["frames"] == 176126
+    assert line["heaviest_over_mean"] <= 1.001, line
+    assert line["threads_per_rank"] == [2] * 8 and line["cpus_per_rank"] == [32] * 8, line
+
+
 def test_balanced_partition_on_vid_val_shaped_set():
     """SURVEY.md 8e / BASELINE.json configs[4]: 555 videos, 176126 frames over 8 ranks -- greedy balance by frame count
     on video boundaries against the reference's equal-range-snapped-forward sampler."""

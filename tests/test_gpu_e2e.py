@@ -1364,7 +1364,7 @@ def test_call_graph_dropped_when_the_workspace_moves():
                 before = model.graph_replays
                 for idx in range(len(ds)):
                     res += [r.to(torch.device("cpu")) for r in model(ds[idx][0])]
-                    seen.add(ops.workspace_generation())
+                    seen.add(model._get_engine().workspace_generation())
                 per_video.append(model.graph_replays - before)
         outs[graphs], replays[graphs], gens[graphs] = res, per_video, seen
         del model
@@ -1550,4 +1550,37 @@ def test_call_graph_projects_an_adopted_memory():
         assert len(res) == 16 and (model.graph_replays - before == (2 if graphs else 0))
         outs[graphs] = [r.to(torch.device("cpu")) for r in res]
     for a, b in zip(outs[True], outs[False]):
+        assert len(a) == len(b) > 0 and torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
+
+
+def test_fresh_model_adopts_a_memory_and_runs_its_first_batch():
+    """A process that has never run its model -- rank > 0 of engine.compute_on_video_sharded with the reference's protocol (look-ahead 1)
+    -- adopts the video's memory (`adopt_video_memory` does not build the engine), queues seven calls and reaches its first full batch
+    with `_engine` still None.  That call qualifies for the hipGraph path, whose key read `self._engine.chains` (AttributeError on None,
+    ADVICE r05): the key is now built from `_get_engine()`.  Same after a device move dropped the engine.  The detections equal those of
+    a model that had run before adopting the same memory."""
+    from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
+    from diffusionvid_amd.utils import synthetic
+    g = torch.Generator().manual_seed(5)
+    memory = [torch.randn(900, 256, generator=g).cuda(), torch.randn(150, 256, generator=g).cuda()]
+
+    def run(warm):
+        cfg, model = _build(1, (1, 1, 1, 1), "trained_like")
+        model.noise_fn = synthetic.DeviceNoise()
+        ds = SyntheticVIDDataset([40], cfg, height=120, width=200, device="cuda", smooth=True)
+        if warm:
+            with torch.no_grad():
+                for idx in range(16):
+                    model(ds[idx][0])
+        else:
+            assert model._engine is None
+        model.adopt_video_memory([m.clone() for m in memory])
+        res = []
+        with torch.no_grad():
+            for idx in range(1, 25):          # calls 1-7 queue frames; calls 8, 16, 24 each finish a batch (eager, eager, captured / replayed)
+                res += model(ds[idx][0])
+        assert len(res) == 24
+        return [r.to(torch.device("cpu")) for r in res]
+    fresh, warm = run(False), run(True)
+    for a, b in zip(fresh, warm):
         assert len(a) == len(b) > 0 and torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))

@@ -160,10 +160,8 @@ def test_add_layernorm(dv):
 @pytest.mark.parametrize("rows,d,with_r,relu", [(1003, 128, False, False), (1003, 128, True, True), (777, 256, True, False), (5, 256, False, True),
                                                  (40, 512, True, False)])
 def test_add_layernorm_rows_per_wave_bit_identical(dv, tmp_path, rows, d, with_r, relu):
-    """The several-rows-per-wave LayerNorm (d = 128 / 256) against the oracle AND bit for bit against the one-row-per-wave kernel,
-    which a child process with DVID_LN_ROWS=0 runs on the same inputs (the switch is read once per process)."""
-    import subprocess
-    import sys
+    """The several-rows-per-wave LayerNorm (d = 128 / 256) against the oracle AND bit for bit against the one-row-per-wave kernel
+    (library option ln_rows = 0) on the same inputs."""
     g = torch.Generator().manual_seed(rows + d)
     x = torch.randn(rows, d, generator=g) * 3 + 1
     r = torch.randn(rows, d, generator=g) if with_r else None
@@ -172,14 +170,12 @@ def test_add_layernorm_rows_per_wave_bit_identical(dv, tmp_path, rows, d, with_r
     ref = F.relu(ref) if relu else ref
     out = dv.add_layernorm(x.cuda(), None if r is None else r.cuda(), gm.cuda(), bt.cuda(), relu=relu)
     check(f"add_layernorm_rows[{rows},{d}]", out, ref, 1e-4, 1e-4)
-    torch.save({"x": x, "r": r, "g": gm, "b": bt, "relu": relu}, tmp_path / "in.pt")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, torch; sys.path.insert(0, %r); from diffusionvid_amd import ops; d = torch.load(%r); "
-            "y = ops.add_layernorm(d['x'].cuda(), None if d['r'] is None else d['r'].cuda(), d['g'].cuda(), d['b'].cuda(), relu=d['relu']); "
-            "torch.save(y.cpu(), %r)" % (root, str(tmp_path / "in.pt"), str(tmp_path / "out.pt")))
-    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, DVID_LN_ROWS="0"), timeout=600)
-    one_row = torch.load(tmp_path / "out.pt")
-    assert torch.equal(out.cpu(), one_row), "rows-per-wave LayerNorm differs from the one-row-per-wave kernel"
+    dv.set_option("ln_rows", 0)
+    try:
+        one_row = dv.add_layernorm(x.cuda(), None if r is None else r.cuda(), gm.cuda(), bt.cuda(), relu=relu)
+    finally:
+        dv.reset_options()
+    assert torch.equal(out, one_row), "rows-per-wave LayerNorm differs from the one-row-per-wave kernel"
 
 
 def _head_setup(seed=0):
@@ -306,11 +302,9 @@ def test_head_kernels_against_full_dimension_reference_fixture(dv):
 @pytest.mark.parametrize("cond,n", [(False, 1), (True, 3), (False, 60)])
 def test_head_tail_fused_matches_layerwise(dv, tmp_path, cond, n):
     """csrc/headtail.hip (FFN + norm3 + modulation + towers + class_logits + bboxes_delta + apply_deltas in one row-tile kernel)
-    against the layer-by-layer launches it replaces, which a child process with DVID_HEAD_TAIL=0 runs on the same inputs: the
+    against the layer-by-layer launches it replaces (library option head_tail = 0) on the same inputs: the
     same fp16 operands and fp32 statistics in another summation order, so logits / object features agree to rounding (3e-3 of
     the O(1) values) and boxes to 5e-3 of their size.  300 rows (32-row tiles, ragged last tile), 900 rows, 18000 rows (64-row tiles)."""
-    import subprocess
-    import sys
     sd, _ = _head_setup()
     g = torch.Generator().manual_seed(80 + n)
     M, H, W = 300, 96, 160
@@ -320,18 +314,14 @@ def test_head_tail_fused_matches_layerwise(dv, tmp_path, cond, n):
     pro = torch.randn(n * M, 256, generator=g)
     cnd = torch.randn(n * M, 256, generator=g) if cond else None
     t = torch.full((n,), 499, dtype=torch.long)
-    torch.save({"feats": feats, "boxes": boxes, "pro": pro, "cnd": cnd, "t": t, "n": n, "M": M, "H": H, "W": W, "cond": cond}, tmp_path / "in.pt")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, torch; sys.path.insert(0, %r); from diffusionvid_amd import ops; from diffusionvid_amd.utils import synthetic; "
-            "d = torch.load(%r); m = ops.Model(synthetic.make_head_state_dict(0), res_blocks=(0, 0, 0, 0)); m.reserve(d['n'], d['H'], d['W'], d['M']); "
-            "fd = [ops.nhwc_from_nchw(f.cuda()) for f in d['feats']]; "
-            "o = m.rcnn_head(0 if d['cond'] else 1, fd, d['H'], d['W'], d['boxes'].cuda(), d['pro'].cuda(), d['t'], cond=None if d['cnd'] is None else d['cnd'].cuda()); "
-            "torch.save([x.cpu() for x in o], %r)" % (root, str(tmp_path / "in.pt"), str(tmp_path / "out.pt")))
-    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, DVID_HEAD_TAIL="0"), timeout=900)
-    ll, lb, lo = torch.load(tmp_path / "out.pt")
     model = dv.Model(sd, res_blocks=(0, 0, 0, 0))
     model.reserve(n, H, W, M)
     fd = [dv.nhwc_from_nchw(f.cuda()) for f in feats]
+    dv.set_option("head_tail", 0)
+    try:
+        ll, lb, lo = (x.cpu() for x in model.rcnn_head(0 if cond else 1, fd, H, W, boxes.cuda(), pro.cuda(), t, cond=None if cnd is None else cnd.cuda()))
+    finally:
+        dv.reset_options()
     gl, gb, go = model.rcnn_head(0 if cond else 1, fd, H, W, boxes.cuda(), pro.cuda(), t, cond=None if cnd is None else cnd.cuda())
     tag = f"head_tail[{'cond' if cond else 'plain'},{n}]"
     check(tag + ".obj_features", go, lo, 3e-3, 3e-3)
@@ -634,10 +624,9 @@ def test_fused_blocks_reproducible_beside_another_stream(dv):
 
 def test_fused_blocks_counted_waits_beside_lds_traffic():
     """The fault behind the wrong patch rows of the first fused-block build, kept reproducible: with less than the whole LDS
-    (DVID_BNECK_LDS) a fused workgroup shares its CU with a synthetic neighbour that keeps the LDS pipe busy (tools/lab/spin_kernel.hip,
+    (library option bneck_lds) a fused workgroup shares its CU with a synthetic neighbour that keeps the LDS pipe busy (tools/lab/spin_kernel.hip,
     mode 3: LDS writes / reads + barriers) -- the condition under which counted vmcnt waits that had ordinary loads among their DMA
-    pieces let a step start early (85 of 450 chains differed).  Runs tools/diag_chain_contention.py in a child process (the LDS size
-    is read once per process); every repetition of the res2 -> res3 chain must reproduce the first bit for bit."""
+    pieces let a step start early (85 of 450 chains differed).  Runs tools/diag_chain_contention.py in a child process; every repetition of the res2 -> res3 chain must reproduce the first bit for bit."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -645,7 +634,7 @@ def test_fused_blocks_counted_waits_beside_lds_traffic():
     if not os.path.exists(so):
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(root, "tools", "lab", "spin_kernel.hip"), "-o", so],
                        check=True)
-    env = dict(os.environ, DVID_BNECK_LDS="158720", SIDE="spin:1024:256:4000000:3")
+    env = dict(os.environ, BNECK_LDS="158720", SIDE="spin:1024:256:4000000:3")          # (the tool's own variables: it sets the library option)
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "diag_chain_contention.py"), "60"], cwd=root, env=env, capture_output=True,
                          text=True, timeout=600)
     print(out.stdout[-600:])
@@ -760,7 +749,7 @@ def test_backbone_swin_small(dv):
 def test_igemm_configs_bit_identical(case):
     """Every tile configuration of the implicit-GEMM kernel must give bit-identical outputs (the per-shape tuner swaps
     them freely), and so must its specialised code paths (FLAT 1x1 addressing, lean epilogue) against the general ones
-    (DVID_IGEMM_GENERIC=1); configuration 0 is also checked against fp32 math."""
+    (library option igemm_generic = 1); configuration 0 is also checked against fp32 math."""
     from diffusionvid_amd import _lib, ops
     lib = _lib.load()
     g = torch.Generator().manual_seed(5)
@@ -783,12 +772,11 @@ def test_igemm_configs_bit_identical(case):
         for cfg in range(lib.dvid_igemm_num_configs()):
             _lib.check(lib.dvid_igemm_set_config(cfg), "set_config")
             outs[cfg] = run()
-        os.environ["DVID_IGEMM_GENERIC"] = "1"
+        ops.set_option("igemm_generic", 1)
         _lib.check(lib.dvid_igemm_set_config(0), "set_config")
         generic = run()
     finally:
-        os.environ.pop("DVID_IGEMM_GENERIC", None)
-        lib.dvid_igemm_set_config(-1)
+        ops.reset_options()
     ref = outs[0]
     for cfg, o in outs.items():
         assert torch.equal(o, ref), f"configuration {cfg} differs from configuration 0 (max |d| = {(o.float() - ref.float()).abs().max().item():.3e})"
@@ -802,7 +790,7 @@ def test_igemm_configs_bit_identical(case):
 
 def test_swin_backbone_specialised_paths_bit_identical():
     """Swin-FPN backbone (fp32 residual stream updated in place, GELU MLP): the specialised igemm code paths against the
-    general ones (DVID_IGEMM_GENERIC=1), bit for bit."""
+    general ones (library option igemm_generic = 1), bit for bit."""
     from diffusionvid_amd import ops
     from diffusionvid_amd.utils import synthetic
     swin = dict(embed_dim=64, depths=(2, 2, 2, 1), heads=(2, 4, 8, 16), window=7)
@@ -811,11 +799,11 @@ def test_swin_backbone_specialised_paths_bit_identical():
     x = torch.rand(2, 3, 160, 224, generator=torch.Generator().manual_seed(1)).cuda()
     m.reserve(2, 160, 224, 300)
     fast = [t.clone() for t in m.backbone(x)]
-    os.environ["DVID_IGEMM_GENERIC"] = "1"
+    ops.set_option("igemm_generic", 1)
     try:
         slow = [t.clone() for t in m.backbone(x)]
     finally:
-        os.environ.pop("DVID_IGEMM_GENERIC", None)
+        ops.reset_options()
     for a, b in zip(fast, slow):
         assert torch.isfinite(a.float()).all() and torch.equal(a, b)
     m.close()

@@ -28,6 +28,54 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.dvid_version() >= 1
 
 
+ALLOWED_ENV_SWITCHES = {"DVID_LIB", "DVID_IGEMM_TUNE", "DVID_IGEMM_TUNE_CACHE", "DVID_CHAINS", "DVID_POISON_WORKSPACE", "DVID_CALL_GRAPH", "DVID_PROFILE_DUMP"}
+
+
+def test_default_library_configuration_is_the_benchmarked_one():
+    """Round 6: the library's switches are one option table set through the C ABI (csrc/options.h), not 38 environment variables.  With a
+    clean environment the effective configuration of a freshly loaded library equals the string bench.py quotes its numbers on
+    (bench.DEFAULT_LIBRARY_CONFIG, echoed in the line's build.library_config); options round-trip through dvid_set_option /
+    dvid_get_option / dvid_reset_options, bad names and values are refused; and the product sources read no DVID_* environment
+    variable beyond the seven documented ones."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from diffusionvid_amd import ops; import bench; c = ops.effective_config(); "
+            "assert c.split(' DVID_')[0] == bench.DEFAULT_LIBRARY_CONFIG, c; "
+            "assert c.endswith('DVID_IGEMM_TUNE= DVID_IGEMM_TUNE_CACHE= DVID_CHAINS= DVID_POISON_WORKSPACE='), c; print('ok')" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DVID_")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+    from diffusionvid_amd import _lib, ops
+    try:
+        ops.set_option("head_tail", 0)
+        ops.set_option("conv3x3", 2)
+        assert ops.get_option("head_tail") == 0 and ops.get_option("conv3x3") == 2
+        assert "head_tail=0" in ops.effective_config() and "conv3x3=2" in ops.effective_config()
+        _lib.check(_lib.load().dvid_igemm_set_conv3x3(-1), "set_conv3x3")          # -1 = the default
+        assert ops.get_option("conv3x3") == 1
+        with pytest.raises(_lib.DvidError, match="unknown option"):
+            ops.set_option("no_such_option", 1)
+        with pytest.raises(_lib.DvidError, match="outside"):
+            ops.set_option("stem_pool", 7)
+    finally:
+        ops.reset_options()
+    import bench
+    assert ops.effective_config().split(" DVID_")[0] == bench.DEFAULT_LIBRARY_CONFIG
+    # environment reads of the product sources (library, package, bench.py)
+    seen = set()
+    for d, _, files in os.walk(os.path.join(ROOT, "diffusionvid_amd")):
+        if "_build" in d:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(d, f)).read()
+                seen |= set(re.findall(r'(?:getenv\(|environ(?:\.get|\.setdefault)?[\[(]|in os\.environ)\s*"(DVID_[A-Z0-9_]+)"', src))
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    seen |= set(re.findall(r'environ(?:\.get|\.setdefault)?[\[(]\s*"(DVID_[A-Z0-9_]+)"', src))
+    assert seen <= ALLOWED_ENV_SWITCHES, sorted(seen - ALLOWED_ENV_SWITCHES)
+    assert len(ALLOWED_ENV_SWITCHES) < 15
+
+
 def test_product_path_fails_loudly_without_gpu():
     from diffusionvid_amd import _lib, ops
     if torch.cuda.is_available():

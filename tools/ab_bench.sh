@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of one environment switch on ONE box:  tools/ab_bench.sh DVID_STEM_POOL "0 1 0 1" [extra bench.py args]
+# A/B of one library option (csrc/options.h) on ONE box:  tools/ab_bench.sh stem_pool "0 1 0 1" [extra bench.py args]
 # prints value / ms_per_step / family frac and the five heaviest kernel groups per run
 var=$1; vals=$2; shift 2
 for v in $vals; do
-  env $var=$v python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-host-fed --no-side-configs "$@" 2>/dev/null > /tmp/ab_line.json
+  python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-host-fed --no-side-configs --option $var=$v "$@" 2>/dev/null > /tmp/ab_line.json
   python - "$var" "$v" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab_line.json"))

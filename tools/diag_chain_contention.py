@@ -13,6 +13,8 @@ from diffusionvid_amd import ops as dv  # noqa: E402
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    if os.environ.get("BNECK_LDS"):          # less than the whole LDS for the fused block kernels, so that a neighbour with LDS fits beside them
+        dv.set_option("bneck_lds", int(os.environ["BNECK_LDS"]))
     n, hh, ww = 24, 152, 256
     g = torch.Generator().manual_seed(0)
     mk = lambda *s, sc=0.1: torch.randn(*s, generator=g) * sc

@@ -1,5 +1,5 @@
 """Run-to-run determinism of the ResNet-FPN backbone at a two-chain launch size (full R-101 depth): the same 144 frames K times, p3 / p4 /
-p5 compared bit for bit with the first run; with the fused res2 / res3 blocks on and off (DVID_BNECK_FUSE) and one or two chains."""
+p5 compared bit for bit with the first run; with the fused res2 / res3 blocks on and off (dvid_igemm_set_bottleneck_fusion) and one or two chains."""
 import sys
 
 import torch
