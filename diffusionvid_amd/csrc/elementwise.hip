@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void add_layernorm_rows_kernel(const float* __
 // One wave per output token; the bias-free reduction Linear(4C -> 2C) that follows is an igemm launch.
 // C <= 512: every lane holds up to 2 float4 of each of the 4 source tokens (no per-element division, 32 live registers)
 __global__ __launch_bounds__(256) void patch_merge_ln_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                             const float* __restrict__ b, half_t* __restrict__ y16, int B, int H,
+                                                             const float* __restrict__ b, half_t* __restrict__ y16, float* __restrict__ y32, int B, int H,
                                                              int W, int C) {
     const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
     const long tok = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -327,10 +327,11 @@ __global__ __launch_bounds__(256) void patch_merge_ln_kernel(const float* __rest
                 const int j = part * cv + c4;
                 const float4v gg = *reinterpret_cast<const float4v*>(g + j * 4);
                 const float4v bb = *reinterpret_cast<const float4v*>(b + j * 4);
-                half4 h;
+                float4v o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (half_t)((v[part][i][e] - mean) * rstd * gg[e] + bb[e]);
-                *reinterpret_cast<half4*>(y16 + tok * d + j * 4) = h;
+                for (int e = 0; e < 4; ++e) o[e] = (v[part][i][e] - mean) * rstd * gg[e] + bb[e];
+                if (y32) *reinterpret_cast<float4v*>(y32 + tok * d + j * 4) = o;          // DTYPE float32
+                if (y16) *reinterpret_cast<half4*>(y16 + tok * d + j * 4) = (half4){(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
             }
         }
 }
@@ -475,11 +476,11 @@ int dvid_modulate_launch(const float* x, const float* scale, int scale_ld, const
     return DVID_OK;
 }
 
-int dvid_patch_merge_ln_launch(const float* x, const float* g, const float* b, half_t* y16, int B, int H, int W, int C, hipStream_t s) {
+int dvid_patch_merge_ln_launch(const float* x, const float* g, const float* b, half_t* y16, int B, int H, int W, int C, hipStream_t s, float* y32) {
     if (C % 4 || C > 512) return DVID_ERR_UNSUPPORTED;
     const long ntok = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
     const int wpb = 4;
-    hipLaunchKernelGGL(patch_merge_ln_kernel, dim3((unsigned)((ntok + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, x, g, b, y16, B, H, W, C);
+    hipLaunchKernelGGL(patch_merge_ln_kernel, dim3((unsigned)((ntok + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, x, g, b, y16, y32, B, H, W, C);
     LAUNCH_CHECK();
     return DVID_OK;
 }

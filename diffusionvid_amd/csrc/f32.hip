@@ -37,8 +37,10 @@ constexpr int F32_BM = 128, F32_BK = 16, F32_LDT = 20;
 template <int BN>
 __global__ __launch_bounds__(256) void f32_igemm_kernel(F32GemmParams p) {
     constexpr int NB = BN / 64;          // 32-column blocks per wave
-    __shared__ float As[2][F32_BM * F32_LDT];
-    __shared__ float Bs[2][BN * F32_LDT];
+    __shared__ float Smem[2 * F32_BM * F32_LDT + 2 * BN * F32_LDT];          // A stages | B stages; the epilogue's half tile afterwards
+    float (*As)[F32_BM * F32_LDT] = reinterpret_cast<float (*)[F32_BM * F32_LDT]>(Smem);
+    float (*Bs)[BN * F32_LDT] = reinterpret_cast<float (*)[BN * F32_LDT]>(Smem + 2 * F32_BM * F32_LDT);
+    float* Cs = Smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int t = igemm_xcd_remap((int)blockIdx.x, p.tiles_m * p.tiles_n);          // an XCD owns a contiguous run of row tiles
@@ -140,8 +142,56 @@ __global__ __launch_bounds__(256) void f32_igemm_kernel(F32GemmParams p) {
         __syncthreads();
     }
 
-    // epilogue straight from the accumulator layout: register r of a block = row (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3), column
-    // lane & 31 -- a store instruction writes two rows x 32 consecutive floats
+    // epilogue.  Register r of an accumulator block = row (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3), column lane & 31.
+    // Row-coalesced form (N and ldc multiples of 4): the tile crosses LDS in two halves of 64 rows (the operand buffers are free now),
+    // and every lane finishes 4 consecutive channels of a row -- 16-byte residual reads and stores, 512 contiguous bytes per 32 lanes --
+    // instead of 4-byte accesses 2 rows x 128 bytes per instruction (the short-K layers, res3 / res4 conv3 + residual, ran at 0.39 of
+    // the MFMA rate on their stores: profiles/r06c_bench.json).
+    if (((p.Cout | p.ldc) & 3) == 0) {
+        constexpr int CP = BN + 4;          // pitch of an LDS row (floats)
+        static_assert(64 * CP <= 2 * F32_BM * F32_LDT + 2 * BN * F32_LDT, "half tile fits the operand buffers");
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (wm == half) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            Cs[(mb * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3)) * CP + wn * (BN / 2) + nb * 32 + fr] = acc[mb][nb][r];
+            }
+            __syncthreads();
+            constexpr int VPR = BN / 4;          // float4 per row
+            for (int idx = tid; idx < 64 * VPR; idx += 256) {
+                const int row = idx / VPR, c4 = (idx - row * VPR) * 4;
+                const int m = m0 + half * 64 + row, n = n0 + c4;
+                if (m >= p.M || n >= p.Cout) continue;
+                float4v v = *reinterpret_cast<const float4v*>(&Cs[row * CP + c4]);
+                if (p.bias) v += *reinterpret_cast<const float4v*>(p.bias + n);
+                if (p.res_mode == 1) {
+                    v += *reinterpret_cast<const float4v*>(p.res + (long)m * p.Cout + n);
+                } else if (p.res_mode == 2) {
+                    const int ox = m % p.Wo;
+                    const int t2 = m / p.Wo;
+                    const int oy = t2 % p.Ho;
+                    const int img = t2 / p.Ho;
+                    v += *reinterpret_cast<const float4v*>(p.res + ((long)(img * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + n);
+                }
+                if (p.relu == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.relu == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                *reinterpret_cast<float4v*>(p.out + (long)m * p.ldc + n) = v;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // general form (N tails: class_logits, bboxes_delta), straight from the accumulator layout
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + wn * (BN / 2) + nb * 32 + fr;
@@ -434,6 +484,109 @@ __global__ __launch_bounds__(64) void f32_mha_kernel(const float* __restrict__ q
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Swin window attention (swintransformer.py:68-176, :226-254), fp32: one workgroup (one wave) per (window, head), lane = query position of
+// the 7 x 7 window, keys and values through LDS.  A padded window position holds the qkv BIAS (the reference pads the normalised tokens
+// with zeros before the qkv Linear); the shifted map's region mask adds -100 between positions of different regions.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void f32_swin_window_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                                  const float* __restrict__ relbias, float* __restrict__ out, int H, int W, int C,
+                                                                  int nheads, int shift, float scaling, int nwin) {
+    constexpr int WS = 7, NT = 49;
+    __shared__ float Ks[NT * 32];
+    __shared__ float Vs[NT * 32];
+    __shared__ int tok[64];
+    __shared__ int region[64];
+    const int tid = threadIdx.x;
+    const int lid = igemm_xcd_remap((int)blockIdx.x, nwin * nheads);
+    int wid = lid / nheads;
+    const int h = lid - wid * nheads;
+    const int Hp = (H + WS - 1) / WS * WS, Wp = (W + WS - 1) / WS * WS;
+    const int nwx = Wp / WS, nwy = Hp / WS;
+    const int wx = wid % nwx;
+    wid /= nwx;
+    const int wy = wid % nwy;
+    const int b = wid / nwy;
+    {
+        int t = -1, reg = 0;
+        if (tid < NT) {
+            const int py = tid / WS, px = tid - py * WS;
+            const int ys = wy * WS + py, xs = wx * WS + px;          // coordinates in the shifted, padded map
+            int y = ys + shift, x = xs + shift;                      // source coordinates before the roll
+            if (y >= Hp) y -= Hp;
+            if (x >= Wp) x -= Wp;
+            if (y < H && x < W) t = (b * H + y) * W + x;
+            if (shift > 0) {
+                const int hr = ys < Hp - WS ? 0 : (ys < Hp - shift ? 1 : 2);
+                const int wr = xs < Wp - WS ? 0 : (xs < Wp - shift ? 1 : 2);
+                reg = hr * 3 + wr;
+            }
+        }
+        tok[tid] = t;
+        region[tid] = reg;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NT * 8; idx += 64) {
+        const int key = idx >> 3, c4 = (idx & 7) * 4;
+        const int t = tok[key];
+        const float* src = t >= 0 ? qkv + (long)t * 3 * C : qkv_bias;
+        *reinterpret_cast<float4v*>(&Ks[key * 32 + c4]) = *reinterpret_cast<const float4v*>(src + C + h * 32 + c4);
+        *reinterpret_cast<float4v*>(&Vs[key * 32 + c4]) = *reinterpret_cast<const float4v*>(src + 2 * C + h * 32 + c4);
+    }
+    const int qp = tid < NT ? tid : NT - 1;
+    const int tq = tok[qp], qreg = region[qp];
+    float qv[32];
+    {
+        const float* qsrc = (tq >= 0 ? qkv + (long)tq * 3 * C : qkv_bias) + h * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4v t = *reinterpret_cast<const float4v*>(qsrc + j * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qv[j * 4 + e] = t[e] * scaling;
+        }
+    }
+    __syncthreads();
+    const float* brow = relbias + ((long)h * NT + qp) * SWIN_RELBIAS_PITCH;
+    float sc[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int key = 0; key < NT; ++key) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4v t = *reinterpret_cast<const float4v*>(&Ks[key * 32 + j * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d = __builtin_fmaf(qv[j * 4 + e], t[e], d);
+        }
+        d += brow[key];
+        if (shift > 0 && region[key] != qreg) d += -100.0f;
+        sc[key] = d;
+        mx = fmaxf(mx, d);
+    }
+    float acc[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc[e] = 0.f;
+    float den = 0.f;
+#pragma unroll
+    for (int key = 0; key < NT; ++key) {
+        const float pr = expf(sc[key] - mx);
+        den += pr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4v t = *reinterpret_cast<const float4v*>(&Vs[key * 32 + j * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j * 4 + e] = __builtin_fmaf(pr, t[e], acc[j * 4 + e]);
+        }
+    }
+    if (tid < NT && tq >= 0) {          // padded positions produce no output
+        const float inv = 1.f / den;
+        float* op = out + (long)tq * C + h * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            *reinterpret_cast<float4v*>(op + j * 4) = (float4v){acc[j * 4] * inv, acc[j * 4 + 1] * inv, acc[j * 4 + 2] * inv, acc[j * 4 + 3] * inv};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // DynamicConv (box_head.py:687-711), one workgroup per box: F1 = roi[49 x 256] . param1[256 x 64] -> LayerNorm(64) + ReLU ->
 // F2 = F1 . param2[64 x 256] -> LayerNorm(256) + ReLU -> out[49 x 256].  The per-box parameters arrive as P1T[64][256] | P2T[256][64]
 // ([N][K] rows, the row order csrc/model.hip gives dynamic_layer), so both MFMA operands are K-contiguous rows read straight from
@@ -647,6 +800,18 @@ int dvid_f32_mha_launch(const float* q, const float* k, const float* v, float* o
     if (lk <= 0 || nheads <= 0 || (q_ld | kv_ld | out_ld) % 4) return DVID_ERR_ARG;
     hipLaunchKernelGGL(f32_mha_kernel, dim3(ceil_div(lq, 64), nheads, batch), dim3(64), 0, s, q, k, v, out, lq, lk, q_ld, kv_ld, out_ld, q_bs, kv_bs,
                        out_bs, 0.17677669529663688110f);          // 1 / sqrt(32)
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+int dvid_f32_swin_window_attn_launch(const float* qkv, const float* qkv_bias, const float* relbias, float* out, int batch, int H, int W, int C,
+                                     int nheads, int shift, hipStream_t s) {
+    if (C != nheads * 32) return DVID_ERR_UNSUPPORTED;
+    const long nwin = (long)batch * ((H + 6) / 7) * ((W + 6) / 7);
+    if (nwin * nheads > 0x7fffffffL) return DVID_ERR_UNSUPPORTED;
+    if (nwin == 0) return DVID_OK;
+    hipLaunchKernelGGL(f32_swin_window_attn_kernel, dim3((unsigned)(nwin * nheads)), dim3(64), 0, s, qkv, qkv_bias, relbias, out, H, W, C, nheads, shift,
+                       0.17677669529663688110f, (int)nwin);
     LAUNCH_CHECK();
     return DVID_OK;
 }

@@ -88,7 +88,8 @@ int dvid_mha_mfma_launch(const half_t* q, const half_t* k, const half_t* v, half
 constexpr int SWIN_RELBIAS_PITCH = 64;      // floats per query row of the relative-position bias table [heads][49][64] (keys 49..63 = 0)
 int dvid_swin_window_attn_launch(const half_t* qkv, const half_t* qkv_bias16, const float* relbias, half_t* out, int batch, int H,
                                  int W, int C, int nheads, int shift, hipStream_t s);
-int dvid_patch_merge_ln_launch(const float* x, const float* g, const float* b, half_t* y16, int B, int H, int W, int C, hipStream_t s);
+int dvid_patch_merge_ln_launch(const float* x, const float* g, const float* b, half_t* y16, int B, int H, int W, int C, hipStream_t s,
+                               float* y32 = nullptr);          // y32: an fp32 copy of the result (DTYPE float32: y16 null)
 
 // dynconv.hip
 int dvid_dynconv_launch(const half_t* roi, const half_t* params, const float* g1, const float* b1, const float* g2,
@@ -184,6 +185,10 @@ int dvid_f32_roialign_launch(const RoiLevels32& lv, int channels, const float* b
 // q / k / v fp32 with head h at columns [32 h, 32 h + 32) of a row (head dim 32)
 int dvid_f32_mha_launch(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int q_ld, int kv_ld,
                         int out_ld, long q_bs, long kv_bs, long out_bs, hipStream_t s);
+// Swin window attention (shift + 7 x 7 windows + relative-position bias + region mask), fp32: qkv [B*H*W][3C], qkv_bias [3C] (q / k / v of a
+// padded window position), relbias [nheads][49][SWIN_RELBIAS_PITCH], out [B*H*W][C]
+int dvid_f32_swin_window_attn_launch(const float* qkv, const float* qkv_bias, const float* relbias, float* out, int batch, int H, int W, int C,
+                                     int nheads, int shift, hipStream_t s);
 // roi [R][49][256], params [R][32768] as P1T[64][256] | P2T[256][64], out [R][49][256]
 int dvid_f32_dynconv_launch(const float* roi, const float* params, const float* g1, const float* b1, const float* g2, const float* b2,
                             float* out, int rows, hipStream_t s);

@@ -1021,6 +1021,63 @@ int backbone_resnet_f32(dvid_model* m, const float* const* frames, int n, int he
     return DVID_OK;
 }
 
+// Swin-Transformer + FPN with DTYPE float32 (swintransformer.py:464-751): the fp16 path's launch sequence with fp32 operands everywhere
+int backbone_swin_f32(dvid_model* m, const float* const* frames, int n, int height, int width, float* p3, float* p4, float* p5, hipStream_t s) {
+    float mean[3], stdv[3];
+    for (int i = 0; i < 3; ++i) {
+        mean[i] = m->cfg.pixel_mean[i] / 255.f;
+        stdv[i] = m->cfg.pixel_std[i] / 255.f;
+    }
+    float* img = m->img8.as<float>();
+    TRY(dvid_f32_prep_images_launch(frames, img, n, height, width, mean, stdv, s));
+    int H = height, W = width;
+    float* x = m->sw_x.as<float>();
+    float* x2 = m->sw_x2.as<float>();
+    TRY(conv_run32(m->swin_patch, img, n, H, W, x, 0, nullptr, 0, s, &H, &W));
+    TRY(dvid_add_layernorm_launch(x, nullptr, m->swin_patch_norm.g, m->swin_patch_norm.b, x, nullptr, n * H * W, m->swin[0].dim, 0, s));
+    float* ln = m->sw_ln16.as<float>();
+    float* qkv = m->sw_qkv16.as<float>();
+    float* attn = m->sw_attn16.as<float>();
+    float* hid = m->sw_h16.as<float>();
+    float* stage_out[4] = {nullptr, m->c3.as<float>(), m->c4.as<float>(), m->c5.as<float>()};
+    int sh[4], sw[4];
+    for (int st = 0; st < 4; ++st) {
+        const SwinStageW& S = m->swin[st];
+        const int C = S.dim, M = n * H * W;
+        for (size_t b = 0; b < S.blocks.size(); ++b) {
+            const SwinBlockW& B = S.blocks[b];
+            const int shift = (b % 2 == 0) ? 0 : 3;
+            TRY(dvid_add_layernorm_launch(x, nullptr, B.norm1.g, B.norm1.b, ln, nullptr, M, C, 0, s));
+            TRY(linear_run32(B.qkv, ln, M, qkv, 0, s));
+            TRY(prof_other("swin_attn_f32", M, C, 49, 4.0 * M * 49.0 * C, (double)M * C * 4.0 * 4.0, s,
+                           [&] { return dvid_f32_swin_window_attn_launch(qkv, B.qkv.bias, B.relbias, attn, n, H, W, C, S.heads, shift, s); }));
+            TRY(conv_run32(B.proj, attn, M, 1, 1, x, 0, x, 1, s));                                // x += proj(attn)
+            TRY(dvid_add_layernorm_launch(x, nullptr, B.norm2.g, B.norm2.b, ln, nullptr, M, C, 0, s));
+            TRY(linear_run32(B.fc1, ln, M, hid, 2, s));                                           // exact GELU
+            TRY(conv_run32(B.fc2, hid, M, 1, 1, x, 0, x, 1, s));                                  // x += fc2(...)
+        }
+        sh[st] = H;
+        sw[st] = W;
+        if (S.has_out) TRY(dvid_add_layernorm_launch(x, nullptr, S.out_norm.g, S.out_norm.b, stage_out[st], nullptr, M, C, 0, s));
+        if (S.has_down) {
+            TRY(dvid_patch_merge_ln_launch(x, S.down_norm.g, S.down_norm.b, nullptr, n, H, W, C, s, hid));
+            H = (H + 1) / 2;
+            W = (W + 1) / 2;
+            TRY(linear_run32(S.down_red, hid, n * H * W, x2, 0, s));
+            float* t = x;
+            x = x2;
+            x2 = t;
+        }
+    }
+    float* pout[3] = {p3, p4, p5};
+    for (int l = 2; l >= 0; --l) {
+        const float* res = (l < 2) ? m->lat[l + 1].as<float>() : nullptr;
+        TRY(conv_run32(m->lateral[l], stage_out[l + 1], n, sh[l + 1], sw[l + 1], m->lat[l].as<float>(), 0, res, res ? 2 : 0, s));
+        TRY(conv_run32(m->output[l], m->lat[l].as<float>(), n, sh[l + 1], sw[l + 1], pout[l], 0, nullptr, 0, s));
+    }
+    return DVID_OK;
+}
+
 float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // box_head.py:218-223 + :734-741 on the host (a handful of distinct t values per config)
@@ -1103,8 +1160,6 @@ int dvid_model_finalize(dvid_model* m) {
     if (m->finalized) return DVID_OK;
     const dvid_config& c = m->cfg;
     m->has_backbone = c.backbone_type == 1 ? c.swin_depths[0] > 0 : c.res_blocks[0] > 0;
-    if (m->precision == 1 && m->has_backbone && c.backbone_type == 1)
-        FAIL(DVID_ERR_UNSUPPORTED, "DTYPE float32 is built for the ResNet-FPN backbone only (the Swin backbone runs DTYPE float16)");
     if (m->has_backbone && c.backbone_type == 0) {
         const std::string bu = "backbone.bottom_up.";
         TRY(make_conv_bn(m, bu + "stem.conv1", 2, 3, 8, &m->stem));
@@ -1315,14 +1370,14 @@ int dvid_workspace_reserve(dvid_model* m, int max_frames, int height, int width,
         TRY(m->img8.ensure(n * height * width * 8 * 2, &m->ws_gen));
         TRY(m->sw_x.ensure(M0 * C0 * 4, &m->ws_gen));
         TRY(m->sw_x2.ensure(M0 * C0 * 4 / 2, &m->ws_gen));
-        TRY(m->sw_ln16.ensure(M0 * C0 * 2, &m->ws_gen));
-        TRY(m->sw_qkv16.ensure(M0 * C0 * 3 * 2, &m->ws_gen));
-        TRY(m->sw_attn16.ensure(M0 * C0 * 2, &m->ws_gen));
-        TRY(m->sw_h16.ensure(M0 * C0 * 4 * 2, &m->ws_gen));
-        TRY(m->c3.ensure(n * (px4 / 4) * (C0 * 2) * 2, &m->ws_gen));
-        TRY(m->c4.ensure(n * (px4 / 16) * (C0 * 4) * 2, &m->ws_gen));
-        TRY(m->c5.ensure(n * (px4 / 64) * (C0 * 8) * 2, &m->ws_gen));
-        for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2, &m->ws_gen));
+        TRY(m->sw_ln16.ensure(M0 * C0 * 2 * es, &m->ws_gen));
+        TRY(m->sw_qkv16.ensure(M0 * C0 * 3 * 2 * es, &m->ws_gen));
+        TRY(m->sw_attn16.ensure(M0 * C0 * 2 * es, &m->ws_gen));
+        TRY(m->sw_h16.ensure(M0 * C0 * 4 * 2 * es, &m->ws_gen));
+        TRY(m->c3.ensure(n * (px4 / 4) * (C0 * 2) * 2 * es, &m->ws_gen));
+        TRY(m->c4.ensure(n * (px4 / 16) * (C0 * 4) * 2 * es, &m->ws_gen));
+        TRY(m->c5.ensure(n * (px4 / 64) * (C0 * 8) * 2 * es, &m->ws_gen));
+        for (int l = 0; l < 3; ++l) TRY(m->lat[l].ensure(n * (px4 / (4 << (2 * l))) * 256 * 2 * es, &m->ws_gen));
     }
     if (m->has_backbone && m->cfg.backbone_type == 0) {
         TRY(m->img8.ensure(n * height * width * 8 * 2, &m->ws_gen));          // (fp32: NHWC4 = the same bytes)
@@ -1578,6 +1633,8 @@ int dvid_backbone_swin_fpn_frames(dvid_model* m, const float* const* frames, int
         FAIL(DVID_ERR_STATE, "workspace reserved for %d frames of up to %dx%d, got %d of %dx%d", m->ws_frames, m->ws_h, m->ws_w, n,
              height, width);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (m->precision == 1)          // DTYPE float32: p3 / p4 / p5 are fp32 NHWC
+        return backbone_swin_f32(m, frames, n, height, width, reinterpret_cast<float*>(p3), reinterpret_cast<float*>(p4), reinterpret_cast<float*>(p5), s);
     float mean[3], inv_std[3];
     for (int i = 0; i < 3; ++i) {
         mean[i] = m->cfg.pixel_mean[i] / 255.f;

@@ -366,7 +366,7 @@ class Model:
                  backbone="resnet", swin_embed_dim=128, swin_depths=(2, 2, 18, 2), swin_heads=(4, 8, 16, 32), swin_window=7,
                  precision="float16"):
         """precision: the reference's DTYPE key -- "float16" (fp16 storage, fp16 MFMA, fp32 accumulation) or "float32" (fp32 storage,
-        fp32 MFMA; csrc/f32.hip, ResNet-FPN only).  Feature maps are fp16 / fp32 NHWC tensors accordingly."""
+        fp32 MFMA; csrc/f32.hip).  Feature maps are fp16 / fp32 NHWC tensors accordingly."""
         if precision not in PRECISIONS:
             raise _lib.DvidError(f"precision must be one of {sorted(PRECISIONS)} (the reference's DTYPE), got {precision!r}")
         lib = _lib.load()

@@ -80,8 +80,7 @@ int dvid_model_destroy(dvid_model* m);
 int dvid_model_set_tensor(dvid_model* m, const char* name, const float* data, const int64_t* shape, int ndim);
 /* The reference's global DTYPE switch (mega_core/config/defaults.py:582, default "float32"; tools/test_net.py:97-98 turns apex amp on for
  * "float16" only): precision 0 = DTYPE float16 -- fp16 weights / stored activations, fp16 MFMA, fp32 accumulation (the apex O1 policy);
- * precision 1 = DTYPE float32 -- every weight and activation fp32, products on the fp32 MFMA (csrc/f32.hip; ResNet-FPN backbone only:
- * finalize fails for Swin).  Feature maps handed to / taken from the stage functions below are fp16 NHWC in mode 0 and fp32 NHWC in
+ * precision 1 = DTYPE float32 -- every weight and activation fp32, products on the fp32 MFMA (csrc/f32.hip; both backbones).  Feature maps handed to / taken from the stage functions below are fp16 NHWC in mode 0 and fp32 NHWC in
  * mode 1.  Must be called before dvid_model_finalize (the weights are packed for one precision); the default is 0. */
 int dvid_model_set_precision(dvid_model* m, int precision);
 /* fold FrozenBN, repack to MFMA operand layouts, upload.  Fails (DVID_ERR_STATE) naming the first

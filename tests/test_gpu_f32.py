@@ -206,12 +206,29 @@ def test_f32_backbone_small(dv):
     model.close()
 
 
-def test_f32_swin_is_refused_not_run_in_fp16(dv):
-    from diffusionvid_amd._lib import DvidError
+def test_f32_backbone_swin_small(dv):
+    """Swin-Transformer + FPN with DTYPE float32 (reduced widths / depths; odd token maps, padded windows, shifted-window masks, GELU MLP,
+    PatchMerging) against the fp32 oracle (oracle/swin.py, itself bit-exact against the reference's module: golden g8).  The fp16 path's
+    bound on the same test is 3e-2."""
     from diffusionvid_amd.utils import synthetic
+    from oracle import swin as oswin
     sw = dict(embed_dim=64, depths=(2, 2, 2, 1), heads=(2, 4, 8, 16), window=7)
-    sd = synthetic.make_state_dict(0, blocks=(0, 0, 0, 0), swin=sw)
-    with pytest.raises(DvidError, match="float32"):
-        dv.Model(sd, res_blocks=(0, 0, 0, 0), backbone="swin", swin_embed_dim=64, swin_depths=sw["depths"], swin_heads=sw["heads"], precision="float32")
+    sd = synthetic.make_state_dict(0, swin=sw)
+    g = torch.Generator().manual_seed(15)
+    imgs = torch.rand(2, 3, 160, 224, generator=g)        # tokens 40x56 -> 20x28 -> 10x14 -> 5x7 (pads to 42x56, 21x28, 14x14, 7x7)
+    mean, std = (123.675, 116.280, 103.530), (58.395, 57.120, 57.375)
+    ref = oswin.backbone_swin_fpn(backbone_r101.normalizer(imgs, mean, std), sd, "backbone.", embed_dim=64, depths=sw["depths"], num_heads=sw["heads"])
+    model = dv.Model(sd, res_blocks=(0, 0, 0, 0), backbone="swin", swin_embed_dim=64, swin_depths=sw["depths"], swin_heads=sw["heads"], precision="float32")
+    model.reserve(2, 160, 224, 300)
+    p3, p4, p5 = model.backbone(imgs.cuda())
+    assert p3.dtype == torch.float32
+    for name, got in (("p3", p3), ("p4", p4), ("p5", p5)):
+        check(f"f32_backbone_swin_small.{name}", dv.nchw_from_nhwc(got), ref[name], 2e-4, 2e-4)
+    model.close()
+
+
+def test_unknown_precision_is_refused(dv):
+    from diffusionvid_amd._lib import DvidError
+    sd, _ = _head_state()
     with pytest.raises(DvidError, match="precision"):
         dv.Model(sd, res_blocks=(0, 0, 0, 0), precision="bfloat16")
