@@ -170,6 +170,39 @@ def test_f32_rcnn_head(dv, cond):
     model.close()
 
 
+def test_f32_head_against_full_dimension_reference_fixture(dv):
+    """DTYPE float32 against the REFERENCE's own RCNNHead / RCNNHead_cond at the kernels' dimensions, no oracle in between: golden g16
+    (tests/golden/make_golden.py: g16_full_dim_head) holds inputs and fp32 outputs of the reference modules run in fp32 on
+    synthetic.make_head_state_dict(0) with fp16-representable matrices (box_head.py:495-548, :605-664).  The fp16 path is held to
+    2e-3 .. 6e-3 on this fixture (test_gpu_kernels.py); with fp32 storage and products the logits agree to 2e-4 of their RMS and the
+    boxes to 3e-4 of the box size -- what is left is the fp32 summation order.  (The fixture's pooler is oracle.roi_align standing in
+    for detectron2's; tests/test_known_answers.py pins that function and the kernels against closed-form answers.)"""
+    from conftest import golden
+    from diffusionvid_amd.utils import synthetic
+    z = golden("g16_full_dim_head")
+    n, M, H, W = (int(z[k]) for k in ("n", "M", "H", "W"))
+    sd = {k: (v.half().float() if v.dim() > 1 else v.clone()) for k, v in synthetic.make_head_state_dict(int(z["weights_seed"])).items()}
+    T32 = lambda k: torch.from_numpy(z[k].astype(np.float32))
+    fd = [nhwc(T32(k)) for k in ("p3", "p4", "p5")]
+    t = torch.from_numpy(z["t"])
+    model = dv.Model(sd, res_blocks=(0, 0, 0, 0), precision="float32")
+    model.reserve(n, H, W, M)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    stages = (("head_series.0", 0, False, "boxes", None, "0"), ("head_series.1", 1, False, "bx0", "of0", "1"), ("head_series_cond.0", 0, True, "bx1", "of1", "2"))
+    for name, idx, is_cond, kb, kf, o in stages:
+        bin_ = T32(kb)
+        pro = None if kf is None else T32(kf)[0].cuda()
+        gl, gb, go = model.rcnn_head(idx, fd, H, W, bin_.cuda(), pro, t, cond=T32("cond").cuda() if is_cond else None, bad_flag=flag)
+        check(f"f32_reference_fixture[{name}].logits", gl, T32("cl" + o), 2e-4, 2e-4)
+        check(f"f32_reference_fixture[{name}].obj_features", go, T32("of" + o)[0], 1.5e-3, 1.5e-3)          # the fixture stores them as fp16
+        bw = (bin_[..., 2:] - bin_[..., :2]).clamp(min=1.0).max(-1).values
+        err = ((gb.cpu() - T32("bx" + o)).abs().max(-1).values / bw).max().item()
+        print(f"f32_reference_fixture[{name}]: boxes rel-to-size err max={err:.3e}")
+        assert err < 3e-4, name
+    assert int(flag.item()) == 0
+    model.close()
+
+
 def test_f32_global_xattn(dv):
     sd, sdo = _head_state()
     g = torch.Generator().manual_seed(8)
