@@ -1495,7 +1495,7 @@ def test_x4_free_running_statistics():
 
 
 def test_x4_free_running_statistics_float32():
-    """The same eight free-running x4 videos with `DTYPE float32` (round 6; csrc/f32.hip), against the fp32 oracle alone: with fp32 storage
+    """The same free-running x4 videos (the first four of the eight) with `DTYPE float32` (round 6; csrc/f32.hip), against the fp32 oracle alone: with fp32 storage
     and fp32 products the two evaluations differ by summation order only (~1e-5 in the logits), so a keep decision flips only when a
     score sits within ~3e-6 of 0.5 -- the chaos that separates the fp16 path (and the fp16-policy CPU oracle) from the fp32 run by 25
     AP50 points does not start.  Gate (the round-5 review's): mean AP50 of the GPU detections over the fp32 oracle's objects >= 0.99,
@@ -1504,7 +1504,7 @@ def test_x4_free_running_statistics_float32():
                                                          "MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 4], dtype="float32")
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     rows = []
-    for v in range(X4_STAT_VIDEOS):
+    for v in range(max(1, X4_STAT_VIDEOS // 2)):          # four of the eight videos keep the GPU suite near twenty minutes (all eight: profiles/r06b_f32_parity_report.txt, 5766 objects, AP50 1.0000)
         r = _x4_free_running_once(cfg, model, sd, None, v, 4, 600, 1000, with_policy=False)
         rows.append(r)
         line = (f"[x4 statistics, DTYPE float32, video {v}] {r['n_obj']} objects; AP50 over the fp32 oracle's objects: GPU {r['ap_gpu']:.4f}; over all its "
