@@ -53,8 +53,9 @@ from diffusionvid_amd.utils import comm, synthetic  # noqa: E402
 
 # measured HBM bytes per implicit-GEMM launch (rocprofv3 --pmc passes of tools/profile_round.sh), one file PER CONFIGURATION: a line
 # only ever carries the traffic collected on its own workload, never another configuration's
-TRAFFIC_FILES = {("r101", 1): "r05_pmc_igemm_traffic_r101_x1.json", ("r101", 4): "r05_pmc_igemm_traffic_r101_x4.json",
-                 ("swinb", 1): "r05_pmc_igemm_traffic_swinb_x1.json", ("r101", 1, "lookahead1"): "r05_pmc_igemm_traffic_r101_x1_lookahead1.json"}
+TRAFFIC_FILES = {("r101", 1): "r06_pmc_igemm_traffic_r101_x1.json", ("r101", 4): "r06_pmc_igemm_traffic_r101_x4.json",
+                 ("swinb", 1): "r06_pmc_igemm_traffic_swinb_x1.json", ("r101", 1, "lookahead1"): "r06_pmc_igemm_traffic_r101_x1_lookahead1.json",
+                 ("r101", 1, "float32"): "r06_pmc_igemm_traffic_r101_x1_float32.json"}
 
 
 def _md5(path):
@@ -680,13 +681,13 @@ def main():
                     os.unlink(path)
         lib.dvid_profile_reset()
         traffic = mfma_busy = stamp = None
-        key = (arch, sample_step) if lookahead > 1 else (arch, sample_step, "lookahead1")
+        key = (arch, sample_step, "float32") if f32 else (arch, sample_step) if lookahead > 1 else (arch, sample_step, "lookahead1")
         traffic_file = TRAFFIC_FILES.get(key, "")
         tpath = os.path.join(ROOT, "profiles", traffic_file)
         if traffic_file and os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS configuration (cannot be collected in-process)
             pmc = json.load(open(tpath))
             stamp = pmc.get("library_md5")
-            if stamp == LIB_MD5 and not f32:          # a profile of ANOTHER build (or another precision) is refused, not reported with a warning
+            if stamp == LIB_MD5:          # a profile of ANOTHER build is refused, not reported with a warning
                 traffic = round(pmc["hbm_bytes_per_launch"])
                 mfma_busy = pmc.get("mfma_busy_fraction")
         if ms.value <= 0:
@@ -708,7 +709,7 @@ def main():
                                 "configuration's workload and THIS build of the library, md5 %s; bytes per launch; not collected in this run)"
                                 % (traffic_file, stamp)) if traffic is not None
                                else ("refused: profiles/%s was collected on another build of the library (md5 %s, this run %s) -- re-run tools/profile_round.sh"
-                                     % (traffic_file, stamp, LIB_MD5)) if (stamp is not None and not f32)
+                                     % (traffic_file, stamp, LIB_MD5)) if stamp is not None
                                else "no PMC profile of this configuration is committed (tools/profile_round.sh <tag> --arch ... --sample-step ...)",
              "mfma_busy_pmc": None if mfma_busy is None else round(mfma_busy, 4),
              "end_to_end_tflops": round(fps / max(world, 1) * gflop_frame / 1e3, 1),
@@ -765,10 +766,9 @@ def main():
             side("swinb_x1", "swinb", 1, 76, 5, with_roofline=True)
             # `DTYPE float32` (the reference's default precision; round 6): fp32 storage + fp32 MFMA end to end (csrc/f32.hip) -- the mode in
             # which the path meets SURVEY.md 8(d)'s tolerances against the fp32 oracle (tests/test_gpu_e2e.py); 1/16 of the fp16 MFMA rate
-            f32_note = ("DTYPE float32: every weight and activation fp32, products on v_mfma_f32_32x32x2_f32 (157 TFLOP/s dense peak); groups of 13 "
-                        "batches (104 frames)")
-            side("r101_x1_float32", "r101", 1, 13, 2, with_roofline=True, dtype="float32", note=f32_note)
-            side("r101_x4_float32", "r101", 4, 13, 2, dtype="float32", note=f32_note)
+            f32_note = "DTYPE float32: every weight and activation fp32, products on v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s dense peak); one group per 304-frame video"
+            side("r101_x1_float32", "r101", 1, 38, 2, with_roofline=True, dtype="float32", note=f32_note)
+            side("r101_x4_float32", "r101", 4, 38, 2, dtype="float32", note=f32_note)
             # the latency-oriented variant of demo/demo.py:60-68 -- one frame per call, one new global frame per
             # call merged into the memory and pruned back (vid_mega.py:213-215)
             side("r101_x1_streaming", "r101", 1, 1, 3,

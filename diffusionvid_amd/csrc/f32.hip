@@ -34,8 +34,10 @@ __device__ __forceinline__ float16v mfma_f32(float a, float b, float16v c) { ret
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int F32_BM = 128, F32_BK = 16, F32_LDT = 20;
 
+// (four waves per SIMD: with 128 registers per wave the accumulators stay in VGPRs and four 40-KB workgroups fill a CU's LDS exactly; 1-10 %
+// faster than three per SIMD on every layer shape, profiles/r06k_f32_gemm_w4.txt)
 template <int BN>
-__global__ __launch_bounds__(256) void f32_igemm_kernel(F32GemmParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void f32_igemm_kernel(F32GemmParams p) {
     constexpr int NB = BN / 64;          // 32-column blocks per wave
     __shared__ float Smem[2 * F32_BM * F32_LDT + 2 * BN * F32_LDT];          // A stages | B stages; the epilogue's half tile afterwards
     float (*As)[F32_BM * F32_LDT] = reinterpret_cast<float (*)[F32_BM * F32_LDT]>(Smem);

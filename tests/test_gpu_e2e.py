@@ -1249,12 +1249,14 @@ def test_memory_build_on_side_stream_is_identical(lookahead):
         assert torch.equal(a.get_field("labels"), b.get_field("labels"))
 
 
-@pytest.mark.parametrize("arch,sample_step,noise", [("r101", 1, "device"), ("r101", 4, "device"), ("r101", 1, "host"), ("swin", 1, "device")])
-def test_call_graph_replay_is_bit_identical(arch, sample_step, noise):
+@pytest.mark.parametrize("arch,sample_step,noise,dtype", [("r101", 1, "device", "float16"), ("r101", 4, "device", "float16"), ("r101", 1, "host", "float16"),
+                                                          ("swin", 1, "device", "float16"), ("r101", 4, "device", "float32")])
+def test_call_graph_replay_is_bit_identical(arch, sample_step, noise, dtype):
     """The steady-state call of the reference's protocol (one batch per call, INPUT.LOOKAHEAD_BATCHES 1) replayed as one hipGraph
     (DiffusionDet._graphed_call) against the same calls launched kernel by kernel: two videos of different lengths (the second
     one re-uses the graph captured during the first, with another global memory; ragged tails run the ordinary way), every
-    detection bit for bit.  The graphed run must actually have replayed (calls 3.. of each video's full batches)."""
+    detection bit for bit.  The graphed run must actually have replayed (calls 3.. of each video's full batches).  dtype float32: the
+    same with the fp32 path's launches (csrc/f32.hip) in the capture."""
     from diffusionvid_amd.config import get_cfg
     from diffusionvid_amd.data.synthetic_video import SyntheticVIDDataset
     from diffusionvid_amd.modeling.detector import build_detection_model
@@ -1263,9 +1265,9 @@ def test_call_graph_replay_is_bit_identical(arch, sample_step, noise):
     outs, replays = {}, {}
     for graphs in (False, True):
         if arch == "r101":
-            cfg, model = _build(sample_step, (1, 1, 2, 1), "trained_like")
+            cfg, model = _build(sample_step, (1, 1, 2, 1), "trained_like", dtype=dtype)
         else:
-            cfg = get_cfg("configs/vid_Swin_B_DiffusionVID.yaml", ["DTYPE", "float16"], "configs/BASE_RCNN_1gpu.yaml")
+            cfg = get_cfg("configs/vid_Swin_B_DiffusionVID.yaml", ["DTYPE", dtype], "configs/BASE_RCNN_1gpu.yaml")
             cfg.MODEL.SWIN.CONFIG_OVERRIDE = dict(embed_dim=64, depths=(2, 2, 2, 1), heads=(2, 4, 8, 16), window=7)
             cfg.freeze()
             model = _weights(build_detection_model(cfg), "trained_like").to("cuda").eval()
