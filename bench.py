@@ -71,10 +71,13 @@ def _md5(path):
 # traffic comes from another build says so
 LIB_MD5 = _md5(os.path.join(ROOT, "diffusionvid_amd", "libdvid_hip.so"))
 PEAK_FP16_TFLOPS = 2500.0
-PEAK_FP32_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md): the DTYPE float32 path's roof
+PEAK_FP32_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md): the DTYPE float32 path's roof with library option f32_split = 0
+# ... and with f32_split = 1 (default): every fp32-grade product is three passes of the fp16 MFMA over (hi, lo) operand pairs (csrc/f32.hip:
+# f32x3_igemm_kernel), so the roof of that kernel in ALGORITHMIC (fp32-grade) FLOP is a third of the dense fp16 peak
+PEAK_FP32_SPLIT_TFLOPS = round(PEAK_FP16_TFLOPS / 3.0, 1)
 # the library's option table at its defaults (csrc/options.h): the configuration every number of this file is quoted on unless --option says otherwise;
 # tests/test_host_logic.py::test_default_library_configuration_is_the_benchmarked_one holds the library to this string
-DEFAULT_LIBRARY_CONFIG = "conv3x3=1 wstat=1 bneck_fuse=1 stem_pool=1 head_tail=1 ln_rows=1 igemm_cfg=-1 igemm_tune=-1 igemm_generic=0 bneck_lds=0"
+DEFAULT_LIBRARY_CONFIG = "conv3x3=1 wstat=1 bneck_fuse=1 stem_pool=1 head_tail=1 ln_rows=1 igemm_cfg=-1 igemm_tune=-1 igemm_generic=0 f32_split=1 bneck_lds=0"
 PEAK_HBM_GBS = 8000.0
 # algorithmic work per output frame: backbone + heads + global attention, faithful pass counts
 ALG_GFLOP_PER_FRAME = {("r101", 1): 249.3, ("r101", 4): 385.0, ("swinb", 1): 459.6}
@@ -636,6 +639,7 @@ def main():
 
     def measure_roofline(model, ds, arch, sample_step, fps, frames_per_step, lookahead):
         f32 = model.dtype == "float32"
+        f32_peak = PEAK_FP32_SPLIT_TFLOPS if ops.get_option("f32_split") else PEAK_FP32_TFLOPS
         """per-launch HIP events on the library's stream; sub-batch chains are switched off for this pass so that launches do
         not overlap and each event pair times one kernel alone (the same condition the rocprofv3 summaries in profiles/ are
         taken under: DVID_CHAINS=1)"""
@@ -675,7 +679,7 @@ def main():
                 keep = None
             try:
                 _lib.check(lib.dvid_profile_dump(path.encode()), "dvid_profile_dump")
-                top = top_kernels(path, mfma_peak=PEAK_FP32_TFLOPS if f32 else PEAK_FP16_TFLOPS)
+                top = top_kernels(path, mfma_peak=f32_peak if f32 else PEAK_FP16_TFLOPS)
             finally:
                 if not keep:
                     os.unlink(path)
@@ -700,8 +704,11 @@ def main():
         # kFLOP/B); `achieved` = algorithmic FLOP of the launches / their summed durations.  The layer-by-layer byte model
         # (every layer's input + weights + output + residual once) and the measured traffic are printed next to it: their
         # ratio to the ideal-fusion figure is the activation round-trip traffic that fusion has yet to remove.
-        peak = PEAK_FP32_TFLOPS if f32 else PEAK_FP16_TFLOPS
-        r = {"bound": "mfma", "kernel": ("implicit-GEMM conv/linear kernel of the DTYPE float32 path, fp32 MFMA v_mfma_f32_32x32x2_f32 (f32_igemm_kernel, csrc/f32.hip)" if f32 else
+        peak = f32_peak if f32 else PEAK_FP16_TFLOPS
+        r = {"bound": "mfma", "kernel": (("implicit-GEMM conv/linear kernel of the DTYPE float32 path with split operands (f32x3_igemm_kernel, csrc/f32.hip): fp32 storage, every product as three "
+                                          "fp16-MFMA passes over (hi, lo) fp16 pairs with fp32 accumulation; `achieved` counts ALGORITHMIC FLOP (one per fp32-grade product), `peak` = the dense "
+                                          "fp16 MFMA peak / 3" if ops.get_option("f32_split") else
+                                          "implicit-GEMM conv/linear kernel of the DTYPE float32 path, fp32 MFMA v_mfma_f32_32x32x2_f32 (f32_igemm_kernel, csrc/f32.hip)") if f32 else
                                          "implicit-GEMM conv/linear kernels, fp16 MFMA (igemm2_kernel; conv3x3_* for the 3x3 / stride-1 layers; wstat_kernel for the short-K / wide-N 1x1 layers; bneck64 / bneck128_tail_kernel = a res2 / res3 block behind its conv1 as one launch)"),
              "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
              "traffic": traffic,
@@ -735,8 +742,10 @@ def main():
     del model
     others = {}
 
-    def side(name, arch, sample_step, lookahead, steps, skip_unobservable=False, extra=(), note=None, with_roofline=False, dtype="float16"):
+    def side(name, arch, sample_step, lookahead, steps, skip_unobservable=False, extra=(), note=None, with_roofline=False, dtype="float16", options=None):
         try:
+            for k, v in (options or {}).items():          # library options of this side measurement only (restored below)
+                ops.set_option(k, v)
             c2, m2 = build(arch, sample_step, lookahead, skip_unobservable, extra, dtype=dtype)
             d2 = SyntheticVIDDataset([L], c2, height=H, width=W, device=device, video_base=rank, emit_ref_ahead=False)
             d2._cache = ds._cache                  # same frames, already resident
@@ -753,9 +762,16 @@ def main():
             if note:
                 others[name]["ms_per_frame"] = round(t2 / max(f2, 1) * world * 1e3, 3)
                 others[name]["what"] = note
+            if options:
+                others[name]["library_options"] = dict(options)
             release(m2)
         except Exception as e:                     # a side measurement must never take the headline line down
             others[name] = {"error": repr(e)[:300]}
+        finally:
+            if options:
+                ops.reset_options()
+                for kv in args.option:
+                    ops.set_option(kv.partition("=")[0], int(kv.partition("=")[2]))
 
     if not args.no_side_configs:
         side("reference_protocol_lookahead_1", args.arch, args.sample_step, 1, 5, with_roofline=True)
@@ -766,9 +782,12 @@ def main():
             side("swinb_x1", "swinb", 1, 76, 5, with_roofline=True)
             # `DTYPE float32` (the reference's default precision; round 6): fp32 storage + fp32 MFMA end to end (csrc/f32.hip) -- the mode in
             # which the path meets SURVEY.md 8(d)'s tolerances against the fp32 oracle (tests/test_gpu_e2e.py); 1/16 of the fp16 MFMA rate
-            f32_note = "DTYPE float32: every weight and activation fp32, products on v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s dense peak); one group per 304-frame video"
+            f32_note = ("DTYPE float32: every weight and activation fp32; conv / linear products as three fp16-MFMA passes over split (hi, lo) operands with fp32 accumulation "
+                        "(library option f32_split = 1; 0 = the fp32 MFMA, 157.3 TFLOP/s), the per-box products on the fp32 MFMA; one group per 304-frame video")
             side("r101_x1_float32", "r101", 1, 38, 2, with_roofline=True, dtype="float32", note=f32_note)
             side("r101_x4_float32", "r101", 4, 38, 2, dtype="float32", note=f32_note)
+            side("r101_x1_float32_fp32_mfma", "r101", 1, 38, 2, with_roofline=True, dtype="float32", options={"f32_split": 0},
+                 note="DTYPE float32 with library option f32_split = 0: every product exact on the fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense peak)")
             # the latency-oriented variant of demo/demo.py:60-68 -- one frame per call, one new global frame per
             # call merged into the memory and pruned back (vid_mega.py:213-215)
             side("r101_x1_streaming", "r101", 1, 1, 3,

@@ -50,7 +50,7 @@ SIGNATURES = {
                                             c_void_p, c_void_p, c_void_p]),
     "dvid_roialign_v2_multilevel_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                                 c_void_p, c_void_p, c_void_p]),
-    "dvid_conv2d_nhwc_f32": (c_int, [c_void_p] * 5 + [c_int] * 12 + [c_void_p]),
+    "dvid_conv2d_nhwc_f32": (c_int, [c_void_p] * 8 + [c_int] * 12 + [c_void_p]),
     "dvid_mha_f32": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_int64] * 3 + [c_void_p]),
     "dvid_dynconv_f32": (c_int, [c_void_p] * 7 + [c_int, c_void_p]),
     "dvid_select_topk_features": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "igemm_epilogue.h"
 #include "kernels.h"
+#include "options.h"
 
 namespace {
 
@@ -34,6 +35,92 @@ __device__ __forceinline__ float16v mfma_f32(float a, float b, float16v c) { ret
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int F32_BM = 128, F32_BK = 16, F32_LDT = 20;
 
+// Epilogue shared by the two implicit-GEMM kernels below.  Register r of an accumulator block = row (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3),
+// column lane & 31.  out = act((acc * wscale[n]) + bias[n] + residual): wscale undoes the power-of-two row scaling of the packed weights
+// (exact; null = none).
+// Row-coalesced form (N and ldc multiples of 4): the tile crosses LDS in two halves of 64 rows (the operand buffers are free by now),
+// and every lane finishes 4 consecutive channels of a row -- 16-byte residual reads and stores, 512 contiguous bytes per 32 lanes --
+// instead of 4-byte accesses 2 rows x 128 bytes per instruction (the short-K layers, res3 / res4 conv3 + residual, ran at 0.39 of
+// the MFMA rate on their stores: profiles/r06c_bench.json).  General form (N tails: class_logits, bboxes_delta): straight from the
+// accumulator layout.  The caller has passed a barrier behind its last LDS read.
+template <int BN>
+__device__ __forceinline__ void f32_epilogue(const F32GemmParams& p, float16v (&acc)[2][BN / 64], float* Cs, int m0, int n0, int wm, int wn, int lane,
+                                             int tid) {
+    constexpr int NB = BN / 64;
+    const int fr = lane & 31;
+    if (((p.Cout | p.ldc) & 3) == 0) {
+        constexpr int CP = BN + 4;          // pitch of an LDS row (floats)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (wm == half) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            Cs[(mb * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3)) * CP + wn * (BN / 2) + nb * 32 + fr] = acc[mb][nb][r];
+            }
+            __syncthreads();
+            constexpr int VPR = BN / 4;          // float4 per row
+            for (int idx = tid; idx < 64 * VPR; idx += 256) {
+                const int row = idx / VPR, c4 = (idx - row * VPR) * 4;
+                const int m = m0 + half * 64 + row, n = n0 + c4;
+                if (m >= p.M || n >= p.Cout) continue;
+                float4v v = *reinterpret_cast<const float4v*>(&Cs[row * CP + c4]);
+                if (p.wscale) v *= *reinterpret_cast<const float4v*>(p.wscale + n);
+                if (p.bias) v += *reinterpret_cast<const float4v*>(p.bias + n);
+                if (p.res_mode == 1) {
+                    v += *reinterpret_cast<const float4v*>(p.res + (long)m * p.Cout + n);
+                } else if (p.res_mode == 2) {
+                    const int ox = m % p.Wo;
+                    const int t2 = m / p.Wo;
+                    const int oy = t2 % p.Ho;
+                    const int img = t2 / p.Ho;
+                    v += *reinterpret_cast<const float4v*>(p.res + ((long)(img * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + n);
+                }
+                if (p.relu == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.relu == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                *reinterpret_cast<float4v*>(p.out + (long)m * p.ldc + n) = v;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + wn * (BN / 2) + nb * 32 + fr;
+        if (n >= p.Cout) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float ws = p.wscale ? p.wscale[n] : 1.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mb * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                if (m >= p.M) continue;
+                float v = acc[mb][nb][r] * ws + bias;
+                if (p.res_mode == 1) {
+                    v += p.res[(long)m * p.Cout + n];
+                } else if (p.res_mode == 2) {
+                    const int ox = m % p.Wo;
+                    const int t2 = m / p.Wo;
+                    const int oy = t2 % p.Ho;
+                    const int img = t2 / p.Ho;
+                    v += p.res[((long)(img * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + n];
+                }
+                if (p.relu == 1) v = fmaxf(v, 0.f);
+                else if (p.relu == 2) v = gelu_erf(v);
+                p.out[(long)m * p.ldc + n] = v;
+            }
+    }
+}
+
 // (four waves per SIMD: with 128 registers per wave the accumulators stay in VGPRs and four 40-KB workgroups fill a CU's LDS exactly; 1-10 %
 // faster than three per SIMD on every layer shape, profiles/r06k_f32_gemm_w4.txt)
 template <int BN>
@@ -42,7 +129,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ float Smem[2 * F32_BM * F32_LDT + 2 * BN * F32_LDT];          // A stages | B stages; the epilogue's half tile afterwards
     float (*As)[F32_BM * F32_LDT] = reinterpret_cast<float (*)[F32_BM * F32_LDT]>(Smem);
     float (*Bs)[BN * F32_LDT] = reinterpret_cast<float (*)[BN * F32_LDT]>(Smem + 2 * F32_BM * F32_LDT);
-    float* Cs = Smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int t = igemm_xcd_remap((int)blockIdx.x, p.tiles_m * p.tiles_n);          // an XCD owns a contiguous run of row tiles
@@ -144,82 +230,167 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         __syncthreads();
     }
 
-    // epilogue.  Register r of an accumulator block = row (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3), column lane & 31.
-    // Row-coalesced form (N and ldc multiples of 4): the tile crosses LDS in two halves of 64 rows (the operand buffers are free now),
-    // and every lane finishes 4 consecutive channels of a row -- 16-byte residual reads and stores, 512 contiguous bytes per 32 lanes --
-    // instead of 4-byte accesses 2 rows x 128 bytes per instruction (the short-K layers, res3 / res4 conv3 + residual, ran at 0.39 of
-    // the MFMA rate on their stores: profiles/r06c_bench.json).
-    if (((p.Cout | p.ldc) & 3) == 0) {
-        constexpr int CP = BN + 4;          // pitch of an LDS row (floats)
-        static_assert(64 * CP <= 2 * F32_BM * F32_LDT + 2 * BN * F32_LDT, "half tile fits the operand buffers");
+    f32_epilogue<BN>(p, acc, Smem, m0, n0, wm, wn, lane, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same implicit GEMM with SPLIT operands: every fp32 operand value v is staged to LDS as two fp16 numbers hi = fp16(v),
+// lo = fp16(v - hi), and a product row is accumulated as  lo_a * hi_b + hi_a * lo_b + hi_a * hi_b  on v_mfma_f32_32x32x16_f16 (exact
+// fp16 x fp16 products, fp32 accumulation): three passes of the fp16 MFMA, 16 / 3 = 5.3 x the fp32 MFMA's rate.  What is dropped is
+// lo_a * lo_b (2^-22 of the product) and the rounding of lo (2^-22 relative while lo is a normal fp16 number, i.e. |v| >= 2^-3; an absolute
+// 3e-8 below that).  The packed weight rows are scaled by a power of two so that each row's largest magnitude lies in [0.5, 1) (csrc/model.hip:
+// make_conv; undone exactly by `wscale` in the epilogue) -- a weight of 0.02 would otherwise carry its lo part as an fp16 subnormal.
+// Activations need |v| < 65504 (true of every tensor on this path by orders of magnitude).  Library option f32_split (default 1) selects
+// it; 0 = the exact-fp32 kernel above.  Both are held to the same bounds by tests/test_gpu_f32.py and the end-to-end float32 tests.
+// Tile 128 x BN x 32, four waves as 2 x 2; LDS holds A_hi | A_lo | B_hi | B_lo as [row][32 halves] at a pitch of 40 halves (80 bytes: the
+// ds_read_b128 fragment reads are conflict-free), single-buffered: the next step's global loads are in flight under this step's 24 MFMAs,
+// converted and written between two barriers.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int X3_BM = 128, X3_BK = 32, X3_PITCH = 40;
+// (BN 128 at three waves per SIMD -- 162 registers, no spills -- is 2-30 % faster than the compiler's two: profiles/r06o_x3_w3.txt)
+template <int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4))) void f32x3_igemm_kernel(F32GemmParams p) {
+    constexpr int NB = BN / 64;
+    constexpr int AP = X3_BM / 32, BP = BN / 32;          // loader passes (32 tile rows each: 8 lanes x float4 per row)
+    constexpr int ROWS = 2 * X3_BM + 2 * BN;
+    static_assert(64 * (BN + 4) * 4 <= ROWS * X3_PITCH * 2, "the epilogue's half tile fits the operand buffers");
+    __shared__ __attribute__((aligned(16))) half_t Sm[ROWS * X3_PITCH];
+    half_t* const Ahi = Sm;
+    half_t* const Alo = Sm + X3_BM * X3_PITCH;
+    half_t* const Bhi = Sm + 2 * X3_BM * X3_PITCH;
+    half_t* const Blo = Bhi + BN * X3_PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int t = igemm_xcd_remap((int)blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m0 = tm * X3_BM, n0 = tn * BN;
+    const int lr = tid >> 3, kq = (tid & 7) * 4;
+    const bool pointwise = p.KH == 1 && p.KW == 1 && p.pad == 0;
+
+    long abase[AP];
+    int ay[AP], ax[AP];
+    bool aok[AP];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (wm == half) {
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + lr + 32 * i;
+        aok[i] = m < p.M;
+        const int mm = aok[i] ? m : 0;
+        const int ox = mm % p.Wo;
+        const int t2 = mm / p.Wo;
+        const int oy = t2 % p.Ho;
+        const int img = t2 / p.Ho;
+        ay[i] = oy * p.stride - p.pad;
+        ax[i] = ox * p.stride - p.pad;
+        abase[i] = (long)img * p.H * p.W;
+    }
+    // the weights arrive already split (p.w_hi / p.w_lo: the packed, row-scaled fp32 rows as fp16 (hi, lo) planes, made once at load):
+    // their half of the tile needs no conversion
+    long wrow[BP];
+    bool wok[BP];
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
+    for (int i = 0; i < BP; ++i) {
+        const int n = n0 + lr + 32 * i;
+        wok[i] = n < p.Cout;
+        wrow[i] = (long)(wok[i] ? n : 0) * p.Kpad + kq;
+    }
+
+    // unconditional loads (an out-of-range lane reads a valid dummy address; its value becomes zero when staged)
+    float4v ra[AP];
+    half4 rbh[BP], rbl[BP];
+    bool rok[AP], rwk[BP];
+    auto fetch = [&](int kt) {
+        const int k = kt * X3_BK + kq;
+        int c = k, ky = 0, kx = 0;
+        if (!pointwise) {
+            const int tap = k / p.Cin;
+            c = k - tap * p.Cin;
+            ky = tap / p.KW;
+            kx = tap - ky * p.KW;
+        }
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
+        for (int i = 0; i < AP; ++i) {
+            const int iy = ay[i] + ky, ix = ax[i] + kx;
+            rok[i] = aok[i] && k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            ra[i] = *reinterpret_cast<const float4v*>(rok[i] ? p.in + (abase[i] + (long)iy * p.W + ix) * p.Cin + c : p.in);
+        }
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            Cs[(mb * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3)) * CP + wn * (BN / 2) + nb * 32 + fr] = acc[mb][nb][r];
+        for (int i = 0; i < BP; ++i) {
+            rwk[i] = wok[i] && k < p.Kpad;
+            const long off = rwk[i] ? wrow[i] + kt * X3_BK : 0;
+            rbh[i] = *reinterpret_cast<const half4*>(p.w_hi + off);
+            rbl[i] = *reinterpret_cast<const half4*>(p.w_lo + off);
+        }
+    };
+    auto split_store = [&](float4v v, bool ok, half_t* hi_row, half_t* lo_row) {
+        if (!ok) v = (float4v){0.f, 0.f, 0.f, 0.f};
+        const half4 h = __builtin_convertvector(v, half4);                     // round to nearest even
+        const float4v back = __builtin_convertvector(h, float4v);
+        const half4 l = __builtin_convertvector(v - back, half4);              // v - back is exact in fp32
+        *reinterpret_cast<half4*>(hi_row) = h;
+        *reinterpret_cast<half4*>(lo_row) = l;
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) split_store(ra[i], rok[i], Ahi + (lr + 32 * i) * X3_PITCH + kq, Alo + (lr + 32 * i) * X3_PITCH + kq);
+        const half4 hz = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            *reinterpret_cast<half4*>(Bhi + (lr + 32 * i) * X3_PITCH + kq) = rwk[i] ? rbh[i] : hz;
+            *reinterpret_cast<half4*>(Blo + (lr + 32 * i) * X3_PITCH + kq) = rwk[i] ? rbl[i] : hz;
+        }
+    };
+
+    float16v acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (p.Kpad + X3_BK - 1) / X3_BK;
+    const int fr = lane & 31, fk = (lane >> 5) * 8;          // MFMA operand maps: lane l = row l & 31, k = 8 (l >> 5) .. + 8 of a 16-deep K step
+    fetch(0);
+    stage();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) fetch(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < X3_BK / 16; ++ks) {
+            half8 ah[2], al[2], bh[NB], bl[NB];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int off = (wm * 64 + mb * 32 + fr) * X3_PITCH + ks * 16 + fk;
+                ah[mb] = *reinterpret_cast<const half8*>(Ahi + off);
+                al[mb] = *reinterpret_cast<const half8*>(Alo + off);
             }
-            __syncthreads();
-            constexpr int VPR = BN / 4;          // float4 per row
-            for (int idx = tid; idx < 64 * VPR; idx += 256) {
-                const int row = idx / VPR, c4 = (idx - row * VPR) * 4;
-                const int m = m0 + half * 64 + row, n = n0 + c4;
-                if (m >= p.M || n >= p.Cout) continue;
-                float4v v = *reinterpret_cast<const float4v*>(&Cs[row * CP + c4]);
-                if (p.bias) v += *reinterpret_cast<const float4v*>(p.bias + n);
-                if (p.res_mode == 1) {
-                    v += *reinterpret_cast<const float4v*>(p.res + (long)m * p.Cout + n);
-                } else if (p.res_mode == 2) {
-                    const int ox = m % p.Wo;
-                    const int t2 = m / p.Wo;
-                    const int oy = t2 % p.Ho;
-                    const int img = t2 / p.Ho;
-                    v += *reinterpret_cast<const float4v*>(p.res + ((long)(img * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + n);
-                }
-                if (p.relu == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if (p.relu == 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                }
-                *reinterpret_cast<float4v*>(p.out + (long)m * p.ldc + n) = v;
+            for (int nb = 0; nb < NB; ++nb) {
+                const int off = (wn * (BN / 2) + nb * 32 + fr) * X3_PITCH + ks * 16 + fk;
+                bh[nb] = *reinterpret_cast<const half8*>(Bhi + off);
+                bl[nb] = *reinterpret_cast<const half8*>(Blo + off);
             }
+            // the two small terms first, then the leading one (the accumulator is fp32 either way; the order is fixed)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+        }
+        __syncthreads();                       // every wave has read this step's fragments
+        if (kt + 1 < nk) {
+            stage();
             __syncthreads();
         }
-        return;
     }
-    // general form (N tails: class_logits, bboxes_delta), straight from the accumulator layout
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int n = n0 + wn * (BN / 2) + nb * 32 + fr;
-        if (n >= p.Cout) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mb * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-                if (m >= p.M) continue;
-                float v = acc[mb][nb][r] + bias;
-                if (p.res_mode == 1) {
-                    v += p.res[(long)m * p.Cout + n];
-                } else if (p.res_mode == 2) {
-                    const int ox = m % p.Wo;
-                    const int t2 = m / p.Wo;
-                    const int oy = t2 % p.Ho;
-                    const int img = t2 / p.Ho;
-                    v += p.res[((long)(img * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + n];
-                }
-                if (p.relu == 1) v = fmaxf(v, 0.f);
-                else if (p.relu == 2) v = gelu_erf(v);
-                p.out[(long)m * p.ldc + n] = v;
-            }
-    }
+    f32_epilogue<BN>(p, acc, reinterpret_cast<float*>(Sm), m0, n0, wm, wn, lane, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -734,12 +905,15 @@ int dvid_f32_igemm_launch(const F32GemmParams& p0, hipStream_t s) {
     if (p.Cin % 4 || p.Kpad % F32_BK || p.K > p.Kpad || p.ldc < p.Cout) return DVID_ERR_ARG;
     if (p.res_mode == 2 && ((p.Ho | p.Wo) & 1)) return DVID_ERR_ARG;
     p.tiles_m = ceil_div(p.M, F32_BM);
+    const bool split = g_opt.f32_split != 0 && p.w_hi && p.w_lo;          // split (hi, lo) fp16 operands on the fp16 MFMA, or exact fp32 products on the fp32 MFMA
     if (p.Cout <= 64) {
         p.tiles_n = ceil_div(p.Cout, 64);
-        hipLaunchKernelGGL(f32_igemm_kernel<64>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        if (split) hipLaunchKernelGGL(f32x3_igemm_kernel<64>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(f32_igemm_kernel<64>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
     } else {
         p.tiles_n = ceil_div(p.Cout, 128);
-        hipLaunchKernelGGL(f32_igemm_kernel<128>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        if (split) hipLaunchKernelGGL(f32x3_igemm_kernel<128>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(f32_igemm_kernel<128>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
     }
     LAUNCH_CHECK();
     return DVID_OK;

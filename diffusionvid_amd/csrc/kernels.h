@@ -161,7 +161,10 @@ int dvid_gather_rows_launch(const float* x, const int* idx, float* y, int m, int
 struct F32GemmParams {
     const float* in;     // NHWC fp32 [N,H,W,Cin], Cin % 4 == 0  (Linear: [M,K] as N = M, H = W = 1, Cin = K)
     const float* w;      // [Cout][Kpad], k = (ky*KW + kx)*Cin + c, zero beyond K; Kpad % 16 == 0
+    const half_t* w_hi;  // the same rows split for the split-operand kernel: w_hi = fp16(w), w_lo = fp16(w - w_hi) (null: the fp32-MFMA kernel runs)
+    const half_t* w_lo;
     const float* bias;   // [Cout] or nullptr
+    const float* wscale; // [Cout] or nullptr: the accumulator of channel n is multiplied by wscale[n] (undoes a power-of-two scaling of the packed row)
     const float* res;    // fp32 residual, see res_mode
     float* out;          // [M][ldc]
     int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;

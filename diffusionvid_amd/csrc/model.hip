@@ -223,6 +223,8 @@ struct ConvW {   // conv or linear weights in MFMA-operand layout
     int alg_k = 0;             // algorithmic K for the FLOP count when the packed layout carries structural zeros (0: kh*kw*cin_real)
     // DTYPE float32 (csrc/f32.hip): the same rows un-rounded, [cout][kpad32] fp32 with k = (ky*kw + kx)*cin32 + c, cin32 = cin rounded up to 4
     float* w32 = nullptr;
+    half_t *w16hi = nullptr, *w16lo = nullptr;          // the scaled rows as fp16 (hi, lo) planes for the split-operand kernel (csrc/f32.hip)
+    float* wscale32 = nullptr;          // [cout]: 2^-e of the power-of-two scaling that puts each packed row's largest magnitude in [0.5, 1) (exact; undone in the epilogue)
     int cin32 = 0, kpad32 = 0;
 };
 // fragment-order copies of the head-tail weights (csrc/headtail.hip)
@@ -369,16 +371,37 @@ int make_conv(dvid_model* m, const HostTensor& w, const std::vector<float>& scal
     TRY(m->upload(packed.data(), packed.size() * sizeof(half_t), reinterpret_cast<void**>(&out->w)));
     if (m->precision == 1) {          // the un-rounded rows for the fp32 kernels
         const int c4 = (cin + 3) / 4 * 4, k32 = (kh * kw * c4 + 15) / 16 * 16;
-        std::vector<float> p32((size_t)cout * k32, 0.f);
+        std::vector<float> p32((size_t)cout * k32, 0.f), ws(cout, 1.f);
         for (int o = 0; o < cout; ++o) {
             const int so = row_perm ? (*row_perm)[o] : o;
             const float sc = scale.empty() ? 1.f : scale[so];
+            float mx = 0.f;
             for (int c = 0; c < cin; ++c)
                 for (int y = 0; y < kh; ++y)
-                    for (int x = 0; x < kw; ++x)
-                        p32[(size_t)o * k32 + (size_t)(y * kw + x) * c4 + c] = w.v[(((size_t)so * cin + c) * kh + y) * kw + x] * sc;
+                    for (int x = 0; x < kw; ++x) {
+                        const float v = w.v[(((size_t)so * cin + c) * kh + y) * kw + x] * sc;
+                        p32[(size_t)o * k32 + (size_t)(y * kw + x) * c4 + c] = v;
+                        mx = fmaxf(mx, fabsf(v));
+                    }
+            // the row times 2^e with its largest magnitude in [0.5, 1): the split-operand kernel keeps (hi, lo) fp16 parts of every value, and lo
+            // is a full-precision fp16 number only while |v| >= 2^-3; the epilogue multiplies the sums by 2^-e (both exact)
+            if (mx > 0.f && std::isfinite(mx)) {
+                int e = 0;
+                (void)frexpf(mx, &e);          // mx = f * 2^e, f in [0.5, 1)
+                const float up = ldexpf(1.f, -e);
+                for (int k = 0; k < k32; ++k) p32[(size_t)o * k32 + k] *= up;
+                ws[o] = ldexpf(1.f, e);
+            }
         }
         TRY(upload_f32(m, p32, &out->w32));
+        TRY(upload_f32(m, ws, &out->wscale32));
+        std::vector<half_t> hi(p32.size()), lo(p32.size());
+        for (size_t i = 0; i < p32.size(); ++i) {
+            hi[i] = f2h(p32[i]);
+            lo[i] = f2h(p32[i] - (float)hi[i]);
+        }
+        TRY(m->upload(hi.data(), hi.size() * sizeof(half_t), reinterpret_cast<void**>(&out->w16hi)));
+        TRY(m->upload(lo.data(), lo.size() * sizeof(half_t), reinterpret_cast<void**>(&out->w16lo)));
         out->cin32 = c4;
         out->kpad32 = k32;
     }
@@ -661,7 +684,10 @@ int conv_run32(const ConvW& w, const float* in, int n, int h, int wd, float* out
     memset(&p, 0, sizeof(p));
     p.in = in;
     p.w = w.w32;
+    p.w_hi = w.w16hi;
+    p.w_lo = w.w16lo;
     p.bias = w.bias;
+    p.wscale = w.wscale32;
     p.res = res;
     p.out = out;
     p.H = h;
@@ -1287,7 +1313,7 @@ const OptEntry kOptions[] = {
     {"conv3x3", &DvidOptions::conv3x3, 0, 2},       {"wstat", &DvidOptions::wstat, 0, 2},           {"bneck_fuse", &DvidOptions::bneck_fuse, 0, 2},
     {"stem_pool", &DvidOptions::stem_pool, 0, 1},   {"head_tail", &DvidOptions::head_tail, 0, 1},   {"ln_rows", &DvidOptions::ln_rows, 0, 1},
     {"igemm_cfg", &DvidOptions::igemm_cfg, -1, 255}, {"igemm_tune", &DvidOptions::igemm_tune, -1, 1}, {"igemm_generic", &DvidOptions::igemm_generic, 0, 1},
-    {"bneck_lds", &DvidOptions::bneck_lds, 0, 160 * 1024},
+    {"f32_split", &DvidOptions::f32_split, 0, 1},    {"bneck_lds", &DvidOptions::bneck_lds, 0, 160 * 1024},
 };
 }  // namespace
 
@@ -1845,13 +1871,17 @@ int dvid_roialign_v2_multilevel_f32(const float* p3, const float* p4, const floa
     return DVID_OK;
 }
 
-int dvid_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* residual, float* out, int n, int h, int wd, int cin,
-                         int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int residual_mode, void* stream) {
+int dvid_conv2d_nhwc_f32(const float* in, const float* w, const void* w_hi, const void* w_lo, const float* bias, const float* row_scale, const float* residual,
+                         float* out, int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int residual_mode,
+                         void* stream) {
     g_err[0] = 0;
     if (cin % 4 || kpad % 16 || kpad < kh * kw * cin || pad < 0) FAIL(DVID_ERR_ARG, "fp32 conv: cin %% 4 == 0, kpad %% 16 == 0, kpad >= kh*kw*cin, pad >= 0");
     ConvW cw;
     cw.w32 = const_cast<float*>(w);
+    cw.w16hi = reinterpret_cast<half_t*>(const_cast<void*>(w_hi));
+    cw.w16lo = reinterpret_cast<half_t*>(const_cast<void*>(w_lo));
     cw.bias = const_cast<float*>(bias);
+    cw.wscale32 = const_cast<float*>(row_scale);
     cw.cin32 = cin;
     cw.cin_real = cin;
     cw.cout = cout;

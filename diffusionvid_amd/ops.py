@@ -71,8 +71,10 @@ def conv2d_nhwc(x, w_packed, kpad, bias, cout, kh, kw, stride, pad, relu=False, 
 
 
 # ---- DTYPE float32 forms (csrc/f32.hip): fp32 NHWC activations, un-rounded weights, fp32 MFMA --------------------------------------
-def pack_conv_weight_f32(w):
-    """OIHW fp32 (or [out, in]) -> fp32 [cout, kpad], k = (ky*kw+kx)*cin4 + c with cin4 = cin rounded up to 4, kpad to 16 (zeros)."""
+def pack_conv_weight_f32(w, scale_rows=False):
+    """OIHW fp32 (or [out, in]) -> fp32 [cout, kpad], k = (ky*kw+kx)*cin4 + c with cin4 = cin rounded up to 4, kpad to 16 (zeros).
+    scale_rows: additionally multiply each row by the power of two that puts its largest magnitude in [0.5, 1) and return
+    (packed, kpad, row_scale) with row_scale = 2^-e for conv2d_nhwc_f32 (what csrc/model.hip: make_conv does for DTYPE float32)."""
     w = w.detach().float().cpu()
     if w.dim() == 2:
         w = w[:, :, None, None]
@@ -83,24 +85,36 @@ def pack_conv_weight_f32(w):
     packed[:, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
     out = torch.zeros((cout, kpad), dtype=torch.float32)
     out[:, :kh * kw * c4] = packed.reshape(cout, -1)
+    if scale_rows:
+        mx = out.abs().amax(dim=1)
+        e = torch.where(mx > 0, torch.frexp(mx)[1], torch.zeros_like(mx, dtype=torch.int32)).to(torch.float32)
+        return out * torch.exp2(-e)[:, None], kpad, torch.exp2(e)
     return out, kpad
 
 
-def conv2d_nhwc_f32(x, w_packed, kpad, bias, cout, kh, kw, stride, pad, relu=0, residual=None, residual_mode=0):
-    """x fp32 NHWC (channels a multiple of 4); returns fp32 NHWC.  relu: 0 none, 1 ReLU, 2 exact GELU."""
+def split_f16(w_packed):
+    """fp32 -> (hi, lo) fp16 planes, hi = fp16(w), lo = fp16(w - hi): the weight operand of the split-operand kernel (conv2d_nhwc_f32)"""
+    hi = w_packed.to(torch.float16)
+    return hi, (w_packed - hi.to(torch.float32)).to(torch.float16)
+
+
+def conv2d_nhwc_f32(x, w_packed, kpad, bias, cout, kh, kw, stride, pad, relu=0, residual=None, residual_mode=0, row_scale=None, w_split=None):
+    """x fp32 NHWC (channels a multiple of 4); returns fp32 NHWC.  relu: 0 none, 1 ReLU, 2 exact GELU; row_scale: see pack_conv_weight_f32;
+    w_split = split_f16(w_packed): run the products on split fp16 operands (library option f32_split, default on); None: the fp32 MFMA."""
     x = _cuda(x, torch.float32)
     n, h, wd, cin = x.shape
     ho = (h + 2 * pad - kh) // stride + 1
     wo = (wd + 2 * pad - kw) // stride + 1
     out = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
-    call("dvid_conv2d_nhwc_f32", ptr(x), ptr(w_packed), ptr(bias), ptr(residual), ptr(out), n, h, wd, cin, cout, kh, kw, stride, pad, kpad,
+    wh, wl = w_split if w_split is not None else (None, None)
+    call("dvid_conv2d_nhwc_f32", ptr(x), ptr(w_packed), ptr(wh), ptr(wl), ptr(bias), ptr(row_scale), ptr(residual), ptr(out), n, h, wd, cin, cout, kh, kw, stride, pad, kpad,
          int(relu), residual_mode, stream_ptr())
     return out
 
 
-def linear_f32(x, w_packed, kpad, bias, relu=0):
+def linear_f32(x, w_packed, kpad, bias, relu=0, row_scale=None, w_split=None):
     rows, k = x.shape
-    return conv2d_nhwc_f32(x.view(rows, 1, 1, k), w_packed, kpad, bias, w_packed.shape[0], 1, 1, 1, 0, relu=relu).view(rows, -1)
+    return conv2d_nhwc_f32(x.view(rows, 1, 1, k), w_packed, kpad, bias, w_packed.shape[0], 1, 1, 1, 0, relu=relu, row_scale=row_scale, w_split=w_split).view(rows, -1)
 
 
 def roialign_f32(feats_nhwc, boxes, height, width, want_mean=False):

@@ -144,12 +144,17 @@ int dvid_roialign_v2_multilevel(const void* p3, const void* p4, const void* p5, 
                                 int channels, const float* boxes, int boxes_per_frame, void* roi_out /* fp16 [R,49,C] */,
                                 float* mean_out /* [R,C] or NULL */, void* stream);
 /* The DTYPE float32 forms of the stand-alone ops (csrc/f32.hip): fp32 NHWC pyramids -> fp32 [R,49,C] tiles; fp32 conv / linear with
- * w [cout][kpad] fp32, k = (ky*kw+kx)*cin + c, cin % 4 == 0, kpad = round_up(kh*kw*cin, 16) zero-padded; fp32 attention (head dim 32,
- * head h at columns [32h, 32h+32)); fp32 DynamicConv (params [R][32768] = P1T[64][256] | P2T[256][64]). */
+ * w [cout][kpad] fp32, k = (ky*kw+kx)*cin + c, cin % 4 == 0, kpad = round_up(kh*kw*cin, 16) zero-padded, and row_scale [cout] (may be
+ * NULL): out channel n = act(acc_n * row_scale[n] + bias[n] + residual) -- the model packs each row times a power of two that puts its
+ * largest magnitude in [0.5, 1) and hands 2^-e here, which keeps the split-operand products at fp32 grade for small weights; w_hi / w_lo
+ * (fp16 [cout][kpad], may be NULL): w_hi = fp16(w), w_lo = fp16(w - w_hi) -- given, and with option f32_split = 1 (default), the products run
+ * as three fp16-MFMA passes over (hi, lo) operand pairs (the activations are split in the kernel); NULL, or f32_split = 0: fp32 MFMA; fp32 attention (head dim 32, head h at columns [32h, 32h+32)); fp32 DynamicConv (params [R][32768] = P1T[64][256] |
+ * P2T[256][64]). */
 int dvid_roialign_v2_multilevel_f32(const float* p3, const float* p4, const float* p5, int n_frames, int height, int width, int channels,
                                     const float* boxes, int boxes_per_frame, float* roi_out, float* mean_out, void* stream);
-int dvid_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* residual, float* out, int n, int h, int wd, int cin,
-                         int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int residual_mode, void* stream);
+int dvid_conv2d_nhwc_f32(const float* in, const float* w, const void* w_hi, const void* w_lo, const float* bias, const float* row_scale, const float* residual,
+                         float* out, int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int kpad, int relu, int residual_mode,
+                         void* stream);
 int dvid_mha_f32(const float* q, const float* k, const float* v, float* out, int batch, int lq, int lk, int nheads, int q_ld, int kv_ld, int out_ld,
                  int64_t q_bs, int64_t kv_bs, int64_t out_bs, void* stream);
 int dvid_dynconv_f32(const float* roi, const float* params, const float* g1, const float* b1, const float* g2, const float* b2, float* out,
@@ -224,7 +229,8 @@ int dvid_resize_u8_to_f32(const void* src_hwc, int h, int w, void* tmp, float* o
  * The library's behaviour switches are ONE table set through this ABI, never through the environment (csrc/options.h; the defaults
  * are the benchmarked configuration).  Names: conv3x3, wstat, bneck_fuse (0 off / 1 by the layer's shape rule / 2 wherever the layer
  * type fits), stem_pool, head_tail, ln_rows (0 / 1), igemm_cfg (-1 = tuner, >= 0 forced tile configuration), igemm_tune (-1 / 0 / 1, see
- * dvid_igemm_set_tuning), igemm_generic (0 / 1), bneck_lds (diagnostics).  Every choice gives the same values up to fp32 summation
+ * dvid_igemm_set_tuning), igemm_generic (0 / 1), f32_split (DTYPE float32 products: 1 = split fp16 operands on the fp16 MFMA, 0 = the fp32
+ * MFMA), bneck_lds (diagnostics).  Every choice gives the same values up to fp32 summation
  * order (most are bit-identical; the tests say which).  dvid_effective_config writes "name=value ..." of all options followed by the
  * environment variables the library still reads (DVID_IGEMM_TUNE, DVID_IGEMM_TUNE_CACHE, DVID_CHAINS, DVID_POISON_WORKSPACE) as they
  * are set; bench.py echoes it.  The dvid_igemm_set_* / dvid_set_stem_pool entry points below write the same table (-1 = the default). */

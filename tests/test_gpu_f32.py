@@ -44,7 +44,9 @@ def nhwc(x, pad_to=None):
     dict(n=1, h=9, w=11, cin=256, cout=30, k=1, stride=1, pad=0, relu=0, res=0),            # N tail (class_logits)
     dict(n=1, h=5, w=7, cin=64, cout=130, k=3, stride=1, pad=1, relu=2, res=0),             # exact GELU, N tail across two tiles
 ])
-def test_f32_conv(dv, cfg):
+@pytest.mark.parametrize("split", [1, 0])
+def test_f32_conv(dv, cfg, split):
+    """split = 1 (default): (hi, lo) fp16 operands, three passes of the fp16 MFMA; 0: exact fp32 products on the fp32 MFMA.  Same bound."""
     g = torch.Generator().manual_seed(1)
     n, h, w, cin, cout, k = cfg["n"], cfg["h"], cfg["w"], cfg["cin"], cfg["cout"], cfg["k"]
     x = torch.randn(n, cin, h, w, generator=g)
@@ -62,22 +64,36 @@ def test_f32_conv(dv, cfg):
         ref = F.relu(ref)
     elif cfg["relu"] == 2:
         ref = F.gelu(ref)
-    wp, kpad = dv.pack_conv_weight_f32(wt)
-    out = dv.conv2d_nhwc_f32(nhwc(x, (cin + 3) // 4 * 4), wp.cuda(), kpad, bias.cuda(), cout, k, k, cfg["stride"], cfg["pad"], relu=cfg["relu"],
-                             residual=nhwc(res) if res is not None else None, residual_mode=cfg["res"])
-    check(f"f32_conv{cfg}", out.permute(0, 3, 1, 2), ref.float(), 2e-5, 2e-5)
+    wp, kpad, rs = dv.pack_conv_weight_f32(wt, scale_rows=True)
+    ws = tuple(t.cuda() for t in dv.split_f16(wp))
+    dv.set_option("f32_split", split)
+    try:
+        out = dv.conv2d_nhwc_f32(nhwc(x, (cin + 3) // 4 * 4), wp.cuda(), kpad, bias.cuda(), cout, k, k, cfg["stride"], cfg["pad"], relu=cfg["relu"],
+                                 residual=nhwc(res) if res is not None else None, residual_mode=cfg["res"], row_scale=rs.cuda(), w_split=ws)
+    finally:
+        dv.reset_options()
+    check(f"f32_conv[split {split}]{cfg}", out.permute(0, 3, 1, 2), ref.float(), 2e-5, 2e-5)
 
 
 @pytest.mark.parametrize("rows,k,nout", [(600, 256, 768), (300, 256, 4), (257, 12544, 256), (600, 256, 32768), (1, 1024, 256)])
-def test_f32_linear(dv, rows, k, nout):
+@pytest.mark.parametrize("split", [1, 0])
+def test_f32_linear(dv, rows, k, nout, split):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(rows, k, generator=g)
     wt = torch.randn(nout, k, generator=g) / math.sqrt(k)
     bias = torch.randn(nout, generator=g)
     ref = F.linear(x.double(), wt.double(), bias.double()).float()
-    wp, kpad = dv.pack_conv_weight_f32(wt)
-    out = dv.linear_f32(x.cuda(), wp.cuda(), kpad, bias.cuda())
-    check(f"f32_linear[{rows}x{k}->{nout}]", out, ref, 2e-5, 2e-5)
+    wp, kpad, rs = dv.pack_conv_weight_f32(wt, scale_rows=True)
+    ws = tuple(t.cuda() for t in dv.split_f16(wp))
+    dv.set_option("f32_split", split)
+    try:
+        out = dv.linear_f32(x.cuda(), wp.cuda(), kpad, bias.cuda(), row_scale=rs.cuda(), w_split=ws)
+        # small values too: the split keeps an absolute 3e-8 per operand below |v| = 2^-3, so a tensor of 1e-3-sized activations still meets the bound
+        out_small = dv.linear_f32((x * 1e-3).cuda(), wp.cuda(), kpad, None, row_scale=rs.cuda(), w_split=ws)
+    finally:
+        dv.reset_options()
+    check(f"f32_linear[split {split}][{rows}x{k}->{nout}]", out, ref, 2e-5, 2e-5)
+    check(f"f32_linear[split {split}][{rows}x{k}->{nout}] x 1e-3", out_small, (ref - bias) * 1e-3, 1e-4, 1e-4)
 
 
 def test_f32_roialign(dv):

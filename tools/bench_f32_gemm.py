@@ -14,12 +14,13 @@ def run(n, h, w, cin, cout, k, stride, res, reps=5):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(n, h, w, cin, generator=g).cuda()
     wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
-    wp, kpad = ops.pack_conv_weight_f32(wt)
-    wp = wp.cuda()
+    wp, kpad, rs = ops.pack_conv_weight_f32(wt, scale_rows=True)
+    ws = tuple(t.cuda() for t in ops.split_f16(wp))
+    wp, rs = wp.cuda(), rs.cuda()
     bias = torch.zeros(cout).cuda()
     ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
     r = torch.randn(n, ho, wo, cout, generator=g).cuda() if res else None
-    f = lambda: ops.conv2d_nhwc_f32(x, wp, kpad, bias, cout, k, k, stride, k // 2, relu=1, residual=r, residual_mode=1 if res else 0)
+    f = lambda: ops.conv2d_nhwc_f32(x, wp, kpad, bias, cout, k, k, stride, k // 2, relu=1, residual=r, residual_mode=1 if res else 0, row_scale=rs, w_split=ws)
     f()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,6 +36,10 @@ def run(n, h, w, cin, cout, k, stride, res, reps=5):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 104
+    if len(sys.argv) > 2:          # library option f32_split: 1 = split fp16 operands (default), 0 = the fp32 MFMA
+        ops.set_option("f32_split", int(sys.argv[2]))
+        PEAK = 157.3
+    print("f32_split =", ops.get_option("f32_split"), "(fractions are of the 157.3 TFLOP/s fp32 MFMA peak either way)")
     for shape in [(152, 256, 64, 64, 1, 1, False), (152, 256, 64, 64, 3, 1, False), (152, 256, 64, 256, 1, 1, True), (152, 256, 256, 64, 1, 1, False),
                   (76, 128, 128, 128, 3, 1, False), (76, 128, 128, 512, 1, 1, True), (76, 128, 512, 128, 1, 1, False),
                   (38, 64, 1024, 256, 1, 1, False), (38, 64, 256, 256, 3, 1, False), (38, 64, 256, 1024, 1, 1, True),
