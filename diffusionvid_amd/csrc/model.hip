@@ -1001,48 +1001,71 @@ int backbone_resnet_f32(dvid_model* m, const float* const* frames, int n, int he
         mean[i] = m->cfg.pixel_mean[i] / 255.f;
         stdv[i] = m->cfg.pixel_std[i] / 255.f;
     }
-    float* img = m->img8.as<float>();
-    float* bx = m->bufX.as<float>();
-    float* by = m->bufY.as<float>();
-    float* t1 = m->bufT1.as<float>();
-    float* t2 = m->bufT2.as<float>();
-    float* sc = m->bufSC.as<float>();
-    float* stage_out[4] = {nullptr, m->c3.as<float>(), m->c4.as<float>(), m->c5.as<float>()};
-    TRY(dvid_f32_prep_images_launch(frames, img, n, height, width, mean, stdv, s));
-    int h = height, w = width;
-    TRY(conv_run32(m->stem, img, n, h, w, t1, 1, nullptr, 0, s, &h, &w));
-    TRY(prof_other("maxpool_f32", (long)n * h * w, 64, 9, 0.0, (double)n * h * w * 64 * 4.0 * 1.25, s,
-                   [&] { return dvid_f32_maxpool3x3s2_launch(t1, bx, n, h, w, 64, s); }));
-    h = (h + 2 - 3) / 2 + 1;
-    w = (w + 2 - 3) / 2 + 1;
-    float* cur = bx;
-    int sh[4], sw[4];
-    for (int st = 0; st < 4; ++st) {
-        const int nb = (int)m->blocks[st].size();
-        for (int b = 0; b < nb; ++b) {
-            const Block& blk = m->blocks[st][b];
-            int h2 = h, w2 = w;
-            TRY(conv_run32(blk.c1, cur, n, h, w, t1, 1, nullptr, 0, s));
-            TRY(conv_run32(blk.c2, t1, n, h, w, t2, 1, nullptr, 0, s, &h2, &w2));
-            const float* res = cur;
-            if (blk.has_sc) {
-                TRY(conv_run32(blk.sc, cur, n, h, w, sc, 0, nullptr, 0, s));
-                res = sc;
-            }
-            float* dst = (b == nb - 1 && stage_out[st]) ? stage_out[st] : (cur == bx ? by : bx);
-            TRY(conv_run32(blk.c3, t2, n, h2, w2, dst, 1, res, 1, s));
-            h = h2;
-            w = w2;
-            cur = dst;
-        }
-        sh[st] = h;
-        sw[st] = w;
+    // sub-batch chains on separate streams, as the fp16 backbone runs them (frames are independent; every chain works in its own slice of
+    // the workspace): the HBM-paced short-K layers of one chain run beside the operand-stream-paced 3x3 layers of the other
+    const int nchain = (m->nchain > 1 && n >= 16 * m->nchain) ? m->nchain : 1;
+    if (nchain > 1) {
+        TRY(m->ensure_streams());
+        HIP_TRY(hipEventRecord(m->ev_fork, s));
+        for (int c = 0; c < nchain; ++c) HIP_TRY(hipStreamWaitEvent(m->cs[c], m->ev_fork, 0));
     }
-    float* pout[3] = {p3, p4, p5};
-    for (int l = 2; l >= 0; --l) {
-        const float* res = (l < 2) ? m->lat[l + 1].as<float>() : nullptr;
-        TRY(conv_run32(m->lateral[l], stage_out[l + 1], n, sh[l + 1], sw[l + 1], m->lat[l].as<float>(), 0, res, res ? 2 : 0, s));
-        TRY(conv_run32(m->output[l], m->lat[l].as<float>(), n, sh[l + 1], sw[l + 1], pout[l], 0, nullptr, 0, s));
+    const int per = (n + nchain - 1) / nchain;
+    const size_t px = (size_t)height * width, px4 = px / 16;
+    for (int c = 0; c < nchain; ++c) {
+        const int f0 = c * per, nf = (f0 + per <= n) ? per : n - f0;
+        if (nf <= 0) continue;
+        hipStream_t cs = nchain > 1 ? m->cs[c] : s;
+        const size_t fo = (size_t)f0, big = fo * px4 * 256;
+        float* img = m->img8.as<float>() + fo * px * 4;
+        float* bx = m->bufX.as<float>() + big;
+        float* by = m->bufY.as<float>() + big;
+        float* t1 = m->bufT1.as<float>() + big;
+        float* t2 = m->bufT2.as<float>() + big;
+        float* sc = m->bufSC.as<float>() + big;
+        float* stage_out[4] = {nullptr, m->c3.as<float>() + fo * (px4 / 4) * 512, m->c4.as<float>() + fo * (px4 / 16) * 1024,
+                               m->c5.as<float>() + fo * (px4 / 64) * 2048};
+        float* lat[3];
+        for (int l = 0; l < 3; ++l) lat[l] = m->lat[l].as<float>() + fo * (px4 / (4 << (2 * l))) * 256;
+        TRY(dvid_f32_prep_images_launch(frames + f0, img, nf, height, width, mean, stdv, cs));
+        int h = height, w = width;
+        TRY(conv_run32(m->stem, img, nf, h, w, t1, 1, nullptr, 0, cs, &h, &w));
+        TRY(prof_other("maxpool_f32", (long)nf * h * w, 64, 9, 0.0, (double)nf * h * w * 64 * 4.0 * 1.25, cs,
+                       [&] { return dvid_f32_maxpool3x3s2_launch(t1, bx, nf, h, w, 64, cs); }));
+        h = (h + 2 - 3) / 2 + 1;
+        w = (w + 2 - 3) / 2 + 1;
+        float* cur = bx;
+        int sh[4], sw[4];
+        for (int st = 0; st < 4; ++st) {
+            const int nb = (int)m->blocks[st].size();
+            for (int b = 0; b < nb; ++b) {
+                const Block& blk = m->blocks[st][b];
+                int h2 = h, w2 = w;
+                TRY(conv_run32(blk.c1, cur, nf, h, w, t1, 1, nullptr, 0, cs));
+                TRY(conv_run32(blk.c2, t1, nf, h, w, t2, 1, nullptr, 0, cs, &h2, &w2));
+                const float* res = cur;
+                if (blk.has_sc) {
+                    TRY(conv_run32(blk.sc, cur, nf, h, w, sc, 0, nullptr, 0, cs));
+                    res = sc;
+                }
+                float* dst = (b == nb - 1 && stage_out[st]) ? stage_out[st] : (cur == bx ? by : bx);
+                TRY(conv_run32(blk.c3, t2, nf, h2, w2, dst, 1, res, 1, cs));
+                h = h2;
+                w = w2;
+                cur = dst;
+            }
+            sh[st] = h;
+            sw[st] = w;
+        }
+        float* pout[3] = {p3 + (size_t)f0 * sh[1] * sw[1] * 256, p4 + (size_t)f0 * sh[2] * sw[2] * 256, p5 + (size_t)f0 * sh[3] * sw[3] * 256};
+        for (int l = 2; l >= 0; --l) {
+            const float* res = (l < 2) ? lat[l + 1] : nullptr;
+            TRY(conv_run32(m->lateral[l], stage_out[l + 1], nf, sh[l + 1], sw[l + 1], lat[l], 0, res, res ? 2 : 0, cs));
+            TRY(conv_run32(m->output[l], lat[l], nf, sh[l + 1], sw[l + 1], pout[l], 0, nullptr, 0, cs));
+        }
+        if (nchain > 1) {
+            HIP_TRY(hipEventRecord(m->ev_join[c], cs));
+            HIP_TRY(hipStreamWaitEvent(s, m->ev_join[c], 0));
+        }
     }
     return DVID_OK;
 }
