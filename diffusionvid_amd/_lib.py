@@ -34,6 +34,7 @@ SIGNATURES = {
     "dvid_model_set_tensor": (c_int, [c_void_p, C.c_char_p, c_void_p, C.POINTER(c_int64), c_int]),
     "dvid_model_finalize": (c_int, [c_void_p]),
     "dvid_model_set_precision": (c_int, [c_void_p, c_int]),
+    "dvid_model_take_range_flag": (c_int, [c_void_p, C.POINTER(c_int), c_void_p]),
     "dvid_set_chains": (c_int, [c_void_p, c_int]),
     "dvid_set_stem_layout": (c_int, [c_void_p, c_int]),
     "dvid_workspace_reserve": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),

@@ -323,6 +323,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
     };
     auto split_store = [&](float4v v, bool ok, half_t* hi_row, half_t* lo_row) {
         if (!ok) v = (float4v){0.f, 0.f, 0.f, 0.f};
+        // an activation beyond the fp16 range would become inf here where fp32 arithmetic would not: reported, never silent (the model
+        // checks the flag at the batch's host synchronisation and raises; f32_split = 0 has no such limit)
+        if (p.range_flag && fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))) > 65504.f)
+            atomicOr(p.range_flag, 1);
         const half4 h = __builtin_convertvector(v, half4);                     // round to nearest even
         const float4v back = __builtin_convertvector(h, float4v);
         const half4 l = __builtin_convertvector(v - back, half4);              // v - back is exact in fp32

@@ -164,6 +164,7 @@ struct F32GemmParams {
     const half_t* w_hi;  // the same rows split for the split-operand kernel: w_hi = fp16(w), w_lo = fp16(w - w_hi) (null: the fp32-MFMA kernel runs)
     const half_t* w_lo;
     const float* bias;   // [Cout] or nullptr
+    int* range_flag;     // device int or nullptr: the split-operand kernel ORs 1 into it when an activation's magnitude exceeds the fp16 range (65504)
     const float* wscale; // [Cout] or nullptr: the accumulator of channel n is multiplied by wscale[n] (undoes a power-of-two scaling of the packed row)
     const float* res;    // fp32 residual, see res_mode
     float* out;          // [M][ldc]

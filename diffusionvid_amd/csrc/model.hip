@@ -223,6 +223,7 @@ struct ConvW {   // conv or linear weights in MFMA-operand layout
     int alg_k = 0;             // algorithmic K for the FLOP count when the packed layout carries structural zeros (0: kh*kw*cin_real)
     // DTYPE float32 (csrc/f32.hip): the same rows un-rounded, [cout][kpad32] fp32 with k = (ky*kw + kx)*cin32 + c, cin32 = cin rounded up to 4
     float* w32 = nullptr;
+    int* range_flag = nullptr;          // the model's f32_range_flag (null for stand-alone launches)
     half_t *w16hi = nullptr, *w16lo = nullptr;          // the scaled rows as fp16 (hi, lo) planes for the split-operand kernel (csrc/f32.hip)
     float* wscale32 = nullptr;          // [cout]: 2^-e of the power-of-two scaling that puts each packed row's largest magnitude in [0.5, 1) (exact; undone in the epilogue)
     int cin32 = 0, kpad32 = 0;
@@ -277,6 +278,7 @@ struct dvid_model {
     std::map<std::string, HostTensor> raw;
     bool finalized = false;
     std::atomic<unsigned long long> ws_gen{0};          // moves of this model's workspace buffers (DevBuf::ensure)
+    int* f32_range_flag = nullptr;                      // DTYPE float32, split operands: set by a kernel that met |activation| > 65504 (dvid_model_take_range_flag)
     int precision = 0;         // 0: fp16 storage / fp16 MFMA (DTYPE float16), 1: fp32 storage / fp32 MFMA (DTYPE float32); dvid_model_set_precision
     std::vector<void*> owned;  // device allocations of weights
 
@@ -402,6 +404,11 @@ int make_conv(dvid_model* m, const HostTensor& w, const std::vector<float>& scal
         }
         TRY(m->upload(hi.data(), hi.size() * sizeof(half_t), reinterpret_cast<void**>(&out->w16hi)));
         TRY(m->upload(lo.data(), lo.size() * sizeof(half_t), reinterpret_cast<void**>(&out->w16lo)));
+        if (!m->f32_range_flag) {
+            const int zero = 0;
+            TRY(m->upload(&zero, sizeof(int), reinterpret_cast<void**>(&m->f32_range_flag)));
+        }
+        out->range_flag = m->f32_range_flag;
         out->cin32 = c4;
         out->kpad32 = k32;
     }
@@ -686,6 +693,7 @@ int conv_run32(const ConvW& w, const float* in, int n, int h, int wd, float* out
     p.w = w.w32;
     p.w_hi = w.w16hi;
     p.w_lo = w.w16lo;
+    p.range_flag = w.range_flag;
     p.bias = w.bias;
     p.wscale = w.wscale32;
     p.res = res;
@@ -1382,6 +1390,20 @@ int dvid_effective_config(char* buf, int cap) {
     if (!out.empty()) out.pop_back();
     if ((int)out.size() + 1 > cap) FAIL(DVID_ERR_ARG, "buffer of %d bytes, need %d", cap, (int)out.size() + 1);
     memcpy(buf, out.c_str(), out.size() + 1);
+    return DVID_OK;
+}
+
+// DTYPE float32 with split operands: 1 if any launch since the last call staged an activation whose magnitude exceeds the fp16 range (its
+// products are then inf / NaN where fp32 arithmetic would be finite); reads 4 bytes from the device behind `stream` and clears the flag
+int dvid_model_take_range_flag(dvid_model* m, int* exceeded, void* stream) {
+    g_err[0] = 0;
+    if (!m || !exceeded) FAIL(DVID_ERR_ARG, "null argument");
+    *exceeded = 0;
+    if (!m->f32_range_flag) return DVID_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(exceeded, m->f32_range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*exceeded) HIP_TRY(hipMemsetAsync(m->f32_range_flag, 0, sizeof(int), s));
     return DVID_OK;
 }
 

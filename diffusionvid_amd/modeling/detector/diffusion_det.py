@@ -874,6 +874,9 @@ class DiffusionDet(nn.Module):
         counts = oc.tolist()                 # the one host sync of a batch (the caller moves results to CPU anyway)
         self.host_wait_s += time.perf_counter() - t0          # the host blocked on the GPU: its slack (bench.py reports it per rank)
         self.head.check_boxes_valid()
+        if self.dtype == "float32" and self._engine is not None and self._engine.take_range_flag():
+            raise ops._lib.DvidError("DTYPE float32: an activation exceeded the fp16 range (65504) of the split-operand products; the detections of this batch are "
+                                     "not valid.  ops.set_option('f32_split', 0) runs the same layers on the fp32 MFMA, which has no range limit")
         results = []
         for b, k in enumerate(counts):
             bl = (getattr(self, "_result_cls", None) or BoxList)(ob[b, :k], size_wh, mode="xyxy")

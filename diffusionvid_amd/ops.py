@@ -413,6 +413,15 @@ class Model:
         self.chains = -1                 # the library's default until set_chains
         self._kv_src = None
 
+    def take_range_flag(self):
+        """DTYPE float32 with split operands: True if a launch since the last call met an activation beyond the fp16 range (65504); synchronises
+        the current stream and clears the flag (include/dvid_hip.h: dvid_model_take_range_flag).  Always False for float16."""
+        if self.precision != "float32":
+            return False
+        v = C.c_int(0)
+        call("dvid_model_take_range_flag", self.handle, C.byref(v), stream_ptr())
+        return bool(v.value)
+
     def workspace_generation(self):
         """moves of this model's workspace buffers so far (include/dvid_hip.h: dvid_workspace_generation); a captured launch sequence is
         valid only while this stays what it was at capture time"""

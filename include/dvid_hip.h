@@ -83,6 +83,11 @@ int dvid_model_set_tensor(dvid_model* m, const char* name, const float* data, co
  * precision 1 = DTYPE float32 -- every weight and activation fp32, products on the fp32 MFMA (csrc/f32.hip; both backbones).  Feature maps handed to / taken from the stage functions below are fp16 NHWC in mode 0 and fp32 NHWC in
  * mode 1.  Must be called before dvid_model_finalize (the weights are packed for one precision); the default is 0. */
 int dvid_model_set_precision(dvid_model* m, int precision);
+/* precision 1 with library option f32_split = 1 (default) multiplies (hi, lo) fp16 pairs: an ACTIVATION whose magnitude exceeds the fp16 range
+ * (65504) cannot be split, and its products would be inf / NaN where fp32 arithmetic is finite.  Such a launch sets a device flag instead of
+ * failing silently; this call copies it to *exceeded (synchronising `stream`) and clears it.  The detector reads it at each batch's host
+ * synchronisation and raises, naming f32_split = 0 (the fp32 MFMA, no range limit) as the remedy.  Always 0 for precision 0. */
+int dvid_model_take_range_flag(dvid_model* m, int* exceeded, void* stream);
 /* fold FrozenBN, repack to MFMA operand layouts, upload.  Fails (DVID_ERR_STATE) naming the first
  * missing tensor. */
 int dvid_model_finalize(dvid_model* m);

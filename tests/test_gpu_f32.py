@@ -276,6 +276,33 @@ def test_f32_backbone_swin_small(dv):
     model.close()
 
 
+def test_f32_split_range_is_reported_not_silent(dv):
+    """The split-operand products (option f32_split = 1) cannot represent an activation beyond the fp16 range: such a launch sets the
+    model's range flag (dvid_model_take_range_flag), which the detector turns into an error at the batch's host synchronisation.  With
+    f32_split = 0 (the fp32 MFMA) the same input runs clean -- and gives finite results."""
+    sd, _ = _head_state()
+    g = torch.Generator().manual_seed(11)
+    n, M, H, W = 1, 300, 96, 160
+    feats = [nhwc(torch.randn(n, 256, H // s, W // s, generator=g)) for s in (8, 16, 32)]
+    boxes = _boxes(g, n, M, H, W).cuda()
+    pro = torch.randn(n * M, 256, generator=g).cuda()
+    t = torch.tensor([499], dtype=torch.long)
+    model = dv.Model(sd, res_blocks=(0, 0, 0, 0), precision="float32")
+    model.reserve(n, H, W, M)
+    model.rcnn_head(1, feats, H, W, boxes, pro, t)
+    assert model.take_range_flag() is False
+    big = pro * 1e6                                                   # in_proj's operand: |v| up to ~4e6 > 65504
+    model.rcnn_head(1, feats, H, W, boxes, big, t)
+    assert model.take_range_flag() is True and model.take_range_flag() is False          # reported once, then cleared
+    dv.set_option("f32_split", 0)
+    try:
+        gl, gb, go = model.rcnn_head(1, feats, H, W, boxes, big, t)
+        assert model.take_range_flag() is False and torch.isfinite(go).all() and torch.isfinite(gl).all()
+    finally:
+        dv.reset_options()
+    model.close()
+
+
 def test_unknown_precision_is_refused(dv):
     from diffusionvid_amd._lib import DvidError
     sd, _ = _head_state()
