@@ -40,7 +40,7 @@ with open(f"{out}/{tag}_kernel_stats_{suf}.txt", "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-fed --no-side-configs  (DVID_CHAINS=1; 5 videos of 304 frames:\n")
     o.write("# set-up, warm-up, timed step, chains=1 pass and instrumented pass)\n")
     o.write("total kernel time %.1f ms\n" % (tot / 1e6))
-    ig = [r for r in rows if "igemm2_kernel" in r["Name"] or "f32_igemm_kernel" in r["Name"] or "conv3x3_" in r["Name"] or "conv4x4_" in r["Name"] or "stem_pool" in r["Name"] or "wstat" in r["Name"] or "bneck" in r["Name"]]
+    ig = [r for r in rows if "igemm2_kernel" in r["Name"] or "f32_igemm_kernel" in r["Name"] or "f32x3_igemm_kernel" in r["Name"] or "conv3x3_" in r["Name"] or "conv4x4_" in r["Name"] or "stem_pool" in r["Name"] or "wstat" in r["Name"] or "bneck" in r["Name"]]
     igt = sum(float(r["TotalDurationNs"]) for r in ig); igc = sum(int(r["Calls"]) for r in ig)
     o.write("implicit-GEMM kernels (igemm2_kernel / f32_igemm_kernel, conv3x3_halo_kernel, conv3x3_c64_kernel, conv4x4_s2d / stem_pool_kernel, wstat_kernel, wstat2_kernel, bneck64 / bneck128_tail_kernel; all instantiations): calls %d total %.2f ms avg %.2f us  %.1f%%\n" % (igc, igt / 1e6, igt / igc / 1e3, 100 * igt / tot))
     for r in rows[:40]:
@@ -51,14 +51,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     s = n = 0.0
     for fn in fs:
         for r in csv.DictReader(open(fn)):
-            if ("igemm2_kernel" in r["Kernel_Name"] or "f32_igemm_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "conv4x4_" in r["Kernel_Name"] or "stem_pool" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck" in r["Kernel_Name"]) and r["Counter_Name"] == c:
+            if ("igemm2_kernel" in r["Kernel_Name"] or "f32_igemm_kernel" in r["Kernel_Name"] or "f32x3_igemm_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "conv4x4_" in r["Kernel_Name"] or "stem_pool" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck" in r["Kernel_Name"]) and r["Counter_Name"] == c:
                 s += float(r["Counter_Value"]); n += 1
     res[c] = (s, n)
 def per_kernel(c):
     s = n = 0.0
     for fn in glob.glob(f"/tmp/prof_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
-            if ("igemm2_kernel" in r["Kernel_Name"] or "f32_igemm_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "conv4x4_" in r["Kernel_Name"] or "stem_pool" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck" in r["Kernel_Name"]) and r["Counter_Name"] == c:
+            if ("igemm2_kernel" in r["Kernel_Name"] or "f32_igemm_kernel" in r["Kernel_Name"] or "f32x3_igemm_kernel" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "conv4x4_" in r["Kernel_Name"] or "stem_pool" in r["Kernel_Name"] or "wstat" in r["Kernel_Name"] or "bneck" in r["Kernel_Name"]) and r["Counter_Name"] == c:
                 s += float(r["Counter_Value"]); n += 1
     return s, n
 mb, _ = per_kernel("SQ_VALU_MFMA_BUSY_CYCLES")
