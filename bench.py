@@ -667,7 +667,8 @@ def main():
         top = None
         if rank == 0:
             import tempfile
-            cfg_tag = "%s_x%d%s%s" % (arch, sample_step, "" if lookahead > 1 else "_lookahead1", "_float32" if f32 else "")
+            cfg_tag = "%s_x%d%s%s" % (arch, sample_step, "" if lookahead > 1 else "_lookahead1",
+                                      ("_float32" if ops.get_option("f32_split") else "_float32_fp32mfma") if f32 else "")
             keep = os.environ.get("DVID_PROFILE_DUMP")
             if keep and "{cfg}" in keep:
                 path = keep.replace("{cfg}", cfg_tag)
@@ -685,7 +686,8 @@ def main():
                     os.unlink(path)
         lib.dvid_profile_reset()
         traffic = mfma_busy = stamp = None
-        key = (arch, sample_step, "float32") if f32 else (arch, sample_step) if lookahead > 1 else (arch, sample_step, "lookahead1")
+        key = ((arch, sample_step, "float32" if ops.get_option("f32_split") else "float32_fp32mfma") if f32          # (no PMC profile of the fp32-MFMA variant is committed)
+               else (arch, sample_step) if lookahead > 1 else (arch, sample_step, "lookahead1"))
         traffic_file = TRAFFIC_FILES.get(key, "")
         tpath = os.path.join(ROOT, "profiles", traffic_file)
         if traffic_file and os.path.exists(tpath):      # HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS configuration (cannot be collected in-process)
