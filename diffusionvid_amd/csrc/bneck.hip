@@ -73,7 +73,7 @@ constexpr int kBias = kW3 + 32768;             // four 1-KiB slots of floats: b2
 // as the neighbour: barriers alone are harmless, LDS traffic is not): ORDINARY LOADS AND LDS-DMA PIECES DO NOT RETIRE IN ISSUE ORDER
 // RELATIVE TO EACH OTHER.  Each kind does among itself, but when the LDS pipe is busy the pieces lag, younger ordinary loads retire first,
 // and a counted vmcnt that has ordinary loads among the pieces it counts lets a step start on weights that have not landed.  Both kernels
-// here now keep ordinary loads out of every counted wait (below); the full allocation stays as a margin (DVID_BNECK_LDS=<bytes>: diagnostics).
+// here now keep ordinary loads out of every counted wait (below); the full allocation stays as a margin (library option bneck_lds = <bytes>: diagnostics).
 constexpr int kBytes = 160 * 1024;
 
 struct BneckParams {

@@ -89,7 +89,7 @@ int igemm(const IgemmParams& p, hipStream_t s) {
     r.stride = p.stride;
     r.res_mode = p.res_mode;
     r.family = true;
-    // the kernel the shape rules of dvid_igemm_launch pick (a forced tile configuration / DVID_WSTAT=0 / DVID_CONV3X3_HALO=0 runs are labelled by the rule)
+    // the kernel the shape rules of dvid_igemm_launch pick (runs with a forced tile configuration or with the wstat / conv3x3 options off are labelled by the rule)
     r.kind = dvid_wstat_preferred(p) ? (p.res_mode == 1 ? "wstat2" : "wstat") : dvid_conv3x3_halo_preferred(p) ? (p.Cin == 16 ? "conv4x4_s2d" : p.Cout == 64 ? "conv3x3_c64" : "conv3x3_halo") : "igemm2";
     HIP_TRY(hipEventRecord(r.a, s));
     const int rc = dvid_igemm_launch(p, s);

@@ -76,6 +76,44 @@ def test_default_library_configuration_is_the_benchmarked_one():
     assert len(ALLOWED_ENV_SWITCHES) < 15
 
 
+def test_split_operand_arithmetic_bound():
+    """The arithmetic of the DTYPE float32 path's split-operand products (csrc/f32.hip: f32x3_igemm_kernel), restated in numpy -- no GPU: a value v is
+    carried as hi = fp16(v), lo = fp16(v - hi); a dot product is accumulated in fp32 from lo_a hi_b + hi_a lo_b + hi_a hi_b (each fp16 x fp16 product is
+    exact in fp32).  With the weight rows scaled by a power of two to a largest magnitude in [0.5, 1) (ops.pack_conv_weight_f32(scale_rows=True), what
+    make_conv does) the result is as close to the exact dot product as a plain fp32 evaluation is for O(1) activations, where an fp16-operand product
+    (the DTYPE float16 path's arithmetic) is three orders of magnitude away.  The stated limit of the scheme is visible too: an activation below 2^-3
+    carries its lo part as an fp16 subnormal (absolute 3e-8), so a tensor of UNIFORMLY 1e-3-sized activations is reproduced to ~1e-4 of the result's RMS
+    -- still 10 x closer than fp16 operands, no longer fp32 grade (no tensor of this path looks like that: LayerNorm-ed rows and post-ReLU maps have O(1)
+    leading entries; the end-to-end float32 gates measure what matters).
+    Also: the packing helpers reconstruct the weights (hi + lo within 2^-21 of the scaled row, scale exact)."""
+    from diffusionvid_amd import ops
+    rng = np.random.default_rng(0)
+    K, N, M = 2304, 64, 48
+    w = (rng.standard_normal((N, K)) * (2.0 / K) ** 0.5).astype(np.float32)
+    wp, kpad, rs = ops.pack_conv_weight_f32(torch.from_numpy(w), scale_rows=True)
+    hi, lo = ops.split_f16(wp)
+    assert kpad == K and wp.shape == (N, K)
+    mx = wp.abs().amax(1)
+    assert torch.all((mx >= 0.5) & (mx < 1.0)) and torch.equal(wp * rs[:, None], torch.from_numpy(w))          # power-of-two scaling: exact both ways
+    assert float(((hi.float() + lo.float()) - wp).abs().max()) <= 2.0 ** -21
+    whi, wlo = hi.float().numpy(), lo.float().numpy()
+    for scale in (1.0, 1e-3):
+        a = (rng.standard_normal((M, K)) * scale).astype(np.float32)
+        exact = a.astype(np.float64) @ w.astype(np.float64).T
+        f32 = a @ w.T
+        ahi = a.astype(np.float16).astype(np.float32)
+        alo = (a - ahi).astype(np.float16).astype(np.float32)
+        split = ((alo @ whi.T + ahi @ wlo.T) + ahi @ whi.T) * rs.numpy()[None, :]
+        f16 = ahi @ w.astype(np.float16).astype(np.float32).T
+        rms = np.sqrt((exact ** 2).mean())
+        e32, es, e16 = (np.abs(x - exact).max() / rms for x in (f32, split, f16))
+        if scale == 1.0:
+            assert es <= 4.0 * max(e32, 2e-7), (scale, es, e32)          # within a small factor of plain fp32's own rounding
+            assert e16 >= 300 * es, (scale, e16, es)                      # ... where fp16 operands are ~1e-3
+        else:
+            assert es <= 1.5e-4 and e16 >= 10 * es, (scale, es, e16)
+
+
 def test_product_path_fails_loudly_without_gpu():
     from diffusionvid_amd import _lib, ops
     if torch.cuda.is_available():
