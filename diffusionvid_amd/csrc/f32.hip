@@ -908,8 +908,30 @@ int dvid_f32_igemm_launch(const F32GemmParams& p0, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0) return DVID_OK;
     if (p.Cin % 4 || p.Kpad % F32_BK || p.K > p.Kpad || p.ldc < p.Cout) return DVID_ERR_ARG;
     if (p.res_mode == 2 && ((p.Ho | p.Wo) & 1)) return DVID_ERR_ARG;
-    p.tiles_m = ceil_div(p.M, F32_BM);
     const bool split = g_opt.f32_split != 0 && p.w_hi && p.w_lo;          // split (hi, lo) fp16 operands on the fp16 MFMA, or exact fp32 products on the fp32 MFMA
+    // short-K / wide-N 1x1 layers: the weight-stationary form of the same arithmetic (whole 32-row blocks; a ragged tail falls through
+    // to the tiled kernel below on the remaining rows -- same values either way)
+    if (split && g_opt.f32_wstat && p.M >= 32 && (g_opt.f32_wstat == 2 ? dvid_f32_wstat_supported(p) : dvid_f32_wstat_preferred(p))) {
+        const int m0 = p.M & ~31;
+        F32GemmParams q = p;
+        q.M = m0;
+        q.H = m0;          // (a 1x1 layer over contiguous rows: the row count is all the kernel reads of the geometry)
+        q.W = 1;
+        q.Ho = m0;
+        q.Wo = 1;
+        const int rc = dvid_f32_wstat_launch_rows32(q, s);
+        if (rc != DVID_OK) return rc;
+        if (p.M == m0) return DVID_OK;
+        p.in += (long)m0 * p.Cin;
+        p.out += (long)m0 * p.ldc;
+        if (p.res) p.res += (long)m0 * p.Cout;
+        p.M -= m0;
+        p.H = p.M;
+        p.W = 1;
+        p.Ho = p.M;
+        p.Wo = 1;
+    }
+    p.tiles_m = ceil_div(p.M, F32_BM);
     if (p.Cout <= 64) {
         p.tiles_n = ceil_div(p.Cout, 64);
         if (split) hipLaunchKernelGGL(f32x3_igemm_kernel<64>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);

@@ -174,6 +174,10 @@ struct F32GemmParams {
     int tiles_m, tiles_n;   // filled by the launcher
 };
 int dvid_f32_igemm_launch(const F32GemmParams& p, hipStream_t s);
+// csrc/f32_wstat.hip: the weight-stationary form of the split-operand kernel (bit-identical to it)
+bool dvid_f32_wstat_supported(const F32GemmParams& p);
+bool dvid_f32_wstat_preferred(const F32GemmParams& p);
+int dvid_f32_wstat_launch_rows32(const F32GemmParams& p, hipStream_t s);
 struct RoiLevels32 {
     const float* feat[3];
     int h[3], w[3];

@@ -96,6 +96,42 @@ def test_f32_linear(dv, rows, k, nout, split):
     check(f"f32_linear[split {split}][{rows}x{k}->{nout}] x 1e-3", out_small, (ref - bias) * 1e-3, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("rows,k,nout,relu,res", [
+    (2400 + 17, 256, 1024, 1, 1),          # res4 conv3 + residual + ReLU; ragged tail of 17 rows on the tiled kernel
+    (4096, 128, 512, 1, 1),                # res3 conv3
+    (2400, 256, 32768, 0, 0),              # dynamic_layer: 128 slabs, every workgroup walks four
+    (1504, 256, 2048, 1, 0),               # linear1
+    (3200, 128, 512, 2, 0),                # Swin fc1: exact GELU
+    (2080, 256, 768, 0, 0),                # three slabs (Swin qkv): 30 of an XCD's 32 workgroups work
+    (32, 256, 256, 0, 1),                  # one row block: 255 workgroups have nothing to do
+])
+def test_f32_wstat_matches_tiled(dv, rows, k, nout, relu, res):
+    """csrc/f32_wstat.hip (weight-stationary split-operand kernel) against csrc/f32.hip's tiled split-operand kernel: the same split, the
+    same three products per K step in the same order, the same epilogue arithmetic -- bit for bit (and both inside the fp32 bound)."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(rows, k, generator=g)
+    wt = torch.randn(nout, k, generator=g) / math.sqrt(k)
+    bias = torch.randn(nout, generator=g)
+    resid = torch.randn(rows, nout, generator=g) if res else None
+    ref = F.linear(x.double(), wt.double(), bias.double())
+    if res:
+        ref = ref + resid.double()
+    ref = F.relu(ref) if relu == 1 else F.gelu(ref) if relu == 2 else ref
+    wp, kpad, rs = dv.pack_conv_weight_f32(wt, scale_rows=True)
+    ws = tuple(t.cuda() for t in dv.split_f16(wp))
+    outs = {}
+    for mode in (0, 2):
+        dv.set_option("f32_wstat", mode)
+        try:
+            outs[mode] = dv.conv2d_nhwc_f32(x.view(rows, 1, 1, k).cuda(), wp.cuda(), kpad, bias.cuda(), nout, 1, 1, 1, 0, relu=relu,
+                                            residual=resid.view(rows, 1, 1, nout).cuda() if res else None, residual_mode=res, row_scale=rs.cuda(),
+                                            w_split=ws).view(rows, nout)
+        finally:
+            dv.reset_options()
+    check(f"f32_wstat[{rows}x{k}->{nout}]", outs[2], ref.float(), 2e-5, 2e-5)
+    assert torch.equal(outs[0], outs[2]), f"weight-stationary and tiled kernels differ: max |d| {(outs[0] - outs[2]).abs().max().item():.3e}"
+
+
 def test_f32_roialign(dv):
     """zero-area, oversize and edge boxes, all three levels; against oracle/roi_align.py on the same fp32 maps"""
     g = torch.Generator().manual_seed(4)

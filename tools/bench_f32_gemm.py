@@ -39,7 +39,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 2:          # library option f32_split: 1 = split fp16 operands (default), 0 = the fp32 MFMA
         ops.set_option("f32_split", int(sys.argv[2]))
         PEAK = 157.3
-    print("f32_split =", ops.get_option("f32_split"), "(fractions are of the 157.3 TFLOP/s fp32 MFMA peak either way)")
+    if len(sys.argv) > 3:          # library option f32_wstat: 1 = weight-stationary kernel by its shape rule (default), 0 = tiled kernel everywhere
+        ops.set_option("f32_wstat", int(sys.argv[3]))
+    print("f32_split =", ops.get_option("f32_split"), "f32_wstat =", ops.get_option("f32_wstat"), "(fractions are of the 157.3 TFLOP/s fp32 MFMA peak either way)")
     for shape in [(152, 256, 64, 64, 1, 1, False), (152, 256, 64, 64, 3, 1, False), (152, 256, 64, 256, 1, 1, True), (152, 256, 256, 64, 1, 1, False),
                   (76, 128, 128, 128, 3, 1, False), (76, 128, 128, 512, 1, 1, True), (76, 128, 512, 128, 1, 1, False),
                   (38, 64, 1024, 256, 1, 1, False), (38, 64, 256, 256, 3, 1, False), (38, 64, 256, 1024, 1, 1, True),
