@@ -900,6 +900,211 @@ __global__ __launch_bounds__(256) void f32_dynconv_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same per-box pipeline with SPLIT operands (library option f32_split = 1, the default): both products run as three passes of the
+// fp16 MFMA on (hi, lo) halves of the fp32 values -- the arithmetic of f32x3_igemm_kernel: lo_a hi_b + hi_a lo_b + hi_a hi_b, fp32
+// accumulation -- instead of 256 fp32-MFMA instructions of 64 cycles per wave and box.  Each wave splits the fragments it multiplies, in
+// registers, straight from the global loads; product 1 is split over K across the four waves (see the kernel), its partial sums and
+// F1 cross LDS as fp32 for the LayerNorm statistics, and F1 comes back as two fp16 planes (rows of 64 halves at a pitch of 72:
+// conflict-free ds_read_b128 fragments) over the same bytes.
+// LayerNorm / ReLU arithmetic is the fp32 kernel's.  |value| > 65504 in the RoI tile or the parameters sets `range_flag`.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int DX_PH = 72;          // halves per F1 plane row
+__device__ __forceinline__ void split8(const float4v v0, const float4v v1, half8& h, half8& l, float& mx) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(__builtin_fabsf(v0[e]), __builtin_fabsf(v1[e])));
+    const half4 h0 = __builtin_convertvector(v0, half4), h1 = __builtin_convertvector(v1, half4);          // round to nearest even
+    const half4 l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, float4v), half4);            // v - hi is exact in fp32
+    const half4 l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, float4v), half4);
+    h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ float16v mfma_x3(const half8 ah, const half8 al, const half8 bh, const half8 bl, float16v acc) {
+    // the two small terms first, then the leading one: f32x3_igemm_kernel's order
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void f32x3_dynconv_kernel(const float* __restrict__ roi, const float* __restrict__ params,
+                                                             const float* __restrict__ g1, const float* __restrict__ b1,
+                                                             const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ out,
+                                                             int nbox, int* __restrict__ range_flag) {
+#pragma clang fp contract(off)
+    // LDS: product 1's four K-quarter partial sums [4][64][68] fp32 (69632 bytes); afterwards the same bytes hold F1 as two fp16 planes
+    // (18432) and, behind them, F2 [49][260] fp32
+    constexpr int PART = 64 * DC_P1;                      // floats per partial
+    constexpr int F1_BYTES = 2 * 64 * DX_PH * 2;
+    constexpr int LDS_BYTES = 4 * PART * 4 > F1_BYTES + 49 * DC_P2 * 4 ? 4 * PART * 4 : F1_BYTES + 49 * DC_P2 * 4;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    float* const P = reinterpret_cast<float*>(lds);
+    half_t* const F1h = reinterpret_cast<half_t*>(lds);
+    half_t* const F1l = F1h + 64 * DX_PH;
+    float* const F2 = reinterpret_cast<float*>(lds + F1_BYTES);
+    const int box = igemm_xcd_remap((int)blockIdx.x, nbox);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = (lane >> 5) * 8;          // fp16 MFMA operand map: lane l = row l & 31, k = 8 (l >> 5) .. + 8 of a 16-deep step
+    const float* x = roi + (long)box * 49 * 256;
+    const float* p1 = params + (long)box * 32768;
+    const float* p2 = p1 + 64 * 256;
+    float mx = 0.f;
+
+    // ---- product 1, split over K: wave w multiplies k in [64 w, 64 w + 64) for the whole 64 x 64 result.  Every RoI / parameter value is
+    // loaded by exactly one lane, and ALL of a box's 114 KB of first-product operands are requested before the first one is used (the
+    // (row block, column block) split of the fp32 kernel double-buffers 64-deep chunks: ~32 KB in flight per workgroup, which is what
+    // paced it -- 2.4-2.6 TB/s with either MFMA).
+    float16v acc[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+    {
+        float4v a[2][4][2], b[2][4][2];
+        const bool pok = 32 + fr < 49;          // row block 1 holds rows 32..48
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 64 * wave + 16 * ks + fk + 4 * h;
+                a[0][ks][h] = *reinterpret_cast<const float4v*>(x + (long)fr * 256 + k);
+                a[1][ks][h] = pok ? *reinterpret_cast<const float4v*>(x + (long)(32 + fr) * 256 + k) : (float4v){0.f, 0.f, 0.f, 0.f};
+                b[0][ks][h] = *reinterpret_cast<const float4v*>(p1 + (long)fr * 256 + k);
+                b[1][ks][h] = *reinterpret_cast<const float4v*>(p1 + (long)(32 + fr) * 256 + k);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                split8(a[i][ks][0], a[i][ks][1], ah[i], al[i], mx);
+                split8(b[i][ks][0], b[i][ks][1], bh[i], bl[i], mx);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma_x3(ah[mb], al[mb], bh[nb], bl[nb], acc[mb][nb]);
+        }
+    }
+    // the second product's parameter fragments (raw fp32; wave w owns columns [64 w, 64 w + 64)): requested now, they land under the
+    // reduction and the LayerNorm below
+    float4v w2[2][4][2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float* q = p2 + (long)((wave * 2 + nb) * 32 + fr) * 64 + ks * 16 + fk;
+            w2[nb][ks][0] = *reinterpret_cast<const float4v*>(q);
+            w2[nb][ks][1] = *reinterpret_cast<const float4v*>(q + 4);
+        }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                P[wave * PART + (mb * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3)) * DC_P1 + nb * 32 + fr] = acc[mb][nb][r];
+    __syncthreads();
+    // ---- the four partial sums in a fixed order, LayerNorm(64) + ReLU on rows 0..48: four lanes per row, 16 values each; the result goes
+    // back as (hi, lo) planes, rows 49..63 zero
+    {
+        const int row = tid >> 2, part = tid & 3;
+        float vals[16];
+        if (row < 49) {
+            const float* rp = &P[row * DC_P1 + part * 16];
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                vals[e] = (rp[e] + rp[PART + e]) + (rp[2 * PART + e] + rp[3 * PART + e]);
+                sum += vals[e];
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            const float mean = sum / 64.f;
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float t = vals[e] - mean;
+                sq += t * t;
+            }
+            sq += __shfl_xor(sq, 1, 64);
+            sq += __shfl_xor(sq, 2, 64);
+            const float rstd = rsqrtf(sq / 64.f + 1e-5f);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vals[e] = fmaxf((vals[e] - mean) * rstd * g1[part * 16 + e] + b1[part * 16 + e], 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vals[e] = 0.f;
+        }
+        __syncthreads();          // every partial sum has been read
+        float unused = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            half8 vh, vl;
+            split8((float4v){vals[8 * h], vals[8 * h + 1], vals[8 * h + 2], vals[8 * h + 3]},
+                   (float4v){vals[8 * h + 4], vals[8 * h + 5], vals[8 * h + 6], vals[8 * h + 7]}, vh, vl, unused);
+            *reinterpret_cast<half8*>(F1h + row * DX_PH + part * 16 + 8 * h) = vh;
+            *reinterpret_cast<half8*>(F1l + row * DX_PH + part * 16 + 8 * h) = vl;
+        }
+    }
+    __syncthreads();
+    // ---- product 2: wave w owns columns [64 w, 64 w + 64) of the 64 x 256 result, K = 64
+    {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                ah[mb] = *reinterpret_cast<const half8*>(F1h + (mb * 32 + fr) * DX_PH + ks * 16 + fk);
+                al[mb] = *reinterpret_cast<const half8*>(F1l + (mb * 32 + fr) * DX_PH + ks * 16 + fk);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) split8(w2[nb][ks][0], w2[nb][ks][1], bh[nb], bl[nb], mx);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma_x3(ah[mb], al[mb], bh[nb], bl[nb], acc[mb][nb]);
+        }
+        // (F2 lies behind the planes: no wave's fragment reads are disturbed by another wave's results)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mb * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                    if (row < 49) F2[row * DC_P2 + (wave * 2 + nb) * 32 + fr] = acc[mb][nb][r];
+                }
+    }
+    if (range_flag && mx > 65504.f) atomicOr(range_flag, 1);          // reported, never a silent inf (f32_split = 0 has no such limit)
+    __syncthreads();
+    // ---- LayerNorm(256) + ReLU, one wave per row, 4 values per lane; rows go straight to global
+    const float4v gg = *reinterpret_cast<const float4v*>(g2 + lane * 4);
+    const float4v bb = *reinterpret_cast<const float4v*>(b2 + lane * 4);
+    for (int row = wave; row < 49; row += 4) {
+        const float4v t = *reinterpret_cast<const float4v*>(&F2[row * DC_P2 + lane * 4]);
+        const float mean = wave_sum(t[0] + t[1] + t[2] + t[3]) / 256.f;
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = t[e] - mean;
+            sq += u * u;
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / 256.f + 1e-5f);
+        float4v o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf((t[e] - mean) * rstd * gg[e] + bb[e], 0.f);
+        *reinterpret_cast<float4v*>(out + ((long)box * 49 + row) * 256 + lane * 4) = o;
+    }
+}
+
 }  // namespace
 
 // =================================================================================================================================
@@ -1019,9 +1224,10 @@ int dvid_f32_swin_window_attn_launch(const float* qkv, const float* qkv_bias, co
 }
 
 int dvid_f32_dynconv_launch(const float* roi, const float* params, const float* g1, const float* b1, const float* g2, const float* b2,
-                            float* out, int rows, hipStream_t s) {
+                            float* out, int rows, int* range_flag, hipStream_t s) {
     if (rows <= 0) return DVID_OK;
-    hipLaunchKernelGGL(f32_dynconv_kernel, dim3(rows), dim3(256), 0, s, roi, params, g1, b1, g2, b2, out, rows);
+    if (g_opt.f32_split != 0) hipLaunchKernelGGL(f32x3_dynconv_kernel, dim3(rows), dim3(256), 0, s, roi, params, g1, b1, g2, b2, out, rows, range_flag);
+    else hipLaunchKernelGGL(f32_dynconv_kernel, dim3(rows), dim3(256), 0, s, roi, params, g1, b1, g2, b2, out, rows);
     LAUNCH_CHECK();
     return DVID_OK;
 }

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int n
     const int frag_key = lrow & 15;
     const int frag_row_off = lrow * (K * 2);
 
+    float range_max = 0.f;
     float4v ra[CPT][2];
     auto fetch = [&](int t) {
 #pragma unroll
@@ -95,12 +96,8 @@ __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int n
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const float4v v0 = ra[i][0], v1 = ra[i][1];
-            if (p.range_flag) {
-                float mx = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(__builtin_fabsf(v0[e]), __builtin_fabsf(v1[e])));
-                if (mx > 65504.f) atomicOr(p.range_flag, 1);          // as f32x3_igemm_kernel: reported, never a silent inf
-            }
+            for (int e = 0; e < 4; ++e) range_max = fmaxf(range_max, fmaxf(__builtin_fabsf(v0[e]), __builtin_fabsf(v1[e])));
             const half4 h0 = __builtin_convertvector(v0, half4), h1 = __builtin_convertvector(v1, half4);          // round to nearest even
             const half4 l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, float4v), half4);            // v - hi is exact in fp32
             const half4 l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, float4v), half4);
@@ -135,34 +132,46 @@ __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int n
         split_to(0);
         __syncthreads();
 
-        for (int t = 0; t < T; ++t) {
-            const bool more = t + 1 < T;          // workgroup-uniform
-            if (more) fetch(t + 1);               // in flight under this tile's MFMAs
-            float4v rr[2][2];
+        float16v acc;
+        float4v rr[2][2];
+        auto load_res = [&](int t) {
             if (HAS_RES) {
+                const float* r = r_src + (long)t * 32 * p.Cout;
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    rr[g][0] = *reinterpret_cast<const float4v*>(r_src + 16 * g);
-                    rr[g][1] = *reinterpret_cast<const float4v*>(r_src + 16 * g + 4);
+                    rr[g][0] = *reinterpret_cast<const float4v*>(r + 16 * g);
+                    rr[g][1] = *reinterpret_cast<const float4v*>(r + 16 * g + 4);
                 }
-                r_src += (long)32 * p.Cout;
             }
+        };
+        auto products = [&](int t) {
             const char* const stg = smem + (t & 1) * STAGE;
-            float16v acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // the fragments of K step ks + 1 are requested before the three products of step ks (left to itself the compiler reads each
+            // fragment right in front of its first use -- `ds_read; s_waitcnt lgkmcnt(0); v_mfma` sixteen times per tile)
+            half8 ah[2], al[2];
+            auto frag = [&](int ks) {
+                const int off = frag_row_off + (((2 * ks + hi) ^ frag_key) * 16);
+                ah[ks & 1] = *reinterpret_cast<const half8*>(stg + off);
+                al[ks & 1] = *reinterpret_cast<const half8*>(stg + PLANE + off);
+            };
+            frag(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int off = frag_row_off + (((2 * ks + hi) ^ frag_key) * 16);
-                const half8 ah = *reinterpret_cast<const half8*>(stg + off);
-                const half8 al = *reinterpret_cast<const half8*>(stg + PLANE + off);
+                if (ks + 1 < KS) frag(ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
                 // the two small terms first, then the leading one: f32x3_igemm_kernel's order
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], al, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], ah, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], ah, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], al[ks & 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], ah[ks & 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], ah[ks & 1], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // epilogue from the accumulator layout.  acc[4 r4 + r] = channel 8 r4 + 4 hi + r of row lane % 32; one half-wave exchange per
-            // register pair (r4, r4 + 1) leaves lane < 32 with channels 16 g + [0, 8) and lane >= 32 with 16 g + 8 + [0, 8)
+        };
+        // epilogue from the accumulator layout.  acc[4 r4 + r] = channel 8 r4 + 4 hi + r of row lane % 32; one half-wave exchange per
+        // register pair (r4, r4 + 1) leaves lane < 32 with channels 16 g + [0, 8) and lane >= 32 with 16 g + 8 + [0, 8)
+        auto finish = [&](int t) {
+            float* const o = o_dst + (long)t * 32 * p.ldc;
             unsigned int u[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -196,14 +205,27 @@ __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int n
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                     }
-                    *reinterpret_cast<float4v*>(o_dst + 16 * g + 4 * h) = v;
+                    *reinterpret_cast<float4v*>(o + 16 * g + 4 * h) = v;
                 }
             }
-            o_dst += (long)32 * p.ldc;
+        };
+
+        // (Running the two waves of a SIMD in opposite phase -- waves 4-7 finish tile t - 1 while waves 0-3 multiply tile t, and vice
+        // versa -- was built and measured: 0-4 % on these shapes, and the half-step loop it needs costs the straight-line loop below
+        // 20 % on res4 conv3: profiles/r06v_f32_wstat_antiphase.txt.  Not kept.)
+        for (int t = 0; t < T; ++t) {
+            const bool more = t + 1 < T;          // workgroup-uniform
+            if (more) fetch(t + 1);               // in flight under this tile's MFMAs
+            load_res(t);
+            products(t);
+            finish(t);
             if (more) split_to((t + 1) & 1);
             __syncthreads();                      // tile t + 1 visible; nobody reads tile t any more
         }
     }
+    // an activation beyond the fp16 range became inf in its hi part where fp32 arithmetic would not: reported, never silent (as
+    // f32x3_igemm_kernel; one test per thread and launch instead of one per chunk)
+    if (p.range_flag && range_max > 65504.f) atomicOr(p.range_flag, 1);
 }
 
 template <int K, bool HAS_RES, int ACT>

@@ -197,6 +197,7 @@ int dvid_f32_mha_launch(const float* q, const float* k, const float* v, float* o
 // padded window position), relbias [nheads][49][SWIN_RELBIAS_PITCH], out [B*H*W][C]
 int dvid_f32_swin_window_attn_launch(const float* qkv, const float* qkv_bias, const float* relbias, float* out, int batch, int H, int W, int C,
                                      int nheads, int shift, hipStream_t s);
-// roi [R][49][256], params [R][32768] as P1T[64][256] | P2T[256][64], out [R][49][256]
+// roi [R][49][256], params [R][32768] as P1T[64][256] | P2T[256][64], out [R][49][256]; range_flag (device int or null): the split-operand
+// form ORs 1 into it when a RoI / parameter magnitude exceeds the fp16 range
 int dvid_f32_dynconv_launch(const float* roi, const float* params, const float* g1, const float* b1, const float* g2, const float* b2,
-                            float* out, int rows, hipStream_t s);
+                            float* out, int rows, int* range_flag, hipStream_t s);

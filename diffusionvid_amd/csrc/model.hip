@@ -962,7 +962,7 @@ int rcnn_head_chain_f32(dvid_model* m, const HeadW& hw, int is_cond, const void*
     // --- DynamicConv (box_head.py:687-711)
     TRY(linear_run32(hw.dynamic_layer, x1, R, params, 0, s));
     TRY(prof_other("dynconv_f32", R, d, dd, 2.0 * R * 49.0 * d * dd * 2.0, (double)R * (2.0 * 49 * d * 4.0 + 2.0 * d * dd * 4.0), s,
-                   [&] { return dvid_f32_dynconv_launch(roi, params, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn, R, s); }));
+                   [&] { return dvid_f32_dynconv_launch(roi, params, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn, R, m->f32_range_flag, s); }));
     TRY(linear_run32(hw.out_layer, dyn, R, f32b, 0, s));
     TRY(dvid_add_layernorm_launch(f32b, nullptr, hw.dc_norm3.g, hw.dc_norm3.b, f32b, nullptr, R, d, 1, s));
     float* obj = f32d;
@@ -1950,7 +1950,7 @@ int dvid_mha_f32(const float* q, const float* k, const float* v, float* out, int
 int dvid_dynconv_f32(const float* roi, const float* params, const float* g1, const float* b1, const float* g2, const float* b2, float* out,
                      int rows, void* stream) {
     g_err[0] = 0;
-    TRY(dvid_f32_dynconv_launch(roi, params, g1, b1, g2, b2, out, rows, reinterpret_cast<hipStream_t>(stream)));
+    TRY(dvid_f32_dynconv_launch(roi, params, g1, b1, g2, b2, out, rows, nullptr, reinterpret_cast<hipStream_t>(stream)));
     return DVID_OK;
 }
 

@@ -161,8 +161,10 @@ def _head_state(seed=0):
     return sd, {k: v.float() for k, v in sd.items()}
 
 
-def test_f32_dynconv(dv):
-    """box_head.py:687-711 up to (not including) out_layer, on un-rounded parameters"""
+@pytest.mark.parametrize("split", [1, 0])
+def test_f32_dynconv(dv, split):
+    """box_head.py:687-711 up to (not including) out_layer, on un-rounded parameters.  split = 1 (default): both per-box products on split
+    (hi, lo) fp16 operands (f32x3_dynconv_kernel); 0: on the fp32 MFMA.  Same bound."""
     sd, _ = _head_state()
     g = torch.Generator().manual_seed(6)
     R, d, dd = 77, 256, 64
@@ -176,8 +178,12 @@ def test_f32_dynconv(dv):
     f = torch.bmm(f, p2.double())
     ref = F.relu(F.layer_norm(f, (d,), sd[pfx + ".norm2.weight"].double(), sd[pfx + ".norm2.bias"].double())).float()
     packed = torch.cat([p1.transpose(1, 2).reshape(R, -1), p2.transpose(1, 2).reshape(R, -1)], dim=1).contiguous()      # P1T | P2T (model.hip: make_head)
-    out = dv.dynconv_f32(roi.cuda(), packed.cuda(), *(sd[pfx + k].cuda() for k in (".norm1.weight", ".norm1.bias", ".norm2.weight", ".norm2.bias")))
-    check("f32_dynconv", out, ref, 3e-5, 3e-5)
+    dv.set_option("f32_split", split)
+    try:
+        out = dv.dynconv_f32(roi.cuda(), packed.cuda(), *(sd[pfx + k].cuda() for k in (".norm1.weight", ".norm1.bias", ".norm2.weight", ".norm2.bias")))
+    finally:
+        dv.reset_options()
+    check(f"f32_dynconv[split {split}]", out, ref, 3e-5, 3e-5)
 
 
 @pytest.mark.parametrize("cond", [False, True])
