@@ -1114,6 +1114,8 @@ int dvid_f32_igemm_launch(const F32GemmParams& p0, hipStream_t s) {
     if (p.Cin % 4 || p.Kpad % F32_BK || p.K > p.Kpad || p.ldc < p.Cout) return DVID_ERR_ARG;
     if (p.res_mode == 2 && ((p.Ho | p.Wo) & 1)) return DVID_ERR_ARG;
     const bool split = g_opt.f32_split != 0 && p.w_hi && p.w_lo;          // split (hi, lo) fp16 operands on the fp16 MFMA, or exact fp32 products on the fp32 MFMA
+    // 3x3 / stride-1 layers: the halo staged and split once per channel chunk (csrc/f32_conv3x3.hip)
+    if (split && g_opt.f32_conv3x3 && dvid_f32_conv3x3_supported(p)) return dvid_f32_conv3x3_launch(p, s);
     // short-K / wide-N 1x1 layers: the weight-stationary form of the same arithmetic (whole 32-row blocks; a ragged tail falls through
     // to the tiled kernel below on the remaining rows -- same values either way)
     if (split && g_opt.f32_wstat && p.M >= 32 && (g_opt.f32_wstat == 2 ? dvid_f32_wstat_supported(p) : dvid_f32_wstat_preferred(p))) {

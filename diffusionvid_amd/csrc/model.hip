@@ -1344,7 +1344,8 @@ const OptEntry kOptions[] = {
     {"conv3x3", &DvidOptions::conv3x3, 0, 2},       {"wstat", &DvidOptions::wstat, 0, 2},           {"bneck_fuse", &DvidOptions::bneck_fuse, 0, 2},
     {"stem_pool", &DvidOptions::stem_pool, 0, 1},   {"head_tail", &DvidOptions::head_tail, 0, 1},   {"ln_rows", &DvidOptions::ln_rows, 0, 1},
     {"igemm_cfg", &DvidOptions::igemm_cfg, -1, 255}, {"igemm_tune", &DvidOptions::igemm_tune, -1, 1}, {"igemm_generic", &DvidOptions::igemm_generic, 0, 1},
-    {"f32_split", &DvidOptions::f32_split, 0, 1},    {"f32_wstat", &DvidOptions::f32_wstat, 0, 2},    {"bneck_lds", &DvidOptions::bneck_lds, 0, 160 * 1024},
+    {"f32_split", &DvidOptions::f32_split, 0, 1},    {"f32_wstat", &DvidOptions::f32_wstat, 0, 2},    {"f32_conv3x3", &DvidOptions::f32_conv3x3, 0, 1},
+    {"bneck_lds", &DvidOptions::bneck_lds, 0, 160 * 1024},
 };
 }  // namespace
 

@@ -18,6 +18,7 @@ struct DvidOptions {
     int igemm_generic = 0;   // 1 = igemm2's general addressing + general epilogue (the specialised paths are compared with it bit for bit)
     int f32_split = 1;       // DTYPE float32 products: 1 = split (hi, lo) fp16 operands, three fp16-MFMA passes (csrc/f32.hip: f32x3_igemm_kernel); 0 = exact fp32 products on the fp32 MFMA
     int f32_wstat = 1;       // DTYPE float32, split operands: short-K / wide-N 1x1 layers on the weight-stationary kernel (csrc/f32_wstat.hip); 1 = by the shape rule, 2 = wherever it fits, 0 = off
+    int f32_conv3x3 = 1;     // DTYPE float32, split operands: 3x3 / stride-1 layers on the halo-staged kernel (csrc/f32_conv3x3.hip); 0 = the tiled kernel
     int bneck_lds = 0;       // diagnostics: dynamic LDS bytes of the fused block kernels (0 = the whole 160 KB, so nothing with LDS shares their CU)
 };
 extern DvidOptions g_opt;

@@ -43,6 +43,11 @@ def nhwc(x, pad_to=None):
     dict(n=2, h=64, w=96, cin=3, cout=64, k=7, stride=2, pad=3, relu=1, res=0),             # the stem: 3 channels padded to 4, K 196 -> 208
     dict(n=1, h=9, w=11, cin=256, cout=30, k=1, stride=1, pad=0, relu=0, res=0),            # N tail (class_logits)
     dict(n=1, h=5, w=7, cin=64, cout=130, k=3, stride=1, pad=1, relu=2, res=0),             # exact GELU, N tail across two tiles
+    # 3x3 / stride 1 without a residual: csrc/f32_conv3x3.hip (halo staged once per 32-channel chunk) when split = 1
+    dict(n=3, h=19, w=32, cin=256, cout=256, k=3, stride=1, pad=1, relu=1, res=0),          # res5-like map: 19 rows = two full patches + 3 rows
+    dict(n=2, h=9, w=70, cin=32, cout=64, k=3, stride=1, pad=1, relu=1, res=0),             # BN 64, ragged width (2 x 32 + 6), one chunk
+    dict(n=2, h=8, w=32, cin=128, cout=96, k=3, stride=1, pad=1, relu=0, res=0),            # N tail inside one tile
+    dict(n=1, h=38, w=64, cin=64, cout=64, k=3, stride=1, pad=1, relu=1, res=0),
 ])
 @pytest.mark.parametrize("split", [1, 0])
 def test_f32_conv(dv, cfg, split):
