@@ -1118,15 +1118,15 @@ int dvid_f32_igemm_launch(const F32GemmParams& p0, hipStream_t s) {
     if (split && g_opt.f32_conv3x3 && dvid_f32_conv3x3_supported(p)) return dvid_f32_conv3x3_launch(p, s);
     // short-K / wide-N 1x1 layers: the weight-stationary form of the same arithmetic (whole 32-row blocks; a ragged tail falls through
     // to the tiled kernel below on the remaining rows -- same values either way)
-    if (split && g_opt.f32_wstat && p.M >= 32 && (g_opt.f32_wstat == 2 ? dvid_f32_wstat_supported(p) : dvid_f32_wstat_preferred(p))) {
-        const int m0 = p.M & ~31;
+    if (split && g_opt.f32_wstat && (g_opt.f32_wstat == 2 ? dvid_f32_wstat_supported(p) : dvid_f32_wstat_preferred(p)) && p.M >= dvid_f32_wstat_tile_rows(p)) {
+        const int m0 = p.M - p.M % dvid_f32_wstat_tile_rows(p);
         F32GemmParams q = p;
         q.M = m0;
         q.H = m0;          // (a 1x1 layer over contiguous rows: the row count is all the kernel reads of the geometry)
         q.W = 1;
         q.Ho = m0;
         q.Wo = 1;
-        const int rc = dvid_f32_wstat_launch_rows32(q, s);
+        const int rc = dvid_f32_wstat_launch_tiles(q, s);
         if (rc != DVID_OK) return rc;
         if (p.M == m0) return DVID_OK;
         p.in += (long)m0 * p.Cin;

@@ -24,27 +24,30 @@
 
 namespace {
 
-template <int K>
+template <int K, int RB>
 struct F32WsSmem {
-    static constexpr int kPlane = 32 * K * 2;          // one fp16 plane of a 32-row tile
+    static constexpr int kPlane = 32 * RB * K * 2;     // one fp16 plane of a tile of 32 RB rows
     static constexpr int kStage = 2 * kPlane;          // hi | lo
     static constexpr int kVecOff = 2 * kStage;         // two stages, then the slab's per-channel scale | bias (256 floats each)
     static constexpr int kBytes = kVecOff + 2 * 256 * 4;
 };
 
-// ACT: 0 none, 1 ReLU, 2 exact GELU.  Grid: 256 workgroups x 512 threads.  M % 32 == 0, Cout % 256 == 0, Kpad == Cin == K.
-template <int K, bool HAS_RES, int ACT>
+// RB: 32-row blocks per tile (a wave runs RB accumulator chains against the same weight registers; K = 64 needs 2 for every thread to have
+// a chunk to split).  ACT: 0 none, 1 ReLU, 2 exact GELU.  Grid: 256 workgroups x 512 threads.  M % (32 RB) == 0, Cout % 256 == 0, Kpad == Cin == K.
+template <int K, int RB, bool HAS_RES, int ACT>
 __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int nslab) {
     constexpr int WPX = 32;
     constexpr int KS = K / 16;
+    constexpr int TR = 32 * RB;                   // tile rows
     constexpr int CPR = K / 8;                    // 8-value chunks per row
-    constexpr int CPT = 32 * CPR / 512;           // chunks per thread and tile (K = 256: 2, K = 128: 1)
+    constexpr int CPT = TR * CPR / 512;           // chunks per thread and tile
     constexpr int RSTEP = 512 / CPR;              // tile rows between a thread's chunks
-    constexpr int PLANE = F32WsSmem<K>::kPlane;
-    constexpr int STAGE = F32WsSmem<K>::kStage;
+    using SM = F32WsSmem<K, RB>;
+    constexpr int PLANE = SM::kPlane;
+    constexpr int STAGE = SM::kStage;
     static_assert(CPT >= 1, "every thread splits at least one chunk per tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* const vec_scale = reinterpret_cast<float*>(smem + F32WsSmem<K>::kVecOff);
+    float* const vec_scale = reinterpret_cast<float*>(smem + SM::kVecOff);
     float* const vec_bias = vec_scale + 256;
 
     const int tid = threadIdx.x;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int n
     // rows of this workgroup: the decomposition of csrc/wstat.hip (XCD = blockIdx % 8 owns an eighth of the 32-row blocks; inside it the 32
     // workgroups are (sub-range, slab) pairs, or -- more than 32 slabs -- each walks slabs q, q + 32, ... over the whole eighth)
     const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
-    const int MB = p.M >> 5;
+    const int MB = p.M / TR;
     const int xb0 = (int)((long)MB * xcd / 8), xb1 = (int)((long)MB * (xcd + 1) / 8);
     int blk0 = xb0, blk1 = xb1, slab0 = q, slab_step = WPX;
     if (nslab <= WPX) {
@@ -69,16 +72,20 @@ __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int n
     const int T = blk1 - blk0;
     if (T <= 0) return;                           // workgroup-uniform
 
+    // XOR key of a row's 16-byte chunks: the rows of one ds_read_b128 lane group ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) must land on
+    // 16 different (bank quarter, chunk) pairs.  Rows of 256 / 512 bytes all start on bank 0: key = row % 16; rows of 128 bytes (K = 64, 8
+    // chunks) alternate between two bank halves: key = (row / 2) % 8.
+    auto swz_key = [](int row) { return K == 64 ? (row >> 1) & 7 : row & 15; };
     // this thread's chunks of a tile: chunk c = tid + 512 i -> (row, chunk in row); 64 lanes x 32 bytes = whole rows of the source
     const float* a_src[CPT];
     int lds_off[CPT];
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int row = tid / CPR + RSTEP * i, ch = tid % CPR;
-        a_src[i] = p.in + ((long)(blk0 * 32 + row) * K + ch * 8);
-        lds_off[i] = row * (K * 2) + ((ch ^ (row & 15)) * 16);
+        a_src[i] = p.in + ((long)(blk0 * TR + row) * K + ch * 8);
+        lds_off[i] = row * (K * 2) + ((ch ^ swz_key(row)) * 16);
     }
-    const int frag_key = lrow & 15;
+    const int frag_key = swz_key(lrow);          // (a tile's second row block: 32 more rows leave the key unchanged)
     const int frag_row_off = lrow * (K * 2);
 
     float range_max = 0.f;
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int n
     auto fetch = [&](int t) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const float* src = a_src[i] + (long)t * 32 * K;
+            const float* src = a_src[i] + (long)t * TR * K;
             ra[i][0] = *reinterpret_cast<const float4v*>(src);
             ra[i][1] = *reinterpret_cast<const float4v*>(src + 4);
         }
@@ -124,37 +131,45 @@ __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int n
 
         // residual / output of this lane's row in tile 0: channels n0 + 16 g + 8 hi + [0, 8)
         const long col = n0 + 8 * hi;
-        const float* r_src = HAS_RES ? p.res + ((long)(blk0 * 32 + lrow) * p.Cout + col) : nullptr;
-        float* o_dst = p.out + (long)(blk0 * 32 + lrow) * p.ldc + col;
+        const float* r_src = HAS_RES ? p.res + ((long)(blk0 * TR + lrow) * p.Cout + col) : nullptr;
+        float* o_dst = p.out + (long)(blk0 * TR + lrow) * p.ldc + col;
         const int vec_off = 32 * wave + 8 * hi;
 
         fetch(0);
         split_to(0);
         __syncthreads();
 
-        float16v acc;
-        float4v rr[2][2];
+        float16v acc[RB];
+        float4v rr[RB][2][2];
         auto load_res = [&](int t) {
             if (HAS_RES) {
-                const float* r = r_src + (long)t * 32 * p.Cout;
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    rr[g][0] = *reinterpret_cast<const float4v*>(r + 16 * g);
-                    rr[g][1] = *reinterpret_cast<const float4v*>(r + 16 * g + 4);
+                for (int rb = 0; rb < RB; ++rb) {
+                    const float* r = r_src + ((long)t * TR + 32 * rb) * p.Cout;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        rr[rb][g][0] = *reinterpret_cast<const float4v*>(r + 16 * g);
+                        rr[rb][g][1] = *reinterpret_cast<const float4v*>(r + 16 * g + 4);
+                    }
                 }
             }
         };
         auto products = [&](int t) {
             const char* const stg = smem + (t & 1) * STAGE;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            // the fragments of K step ks + 1 are requested before the three products of step ks (left to itself the compiler reads each
-            // fragment right in front of its first use -- `ds_read; s_waitcnt lgkmcnt(0); v_mfma` sixteen times per tile)
-            half8 ah[2], al[2];
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+            // the fragments of K step ks + 1 are requested before the products of step ks (left to itself the compiler reads each
+            // fragment right in front of its first use -- `ds_read; s_waitcnt lgkmcnt(0); v_mfma` once per K step)
+            half8 ah[2][RB], al[2][RB];
             auto frag = [&](int ks) {
-                const int off = frag_row_off + (((2 * ks + hi) ^ frag_key) * 16);
-                ah[ks & 1] = *reinterpret_cast<const half8*>(stg + off);
-                al[ks & 1] = *reinterpret_cast<const half8*>(stg + PLANE + off);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const int off = rb * 32 * (K * 2) + frag_row_off + (((2 * ks + hi) ^ frag_key) * 16);
+                    ah[ks & 1][rb] = *reinterpret_cast<const half8*>(stg + off);
+                    al[ks & 1][rb] = *reinterpret_cast<const half8*>(stg + PLANE + off);
+                }
             };
             frag(0);
 #pragma unroll
@@ -162,50 +177,56 @@ __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int n
                 if (ks + 1 < KS) frag(ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // the two small terms first, then the leading one: f32x3_igemm_kernel's order
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], al[ks & 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], ah[ks & 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], ah[ks & 1], acc, 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], al[ks & 1][rb], acc[rb], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], ah[ks & 1][rb], acc[rb], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], ah[ks & 1][rb], acc[rb], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         // epilogue from the accumulator layout.  acc[4 r4 + r] = channel 8 r4 + 4 hi + r of row lane % 32; one half-wave exchange per
         // register pair (r4, r4 + 1) leaves lane < 32 with channels 16 g + [0, 8) and lane >= 32 with 16 g + 8 + [0, 8)
         auto finish = [&](int t) {
-            float* const o = o_dst + (long)t * 32 * p.ldc;
-            unsigned int u[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float f = acc[r];
-                u[r] = __float_as_uint(f);
-            }
+            for (int rb = 0; rb < RB; ++rb) {
+                float* const o = o_dst + ((long)t * TR + 32 * rb) * p.ldc;
+                unsigned int u[16];
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(u[8 * g + r], u[8 * g + 4 + r], false, false);
-                    u[8 * g + r] = sw[0];
-                    u[8 * g + 4 + r] = sw[1];
+                for (int r = 0; r < 16; ++r) {
+                    const float f = acc[rb][r];
+                    u[r] = __float_as_uint(f);
                 }
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float4v sc = *reinterpret_cast<const float4v*>(vec_scale + vec_off + 16 * g + 4 * h);
-                    const float4v bi = *reinterpret_cast<const float4v*>(vec_bias + vec_off + 16 * g + 4 * h);
-                    float4v v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(u[8 * g + 4 * h + e]);
-                    v *= sc;                      // a power of two: exact
-                    v += bi;
-                    if (HAS_RES) v += rr[g][h];
-                    if (ACT == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    } else if (ACT == 2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(u[8 * g + r], u[8 * g + 4 + r], false, false);
+                        u[8 * g + r] = sw[0];
+                        u[8 * g + 4 + r] = sw[1];
                     }
-                    *reinterpret_cast<float4v*>(o + 16 * g + 4 * h) = v;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4v sc = *reinterpret_cast<const float4v*>(vec_scale + vec_off + 16 * g + 4 * h);
+                        const float4v bi = *reinterpret_cast<const float4v*>(vec_bias + vec_off + 16 * g + 4 * h);
+                        float4v v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(u[8 * g + 4 * h + e]);
+                        v *= sc;                      // a power of two: exact
+                        v += bi;
+                        if (HAS_RES) v += rr[rb][g][h];
+                        if (ACT == 1) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        } else if (ACT == 2) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        }
+                        *reinterpret_cast<float4v*>(o + 16 * g + 4 * h) = v;
+                    }
                 }
             }
         };
@@ -228,29 +249,29 @@ __global__ __launch_bounds__(512) void f32x3_wstat_kernel(F32GemmParams p, int n
     if (p.range_flag && range_max > 65504.f) atomicOr(p.range_flag, 1);
 }
 
-template <int K, bool HAS_RES, int ACT>
+template <int K, int RB, bool HAS_RES, int ACT>
 int f32ws_launch_k(const F32GemmParams& p, hipStream_t s) {
-    constexpr int smem = F32WsSmem<K>::kBytes;
+    constexpr int smem = F32WsSmem<K, RB>::kBytes;
     static_assert(smem <= 160 * 1024, "LDS");
     static std::atomic<unsigned long long> attr_set{0};          // one bit per device: the attribute belongs to (function, device)
     if (first_on_device(attr_set)) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&f32x3_wstat_kernel<K, HAS_RES, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&f32x3_wstat_kernel<K, RB, HAS_RES, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         mark_on_device(attr_set);
     }
-    hipLaunchKernelGGL((f32x3_wstat_kernel<K, HAS_RES, ACT>), dim3(256), dim3(512), smem, s, p, p.Cout / 256);
+    hipLaunchKernelGGL((f32x3_wstat_kernel<K, RB, HAS_RES, ACT>), dim3(256), dim3(512), smem, s, p, p.Cout / 256);
     LAUNCH_CHECK();
     return DVID_OK;
 }
 
-template <int K>
+template <int K, int RB>
 int f32ws_launch_v(const F32GemmParams& p, hipStream_t s) {
     if (p.res_mode == 1) {
-        if (p.relu == 1) return f32ws_launch_k<K, true, 1>(p, s);
-        if (p.relu == 0) return f32ws_launch_k<K, true, 0>(p, s);
+        if (p.relu == 1) return f32ws_launch_k<K, RB, true, 1>(p, s);
+        if (p.relu == 0) return f32ws_launch_k<K, RB, true, 0>(p, s);
         return DVID_ERR_UNSUPPORTED;
     }
-    if (p.relu == 2) return f32ws_launch_k<K, false, 2>(p, s);
-    return p.relu == 1 ? f32ws_launch_k<K, false, 1>(p, s) : f32ws_launch_k<K, false, 0>(p, s);
+    if (p.relu == 2) return f32ws_launch_k<K, RB, false, 2>(p, s);
+    return p.relu == 1 ? f32ws_launch_k<K, RB, false, 1>(p, s) : f32ws_launch_k<K, RB, false, 0>(p, s);
 }
 
 }  // namespace
@@ -260,7 +281,7 @@ int f32ws_launch_v(const F32GemmParams& p, hipStream_t s) {
 bool dvid_f32_wstat_supported(const F32GemmParams& p) {
     if (!p.w_hi || !p.w_lo) return false;
     if (p.KH != 1 || p.KW != 1 || p.pad != 0 || p.stride != 1 || p.Ho != p.H || p.Wo != p.W) return false;
-    if (p.Cin != p.Kpad || p.K != p.Kpad || (p.Kpad != 128 && p.Kpad != 256)) return false;
+    if (p.Cin != p.Kpad || p.K != p.Kpad || (p.Kpad != 64 && p.Kpad != 128 && p.Kpad != 256)) return false;
     if (p.Cout % 256 || (p.ldc & 3)) return false;
     const int ns = p.Cout / 256;
     if (!(ns <= 32 ? (32 % ns == 0 || ns == 3 || ns == 6) : ns % 32 == 0)) return false;
@@ -278,8 +299,12 @@ bool dvid_f32_wstat_preferred(const F32GemmParams& p) {
     return per_wg >= kMinBlocks;
 }
 
-// Whole 32-row blocks only; the caller (dvid_f32_igemm_launch) hands a ragged tail to the tiled kernel -- same values.
-int dvid_f32_wstat_launch_rows32(const F32GemmParams& p, hipStream_t s) {
-    if (!dvid_f32_wstat_supported(p) || (p.M & 31)) return DVID_ERR_UNSUPPORTED;
-    return p.Kpad == 128 ? f32ws_launch_v<128>(p, s) : f32ws_launch_v<256>(p, s);
+// rows per tile of the variant a layer runs on (K = 64: two 32-row blocks, so that every thread has a chunk of the tile to split)
+int dvid_f32_wstat_tile_rows(const F32GemmParams& p) { return p.Kpad == 64 ? 64 : 32; }
+
+// Whole tiles only; the caller (dvid_f32_igemm_launch) hands a ragged tail to the tiled kernel -- same values.
+int dvid_f32_wstat_launch_tiles(const F32GemmParams& p, hipStream_t s) {
+    if (!dvid_f32_wstat_supported(p) || p.M % dvid_f32_wstat_tile_rows(p)) return DVID_ERR_UNSUPPORTED;
+    if (p.Kpad == 64) return f32ws_launch_v<64, 2>(p, s);
+    return p.Kpad == 128 ? f32ws_launch_v<128, 1>(p, s) : f32ws_launch_v<256, 1>(p, s);
 }

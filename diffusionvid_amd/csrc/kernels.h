@@ -177,7 +177,8 @@ int dvid_f32_igemm_launch(const F32GemmParams& p, hipStream_t s);
 // csrc/f32_wstat.hip: the weight-stationary form of the split-operand kernel (bit-identical to it)
 bool dvid_f32_wstat_supported(const F32GemmParams& p);
 bool dvid_f32_wstat_preferred(const F32GemmParams& p);
-int dvid_f32_wstat_launch_rows32(const F32GemmParams& p, hipStream_t s);
+int dvid_f32_wstat_tile_rows(const F32GemmParams& p);
+int dvid_f32_wstat_launch_tiles(const F32GemmParams& p, hipStream_t s);
 // csrc/f32_conv3x3.hip: 3x3 / stride-1 layers with the halo staged and split once per channel chunk (another summation order than the tiled kernel)
 bool dvid_f32_conv3x3_supported(const F32GemmParams& p);
 int dvid_f32_conv3x3_launch(const F32GemmParams& p, hipStream_t s);

@@ -109,6 +109,8 @@ def test_f32_linear(dv, rows, k, nout, split):
     (3200, 128, 512, 2, 0),                # Swin fc1: exact GELU
     (2080, 256, 768, 0, 0),                # three slabs (Swin qkv): 30 of an XCD's 32 workgroups work
     (32, 256, 256, 0, 1),                  # one row block: 255 workgroups have nothing to do
+    (4096 + 40, 64, 256, 1, 1),            # res2 conv3: K = 64 runs tiles of 64 rows; tail of 40 rows on the tiled kernel
+    (64, 64, 512, 0, 0),
 ])
 def test_f32_wstat_matches_tiled(dv, rows, k, nout, relu, res):
     """csrc/f32_wstat.hip (weight-stationary split-operand kernel) against csrc/f32.hip's tiled split-operand kernel: the same split, the
