@@ -707,7 +707,8 @@ def main():
         # (every layer's input + weights + output + residual once) and the measured traffic are printed next to it: their
         # ratio to the ideal-fusion figure is the activation round-trip traffic that fusion has yet to remove.
         peak = f32_peak if f32 else PEAK_FP16_TFLOPS
-        r = {"bound": "mfma", "kernel": (("implicit-GEMM conv/linear kernel of the DTYPE float32 path with split operands (f32x3_igemm_kernel, csrc/f32.hip): fp32 storage, every product as three "
+        r = {"bound": "mfma", "kernel": (("implicit-GEMM conv/linear kernels of the DTYPE float32 path with split operands (f32x3_igemm_kernel, csrc/f32.hip; f32x3_conv3x3_kernel for the 3x3 / stride-1 layers; "
+                                          "f32x3_wstat_kernel for the short-K / wide-N 1x1 layers): fp32 storage, every product as three "
                                           "fp16-MFMA passes over (hi, lo) fp16 pairs with fp32 accumulation; `achieved` counts ALGORITHMIC FLOP (one per fp32-grade product), `peak` = the dense "
                                           "fp16 MFMA peak / 3" if ops.get_option("f32_split") else
                                           "implicit-GEMM conv/linear kernel of the DTYPE float32 path, fp32 MFMA v_mfma_f32_32x32x2_f32 (f32_igemm_kernel, csrc/f32.hip)") if f32 else
@@ -784,10 +785,11 @@ def main():
             side("swinb_x1", "swinb", 1, 76, 5, with_roofline=True)
             # `DTYPE float32` (the reference's default precision; round 6): fp32 storage + fp32 MFMA end to end (csrc/f32.hip) -- the mode in
             # which the path meets SURVEY.md 8(d)'s tolerances against the fp32 oracle (tests/test_gpu_e2e.py); 1/16 of the fp16 MFMA rate
-            f32_note = ("DTYPE float32: every weight and activation fp32; conv / linear products as three fp16-MFMA passes over split (hi, lo) operands with fp32 accumulation "
-                        "(library option f32_split = 1; 0 = the fp32 MFMA, 157.3 TFLOP/s), the per-box products on the fp32 MFMA; one group per 304-frame video")
+            f32_note = ("DTYPE float32: every weight and activation fp32; conv / linear and DynamicConv's per-box products as three fp16-MFMA passes over split (hi, lo) operands "
+                        "with fp32 accumulation (library option f32_split = 1; 0 = the fp32 MFMA, 157.3 TFLOP/s); one group per 304-frame video")
             side("r101_x1_float32", "r101", 1, 38, 2, with_roofline=True, dtype="float32", note=f32_note)
             side("r101_x4_float32", "r101", 4, 38, 2, dtype="float32", note=f32_note)
+            side("swinb_x1_float32", "swinb", 1, 76, 2, dtype="float32", note=f32_note)
             side("r101_x1_float32_fp32_mfma", "r101", 1, 38, 2, with_roofline=True, dtype="float32", options={"f32_split": 0},
                  note="DTYPE float32 with library option f32_split = 0: every product exact on the fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense peak)")
             # the latency-oriented variant of demo/demo.py:60-68 -- one frame per call, one new global frame per
