@@ -770,7 +770,9 @@ __global__ __launch_bounds__(64) void f32_swin_window_attn_kernel(const float* _
 // global as float4 fragments; F1 / F2 cross LDS for the row statistics.
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int DC_P1 = 68, DC_P2 = 260;
-__global__ __launch_bounds__(256) void f32_dynconv_kernel(const float* __restrict__ roi, const float* __restrict__ params,
+// (two workgroups per CU: left to itself the compiler takes 200 VGPRs + 64 AGPRs, over the 256 a wave may have at two waves per SIMD, and
+// a box's loads, products and LayerNorms then run strictly one after the other on the CU)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void f32_dynconv_kernel(const float* __restrict__ roi, const float* __restrict__ params,
                                                            const float* __restrict__ g1, const float* __restrict__ b1,
                                                            const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ out,
                                                            int nbox) {
