@@ -649,11 +649,14 @@ def main():
         with torch.no_grad():
             run_video(model, ds, device)      # un-instrumented: lets the per-shape tile tuner see the chains=1 launch shapes first
         torch.cuda.synchronize()
-        lib.dvid_profile_reset()
         lib.dvid_profile_enable(1)
-        with torch.no_grad():
-            run_video(model, ds, device)
-        torch.cuda.synchronize()
+        # two instrumented passes, the second one kept: the first launch of the first pass (the stem) has come out at 1x-2.5x its steady
+        # duration from run to run (9.0 / 14.2 / 22.9 ms in the float32 tables of round 6 while rocprofv3 shows the kernel at its steady time)
+        for _ in range(2):
+            lib.dvid_profile_reset()
+            with torch.no_grad():
+                run_video(model, ds, device)
+            torch.cuda.synchronize()
         engine_model.set_chains(int(os.environ.get("DVID_CHAINS", "2")))
         model.use_call_graph = graphs
         ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
