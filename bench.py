@@ -77,7 +77,7 @@ PEAK_FP32_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROA
 PEAK_FP32_SPLIT_TFLOPS = round(PEAK_FP16_TFLOPS / 3.0, 1)
 # the library's option table at its defaults (csrc/options.h): the configuration every number of this file is quoted on unless --option says otherwise;
 # tests/test_host_logic.py::test_default_library_configuration_is_the_benchmarked_one holds the library to this string
-DEFAULT_LIBRARY_CONFIG = "conv3x3=1 wstat=1 bneck_fuse=1 stem_pool=1 head_tail=1 ln_rows=1 igemm_cfg=-1 igemm_tune=-1 igemm_generic=0 f32_split=1 f32_wstat=1 f32_conv3x3=1 bneck_lds=0"
+DEFAULT_LIBRARY_CONFIG = "conv3x3=1 wstat=1 bneck_fuse=1 stem_pool=1 head_tail=1 roi_fuse=1 ln_rows=1 igemm_cfg=-1 igemm_tune=-1 igemm_generic=0 f32_split=1 f32_wstat=1 f32_conv3x3=1 bneck_lds=0"
 PEAK_HBM_GBS = 8000.0
 # algorithmic work per output frame: backbone + heads + global attention, faithful pass counts
 ALG_GFLOP_PER_FRAME = {("r101", 1): 249.3, ("r101", 4): 385.0, ("swinb", 1): 459.6}

@@ -10,8 +10,17 @@
 // is staged once in LDS (528-byte pitch: conflict-free ds_read_b128 fragments); the N
 // dimension of both products is split over the 4 waves, so LayerNorm row statistics are
 // combined across waves through a tiny LDS buffer (mean first, then centred variance, fp32).
+//
+// FUSED_ROI (round 6): the RoI tile is not read from memory but GATHERED here -- the per-box walk of multi-level RoIAlignV2
+// (csrc/roi_taps.h, the arithmetic of csrc/roialign.hip bit for bit) writes its 49 bins straight into the LDS image the first product
+// reads.  The separate launches move the fp16 tile through HBM twice (25 KB out, 25 KB in per box) and run an L1-bound gather and an
+// HBM-bound stream one after the other; here the first product's 32 KB of parameters are requested BEFORE the gather, and with three
+// workgroups per CU one box's taps (L1 path) overlap another's parameter stream (HBM).  The unfused pair stays for the passes that need
+// the tile's mean over the bins before the self-attention (box_head.py:509-510: a head without incoming proposal features).
 #include "common.h"
+#include "igemm_epilogue.h"
 #include "kernels.h"
+#include "roi_taps.h"
 
 namespace {
 
@@ -32,34 +41,55 @@ __device__ __forceinline__ float groups4_sum(float v) {
 // channels of ONE tile row instead of 4 rows of one channel, so a LayerNorm statistic is 3-15 in-lane adds + 2 shuffles per row tile
 // (it was 4 shuffles per accumulator register: 64 per pass), and the fp16 results leave as 8-byte LDS writes (they were 2-byte ones).
 // Same products, same K order; only the order of the fp32 sums inside the LayerNorm statistics differs from the row-major form.
+template <bool FUSED_ROI>
 __global__ __launch_bounds__(256, 3) void dynconv_kernel(const half_t* __restrict__ roi, const half_t* __restrict__ params,
                                                        const float* __restrict__ g1, const float* __restrict__ b1,
                                                        const float* __restrict__ g2, const float* __restrict__ b2,
-                                                       half_t* __restrict__ out) {
+                                                       half_t* __restrict__ out, RoiLevels lv, const float* __restrict__ boxes,
+                                                       int boxes_per_img, int nbox) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* As = reinterpret_cast<half_t*>(smem);                     // [64][A_PITCH]; later the output tile
     half_t* Hs = As + 64 * A_PITCH;                                   // [64][H_PITCH]
     float* red = reinterpret_cast<float*>(Hs + 64 * H_PITCH);         // [64 rows][4 waves]
 
-    const int box = blockIdx.x;
+    // (fused: an XCD takes one contiguous run of boxes, i.e. whole images, as csrc/roialign.hip -- the boxes that gather from one image's
+    // pyramid meet in one L2)
+    const int box = FUSED_ROI ? igemm_xcd_remap((int)blockIdx.x, nbox) : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const half_t* roi_b = roi + (long)box * NP * D;
     const half_t* p1t = params + (long)box * (2 * D * DD);
     const half_t* p2t = p1t + D * DD;
-
-    // ---- stage the RoI tile (rows 49..63 zero) ----------------------------------------
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < 64 * 32; i += 256) {
-        const int r = i >> 5, cv = i & 31;
-        const half8 v = *reinterpret_cast<const half8*>(roi_b + (long)(r < NP ? r : 0) * D + cv * 8);
-        *reinterpret_cast<half8*>(As + r * A_PITCH + cv * 8) = (r < NP) ? v : zero8;
-    }
-    // parameter fragments of bmm #1: this wave owns output channels [wave*16, +16)
-    half8 bf[8];
+    half8 bf[8];          // parameter fragments of bmm #1: this wave owns output channels [wave*16, +16)
+    half8 b2f[4][2];      // ... of bmm #2: channels [wave*64, +64)
+
+    if (FUSED_ROI) {
+        // both products' parameters (64 KB per box) are requested first: they stream in from HBM under the gather, which runs on the L1 path
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-        bf[ks] = *reinterpret_cast<const half8*>(p1t + (wave * 16 + l15) * D + ks * 32 + l4 * 8);
+        for (int ks = 0; ks < 8; ++ks)
+            bf[ks] = *reinterpret_cast<const half8*>(p1t + (wave * 16 + l15) * D + ks * 32 + l4 * 8);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                b2f[nt][ks] = *reinterpret_cast<const half8*>(p2t + (wave * 64 + nt * 16 + l15) * DD + ks * 32 + l4 * 8);
+        // ---- gather the RoI tile into its LDS image (rows 49..63 zero) ------------------
+        float macc[8];
+        roi_taps::gather_box(lv, boxes, boxes_per_img, box, tid >> 5, tid & 31, macc,
+                             [&](int p, half8 o) { *reinterpret_cast<half8*>(As + p * A_PITCH + (tid & 31) * 8) = o; });
+        for (int i = tid; i < (64 - NP) * 32; i += 256) *reinterpret_cast<half8*>(As + (NP + (i >> 5)) * A_PITCH + (i & 31) * 8) = zero8;
+    } else {
+        // ---- stage the RoI tile (rows 49..63 zero) ----------------------------------------
+        const half_t* roi_b = roi + (long)box * NP * D;
+        for (int i = tid; i < 64 * 32; i += 256) {
+            const int r = i >> 5, cv = i & 31;
+            const half8 v = *reinterpret_cast<const half8*>(roi_b + (long)(r < NP ? r : 0) * D + cv * 8);
+            *reinterpret_cast<half8*>(As + r * A_PITCH + cv * 8) = (r < NP) ? v : zero8;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            bf[ks] = *reinterpret_cast<const half8*>(p1t + (wave * 16 + l15) * D + ks * 32 + l4 * 8);
+    }
     __syncthreads();
 
     // ---- bmm #1 (transposed): acc1[mt][r] = F1[row mt*16 + l15][channel wave*16 + 4*l4 + r] -----------------------------
@@ -74,13 +104,14 @@ __global__ __launch_bounds__(256, 3) void dynconv_kernel(const half_t* __restric
             acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks], af, acc1[mt], 0, 0, 0);
         }
     }
-    // prefetch this wave's bmm #2 parameter fragments (channels [wave*64, +64))
-    half8 b2f[4][2];
+    // prefetch this wave's bmm #2 parameter fragments (channels [wave*64, +64)); fused: they were requested ahead of the gather
+    if (!FUSED_ROI) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            b2f[nt][ks] = *reinterpret_cast<const half8*>(p2t + (wave * 64 + nt * 16 + l15) * DD + ks * 32 + l4 * 8);
+            for (int ks = 0; ks < 2; ++ks)
+                b2f[nt][ks] = *reinterpret_cast<const half8*>(p2t + (wave * 64 + nt * 16 + l15) * DD + ks * 32 + l4 * 8);
+    }
 
     // ---- LayerNorm(64) + ReLU over rows ------------------------------------------------------------------------------------
     float mean[4], rstd[4];
@@ -201,7 +232,18 @@ constexpr int kSmem = 64 * A_PITCH * 2 + 64 * H_PITCH * 2 + 64 * 4 * 4;
 int dvid_dynconv_launch(const half_t* roi, const half_t* params, const float* g1, const float* b1, const float* g2,
                         const float* b2, half_t* out, int rows, hipStream_t s) {
     if (rows == 0) return DVID_OK;
-    hipLaunchKernelGGL(dynconv_kernel, dim3(rows), dim3(256), kSmem, s, roi, params, g1, b1, g2, b2, out);
+    hipLaunchKernelGGL(dynconv_kernel<false>, dim3(rows), dim3(256), kSmem, s, roi, params, g1, b1, g2, b2, out, RoiLevels{}, nullptr, 1, rows);
+    LAUNCH_CHECK();
+    return DVID_OK;
+}
+
+// RoIAlign + DynamicConv as one launch: the tile of box b of image b / boxes_per_img is gathered from the pyramid `lv` (see the header)
+int dvid_dynconv_roi_launch(const RoiLevels& lv, int channels, const float* boxes, int n_img, int boxes_per_img, const half_t* params,
+                            const float* g1, const float* b1, const float* g2, const float* b2, half_t* out, hipStream_t s) {
+    if (channels != 256) return DVID_ERR_UNSUPPORTED;
+    const int rows = n_img * boxes_per_img;
+    if (rows == 0) return DVID_OK;
+    hipLaunchKernelGGL(dynconv_kernel<true>, dim3(rows), dim3(256), kSmem, s, nullptr, params, g1, b1, g2, b2, out, lv, boxes, boxes_per_img, rows);
     LAUNCH_CHECK();
     return DVID_OK;
 }

@@ -94,6 +94,9 @@ int dvid_patch_merge_ln_launch(const float* x, const float* g, const float* b, h
 // dynconv.hip
 int dvid_dynconv_launch(const half_t* roi, const half_t* params, const float* g1, const float* b1, const float* g2,
                         const float* b2, half_t* out, int rows, hipStream_t s);
+// RoIAlign gathered straight into DynamicConv's LDS tile (csrc/dynconv.hip, FUSED_ROI): bit-identical to dvid_roialign_launch + dvid_dynconv_launch
+int dvid_dynconv_roi_launch(const RoiLevels& lv, int channels, const float* boxes, int n_img, int boxes_per_img, const half_t* params,
+                            const float* g1, const float* b1, const float* g2, const float* b2, half_t* out, hipStream_t s);
 
 // headtail.hip: FFN + norm3 + modulation + cls / reg towers + class_logits + bboxes_delta + apply_deltas of one RCNNHead pass as one
 // row-tile kernel.  Every `*f` weight is in MFMA fragment order (model.hip: make_frags): [n-tile of 32 rows][K step of 16][lane][8].

@@ -781,10 +781,14 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
         lv.scale[l] = 1.f / (float)(8 << l);
     }
     float* pro32 = f32a;
-    {
+    // A pass that gets its proposal features from the caller needs nothing of the tile before DynamicConv: the gather then runs INSIDE the
+    // DynamicConv launch (csrc/dynconv.hip, FUSED_ROI) and the fp16 tile never reaches memory.  A pass without them takes the tile's mean
+    // over the bins as its features (box_head.py:509-510) ahead of the self-attention: the two launches.
+    const bool roi_fused = g_opt.roi_fuse && pro_features != nullptr && d == 256;
+    double map_px = 0;
+    for (int l = 0; l < 3; ++l) map_px += (double)lv.h[l] * lv.w[l];
+    if (!roi_fused) {
         // algorithmic bytes: the three maps of the launch's frames once + one 49 x d tile per box (the 784 taps per box go through L1)
-        double map_px = 0;
-        for (int l = 0; l < 3; ++l) map_px += (double)lv.h[l] * lv.w[l];
         TRY(prof_other("roialign", R, d, 49, 0.0, (double)nf * map_px * d * 2.0 + (double)R * 49 * d * 2.0, s,
                        [&] { return dvid_roialign_launch(lv, d, boxes, nf, M, roi16, pro_features ? nullptr : pro32, s); }));
     }
@@ -804,8 +808,15 @@ int rcnn_head_chain(dvid_model* m, const HeadW& hw, int is_cond, const void* p3,
     TRY(linear_run(hw.dynamic_layer, h16a, R, params16, 0, 0, s));
     {
         const int dd = m->cfg.dim_dynamic;
-        TRY(prof_other("dynconv", R, d, dd, 2.0 * R * 49.0 * d * dd * 2.0, (double)R * (2.0 * 49 * d * 2.0 + 2.0 * d * dd * 2.0), s,
-                       [&] { return dvid_dynconv_launch(roi16, params16, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn16, R, s); }));
+        if (roi_fused) {
+            // algorithmic bytes: the maps once + the parameters + the output tile per box
+            TRY(prof_other("dynconv_roi", R, d, dd, 2.0 * R * 49.0 * d * dd * 2.0, (double)nf * map_px * d * 2.0 + (double)R * (49 * d * 2.0 + 2.0 * d * dd * 2.0), s, [&] {
+                return dvid_dynconv_roi_launch(lv, d, boxes, nf, M, params16, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn16, s);
+            }));
+        } else {
+            TRY(prof_other("dynconv", R, d, dd, 2.0 * R * 49.0 * d * dd * 2.0, (double)R * (2.0 * 49 * d * 2.0 + 2.0 * d * dd * 2.0), s,
+                           [&] { return dvid_dynconv_launch(roi16, params16, hw.dc_norm1.g, hw.dc_norm1.b, hw.dc_norm2.g, hw.dc_norm2.b, dyn16, R, s); }));
+        }
     }
     // out_layer: K = 49*d = 12544 on only R x d outputs -> split K over 7 workgroups per tile; the partial slabs
     // and the bias are summed inside the norm3 kernel that consumes them.
@@ -1342,7 +1353,7 @@ struct OptEntry {
 };
 const OptEntry kOptions[] = {
     {"conv3x3", &DvidOptions::conv3x3, 0, 2},       {"wstat", &DvidOptions::wstat, 0, 2},           {"bneck_fuse", &DvidOptions::bneck_fuse, 0, 2},
-    {"stem_pool", &DvidOptions::stem_pool, 0, 1},   {"head_tail", &DvidOptions::head_tail, 0, 1},   {"ln_rows", &DvidOptions::ln_rows, 0, 1},
+    {"stem_pool", &DvidOptions::stem_pool, 0, 1},   {"head_tail", &DvidOptions::head_tail, 0, 1},   {"roi_fuse", &DvidOptions::roi_fuse, 0, 1},   {"ln_rows", &DvidOptions::ln_rows, 0, 1},
     {"igemm_cfg", &DvidOptions::igemm_cfg, -1, 255}, {"igemm_tune", &DvidOptions::igemm_tune, -1, 1}, {"igemm_generic", &DvidOptions::igemm_generic, 0, 1},
     {"f32_split", &DvidOptions::f32_split, 0, 1},    {"f32_wstat", &DvidOptions::f32_wstat, 0, 2},    {"f32_conv3x3", &DvidOptions::f32_conv3x3, 0, 1},
     {"bneck_lds", &DvidOptions::bneck_lds, 0, 160 * 1024},

@@ -12,6 +12,7 @@ struct DvidOptions {
     int bneck_fuse = 1;      // res2 / res3 bottleneck tails as one launch (csrc/bneck.hip)
     int stem_pool = 1;       // stem + ReLU + max pool as one launch (csrc/conv3x3.hip: stem_pool_kernel); 0 / 1
     int head_tail = 1;       // FFN .. apply_deltas of a head pass as one row-tile kernel (csrc/headtail.hip); 0 = layer by layer
+    int roi_fuse = 1;        // RoIAlign gathered straight into DynamicConv's LDS tile (csrc/dynconv.hip, one launch instead of two; bit-identical) wherever a head pass gets its proposal features from the caller; 0 / 1
     int ln_rows = 1;         // LayerNorm at d = 128 / 256: several rows per wave (bit-identical to one row per wave); 0 / 1
     int igemm_cfg = -1;      // >= 0: force this igemm2 tile configuration wherever it is valid (bit-identity tests); -1 = the tuner
     int igemm_tune = -1;     // 1 = time new shape buckets, 0 = never time, -1 = DVID_IGEMM_TUNE if set, else 0 when DVID_IGEMM_TUNE_CACHE holds winners, else 1

@@ -248,6 +248,37 @@ def test_rcnn_head(dv, cond):
     model.close()
 
 
+@pytest.mark.parametrize("cond", [False, True])
+def test_roi_fused_dynconv_bit_identical(dv, cond):
+    """RoIAlign gathered straight into DynamicConv's LDS tile (csrc/dynconv.hip FUSED_ROI, library option roi_fuse = 1, the default for
+    a pass with incoming proposal features) against the two launches (roi_fuse = 0): one copy of the tap arithmetic (csrc/roi_taps.h),
+    the same fp16 tile, so every output of the head pass is the same bit for bit -- incl. zero-area, oversize and edge boxes."""
+    sd, _ = _head_setup()
+    g = torch.Generator().manual_seed(21)
+    n, M, H, W = 3, 300, 160, 256
+    feats = [f * 0.5 for f in _pyramid(g, n, H, W)]
+    boxes = _boxes(g, n, M, H, W)
+    boxes[0, 0] = torch.tensor([10.0, 10.0, 14.0, 13.0])
+    boxes[1, 5] = torch.tensor([40.0, 40.0, 40.0, 40.0])                # zero area
+    boxes[2, 7] = torch.tensor([-30.0, -20.0, 400.0, 300.0])            # beyond the image on every side
+    t = torch.tensor([999, 499, 249], dtype=torch.long)
+    pro = torch.randn(n * M, 256, generator=g)
+    cnd = torch.randn(n * M, 256, generator=g) if cond else None
+    fd = [dv.nhwc_from_nchw(f.cuda()) for f in feats]
+    outs = {}
+    for mode in (0, 1):
+        dv.set_option("roi_fuse", mode)
+        try:
+            model = dv.Model(sd, res_blocks=(0, 0, 0, 0))
+            model.reserve(n, H, W, M)
+            outs[mode] = tuple(x.clone() for x in model.rcnn_head(0 if cond else 1, fd, H, W, boxes.cuda(), pro.cuda(), t, cond=None if cnd is None else cnd.cuda()))
+            model.close()
+        finally:
+            dv.reset_options()
+    for a, b, name in zip(outs[0], outs[1], ("logits", "boxes", "obj_features")):
+        assert torch.equal(a, b), f"{name}: fused and unfused head passes differ, max |d| {(a.float() - b.float()).abs().max().item():.3e}"
+
+
 def test_head_kernels_against_full_dimension_reference_fixture(dv):
     """dvid_rcnn_head and dvid_dynconv against the REFERENCE's own RCNNHead / RCNNHead_cond / DynamicConv at the kernels'
     dimensions (256 / 8 / 2048 / 64, 300 boxes), no oracle in between: tests/golden/g16_full_dim_head.npz holds inputs and
